@@ -1,0 +1,391 @@
+// Flash-style fused attention for the 2Haff hot path on MI355X (gfx950), bf16 MFMA, fp32 softmax.
+//
+// One kernel family covers every attention on the reference path:
+//   * SAM ViT-H windowed (14x14=196 tokens) and global (64x64=4096 tokens) attention with decomposed
+//     relative-position bias            (2Haff/model/segment_anything/modeling/image_encoder.py:235-260,354-392)
+//   * CLIP ViT-L/14 self-attention, S=257, d=64   (transformers CLIPAttention, reached from clip_encoder.py:53-56)
+//   * Llama causal self-attention, d=128, prefill and KV-cached decode (transformers LlamaAttention,
+//     reached from llava_llama.py:93-102)
+//   * SAM two-way decoder attentions (d=16/32)      (segment_anything/modeling/transformer.py:185-242)
+//
+//   scores = scale * (q . k) + bias(q, k)   [+ causal mask]  ;  out = softmax(scores) @ v
+//
+// Layout/tiling (CDNA4): workgroup = 4 waves = 128 query rows (32 per wave), KV tile = 64 keys.
+// The score MFMA is issued swapped (S^T = K . Q^T with v_mfma_f32_16x16x32_bf16): each lane then owns ONE
+// query column and 4 keys per 16x16 tile, so the online softmax is lane-local except for a 2-step
+// cross-lane max, the exponentiated tile is already the B operand of the P.V MFMA (k-order permuted
+// consistently on both operands) and V^T fragments come straight from the row-major LDS image through
+// ds_read_b64_tr_b16 (no transposed copy of V anywhere). K/V tiles are register-staged (issue the next
+// tile's global loads before the MFMAs, write them to LDS after the barrier) with padded rows
+// (K: 2D+16 B, V: 2D+32 B) so ds_read_b128 / tr reads are bank-conflict free.
+// Rel-pos bias comes from per-query tables relh[q][kh], relw[q][kw] (haff_relpos_tables): BIAS=2 keeps
+// relw in registers when a KV tile is exactly one key-grid row (global attention, S=64); BIAS=1 looks
+// both terms up in an LDS copy (windows, S<=16).
+#include "haff_common.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v;
+  bf16_t* o;
+  long q_sb, q_sh, q_st;
+  long k_sb, k_sh, k_st;
+  long v_sb, v_sh, v_st;
+  long o_sb, o_sh, o_st;
+  int B, H, Nq, Nk, d;
+  float scale;
+  int q_pos0;  // causal: key j visible to query i iff j <= i + q_pos0
+  const float *relh, *relw;  // [B*H][Nq][S]
+  int S;
+};
+
+constexpr int QB = 128;   // queries per workgroup
+constexpr int KT = 64;    // keys per tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef __attribute__((address_space(3))) bf16x4* lds_v4_ptr;
+
+template <int DP, int BIAS, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int KSTRIDE = DP * 2 + 16;  // bytes
+  constexpr int VSTRIDE = DP * 2 + 32;
+  constexpr int NCH = DP / 32;          // 16-B chunks per thread per operand per tile
+  constexpr int CPR = DP / 8;           // chunks per row
+  constexpr int ND = DP / 16;           // output d-tiles
+  constexpr int NKD = DP / 32;          // k-steps over head dim
+  constexpr int SMAX = 16;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* sK = smem_raw;
+  unsigned char* sV = smem_raw + KT * KSTRIDE;
+  float* sRel = reinterpret_cast<float*>(smem_raw + KT * KSTRIDE + KT * VSTRIDE);  // [QB][2*SMAX] when BIAS==1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int fr = lane & 15, fh = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * QB;
+
+  const bf16_t* qb = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
+  const bf16_t* kb = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
+  const bf16_t* vb = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
+
+  // ---- Q fragments (B operand: lane = (query fr, d-chunk fh)) ----
+  bf16x8 qf[2][NKD];
+  int qrow[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qi = q0 + wave * 32 + qt * 16 + fr;
+    qrow[qt] = qi;
+    const int qc = min(qi, p.Nq - 1);
+#pragma unroll
+    for (int kd = 0; kd < NKD; ++kd) {
+      const int col = kd * 32 + fh * 8;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (col < p.d) r = *reinterpret_cast<const uint4*>(qb + (long)qc * p.q_st + col);
+      qf[qt][kd] = __builtin_bit_cast(bf16x8, r);
+    }
+  }
+
+  // ---- bias setup ----
+  float relw_r[2][4][4];
+  const float* relh_row[2];
+  if (BIAS == 2) {
+    const long bh = (long)b * p.H + h;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qc = min(qrow[qt], p.Nq - 1);
+      const float* rw = p.relw + (bh * p.Nq + qc) * p.S;
+      relh_row[qt] = p.relh + (bh * p.Nq + qc) * p.S;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float4 f = *reinterpret_cast<const float4*>(rw + 16 * t + 4 * fh);
+        relw_r[qt][t][0] = f.x; relw_r[qt][t][1] = f.y; relw_r[qt][t][2] = f.z; relw_r[qt][t][3] = f.w;
+      }
+    }
+  }
+  if (BIAS == 1) {
+    const long bh = (long)b * p.H + h;
+    for (int i = tid; i < QB * 2 * p.S; i += 256) {
+      const int ql = i / (2 * p.S);
+      const int j = i - ql * 2 * p.S;
+      const int qc = min(q0 + ql, p.Nq - 1);
+      const float val = (j < p.S) ? p.relh[(bh * p.Nq + qc) * p.S + j] : p.relw[(bh * p.Nq + qc) * p.S + (j - p.S)];
+      sRel[ql * 2 * SMAX + j] = val;
+    }
+  }
+
+  // ---- K/V staging coordinates ----
+  int st_row[NCH], st_c[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = tid + i * 256;
+    st_row[i] = id / CPR;
+    st_c[i] = id - st_row[i] * CPR;
+  }
+  uint4 kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int key = min(kt * KT + st_row[i], p.Nk - 1);
+      const int col = st_c[i] * 8;
+      kreg[i] = make_uint4(0, 0, 0, 0);
+      vreg[i] = make_uint4(0, 0, 0, 0);
+      if (col < p.d) {
+        kreg[i] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st + col);
+        vreg[i] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st + col);
+      }
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<uint4*>(sK + st_row[i] * KSTRIDE + st_c[i] * 16) = kreg[i];
+      *reinterpret_cast<uint4*>(sV + st_row[i] * VSTRIDE + st_c[i] * 16) = vreg[i];
+    }
+  };
+
+  f32x4 oacc[ND][2];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt) {
+    oacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    oacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float m_run[2] = {-1e30f, -1e30f};
+  float l_run[2] = {0.f, 0.f};
+
+  int nkt = (p.Nk + KT - 1) / KT;
+  if (CAUSAL) {
+    const int last_q = min(q0 + QB - 1, p.Nq - 1);
+    const int last_key = min(last_q + p.q_pos0, p.Nk - 1);
+    nkt = min(nkt, last_key / KT + 1);
+  }
+
+  load_tile(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // previous tile's LDS reads are done
+    write_tile();
+    __syncthreads();
+    if (kt + 1 < nkt) load_tile(kt + 1);  // in flight during the MFMAs below
+
+    // ---- S^T = K . Q^T ----
+    f32x4 sacc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kd = 0; kd < NKD; ++kd) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (16 * t + fr) * KSTRIDE + (kd * 4 + fh) * 16);
+        sacc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][kd], sacc[t][0], 0, 0, 0);
+        sacc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][kd], sacc[t][1], 0, 0, 0);
+      }
+    }
+
+    // ---- scale, bias, mask, online softmax (lane owns query column fr of each q-tile) ----
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float s[4][4];
+      float relh_v = 0.f;
+      if (BIAS == 2) relh_v = relh_row[qt][kt];
+      const int ql = wave * 32 + qt * 16 + fr;
+      float mx = -1e30f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * KT + 16 * t + 4 * fh + r;
+          float v = sacc[t][qt][r] * p.scale;
+          if (BIAS == 2) v += relh_v + relw_r[qt][t][r];
+          if (BIAS == 1) {
+            const int kc = min(key, p.Nk - 1);
+            const int kh = kc / p.S;
+            const int kw = kc - kh * p.S;
+            v += sRel[ql * 2 * SMAX + kh] + sRel[ql * 2 * SMAX + p.S + kw];
+          }
+          bool ok = key < p.Nk;
+          if (CAUSAL) ok = ok && (key <= qrow[qt] + p.q_pos0);
+          v = ok ? v : -INFINITY;
+          s[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = exp2f((m_run[qt] - m_new) * LOG2E);
+      m_run[qt] = m_new;
+      float psum = 0.f;
+      const float mb = m_new * LOG2E;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(s[t][r] * LOG2E - mb);
+          s[t][r] = e;
+          psum += e;
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
+        oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+      }
+      // P^T fragment for k-step ks: slots j<4 <- tile 2ks (keys 4fh+j), j>=4 <- tile 2ks+1
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 u;
+        u.x = pack_bf16x2(s[2 * ks][0], s[2 * ks][1]);
+        u.y = pack_bf16x2(s[2 * ks][2], s[2 * ks][3]);
+        u.z = pack_bf16x2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
+        u.w = pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+        pf[qt][ks] = __builtin_bit_cast(bf16x8, u);
+      }
+    }
+
+    // ---- O^T += V^T . P^T  (V^T fragments via transposed LDS reads, same permuted k order) ----
+    const int tr_q = fr >> 2, tr_p = fr & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const unsigned char* a0 = sV + (16 * (2 * ks) + 4 * fh + tr_q) * VSTRIDE + (16 * dt + 4 * tr_p) * 2;
+        const unsigned char* a1 = a0 + 16 * VSTRIDE;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_ptr)(a0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_ptr)(a1));
+        const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        oacc[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][ks], oacc[dt][0], 0, 0, 0);
+        oacc[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][ks], oacc[dt][1], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- finalize: out[q][16dt + 4fh + r] = O^T / l ----
+  bf16_t* ob = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qrow[qt] < p.Nq) {
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const int col = 16 * dt + 4 * fh;
+        if (col < p.d) {
+          float v[4] = {oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv, oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv};
+          store4(ob + (long)qrow[qt] * p.o_st + col, v);
+        }
+      }
+    }
+  }
+}
+
+template <int DP, int BIAS, bool CAUSAL>
+int launch_attn(const AttnArgs& p, hipStream_t s) {
+  constexpr int KSTRIDE = DP * 2 + 16, VSTRIDE = DP * 2 + 32;
+  size_t lds = (size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE;
+  if (BIAS == 1) lds += (size_t)QB * 2 * 16 * sizeof(float);
+  dim3 grid((p.Nq + QB - 1) / QB, p.H, p.B), block(256);
+  hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL>), grid, block, lds, s, p);
+  return haff_check_launch();
+}
+
+}  // namespace
+
+// q/k/v/o: bf16; strides in elements (batch, head, token). d % 8 == 0, d <= 128.
+// causal != 0: key j visible to query i iff j <= i + q_pos0.
+// relh/relw (may be null): fp32 [B*H][Nq][S] decomposed rel-pos terms; key index -> (kh, kw) = (j / S, j % S).
+extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_st,
+                                   const void* k, long k_sb, long k_sh, long k_st,
+                                   const void* v, long v_sb, long v_sh, long v_st,
+                                   void* o, long o_sb, long o_sh, long o_st,
+                                   int B, int H, int Nq, int Nk, int d, float scale,
+                                   int causal, int q_pos0,
+                                   const float* relh, const float* relw, int S, void* stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d > 128 || (d & 7)) return HAFF_ERR_BAD_ARG;
+  if ((q_st & 7) || (k_st & 7) || (v_st & 7) || (o_st & 3) || (q_sh & 7) || (k_sh & 7) || (v_sh & 7) || (o_sh & 3) ||
+      (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (o_sb & 3))
+    return HAFF_ERR_BAD_ARG;
+  const bool rel = relh != nullptr && relw != nullptr;
+  if (rel && (causal || S <= 0 || (Nk % S) != 0)) return HAFF_ERR_BAD_ARG;
+  AttnArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
+             reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
+             B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int dp = d <= 64 ? 64 : (d <= 96 ? 96 : 128);
+  if (rel) {
+    const int mode = (S == 64) ? 2 : 1;
+    if (mode == 1 && S > 16) return HAFF_ERR_UNSUPPORTED;
+    if (dp == 64) return mode == 2 ? launch_attn<64, 2, false>(p, s) : launch_attn<64, 1, false>(p, s);
+    if (dp == 96) return mode == 2 ? launch_attn<96, 2, false>(p, s) : launch_attn<96, 1, false>(p, s);
+    return mode == 2 ? launch_attn<128, 2, false>(p, s) : launch_attn<128, 1, false>(p, s);
+  }
+  if (causal) {
+    if (dp == 64) return launch_attn<64, 0, true>(p, s);
+    if (dp == 96) return launch_attn<96, 0, true>(p, s);
+    return launch_attn<128, 0, true>(p, s);
+  }
+  if (dp == 64) return launch_attn<64, 0, false>(p, s);
+  if (dp == 96) return launch_attn<96, 0, false>(p, s);
+  return launch_attn<128, 0, false>(p, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Decomposed rel-pos tables (image_encoder.py:376-384): relh[bh][q][kh] = q_vec . Rh[qh - kh + S - 1],
+// relw[bh][q][kw] = q_vec . Rw[qw - kw + S - 1], with the UNSCALED q (image_encoder.py:244-248).
+// q: bf16 (dtype 0) or f32 (dtype 1) with (batch, head, token) strides; tables: fp32 [2S-1][d]; outputs fp32 [B*H][N][S], N = S*S.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_tables_kernel(const T* q, long q_sb, long q_sh, long q_st,
+                                                          const float* tab_h, const float* tab_w,
+                                                          float* relh, float* relw, int H, int S, int d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sq = reinterpret_cast<float*>(smem_raw);  // [QPB][d+1]
+  const int N = S * S;
+  const int QPB = 32;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QPB;
+  const T* qb = q + (long)b * q_sb + (long)h * q_sh;
+  for (int i = threadIdx.x; i < QPB * d; i += 256) {
+    const int ql = i / d, c = i - ql * d;
+    const int qi = min(q0 + ql, N - 1);
+    sq[ql * (d + 1) + c] = elem<T>::ld(qb + (long)qi * q_st + c);
+  }
+  __syncthreads();
+  const long bh = (long)b * H + h;
+  for (int i = threadIdx.x; i < QPB * 2 * S; i += 256) {
+    const int ql = i / (2 * S);
+    const int j = i - ql * 2 * S;
+    const int qi = q0 + ql;
+    if (qi >= N) continue;
+    const int qh = qi / S, qw = qi - qh * S;
+    const bool is_h = j < S;
+    const int kk = is_h ? j : j - S;
+    const float* trow = (is_h ? tab_h + (long)(qh - kk + S - 1) * d : tab_w + (long)(qw - kk + S - 1) * d);
+    float acc = 0.f;
+    for (int c = 0; c < d; ++c) acc += sq[ql * (d + 1) + c] * trow[c];
+    (is_h ? relh : relw)[(bh * N + qi) * S + kk] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int haff_relpos_tables(const void* q, long q_sb, long q_sh, long q_st,
+                                  const float* tab_h, const float* tab_w, float* relh, float* relw,
+                                  int B, int H, int S, int d, int dtype, void* stream) {
+  if (B <= 0 || H <= 0 || S <= 0 || d <= 0) return HAFF_ERR_BAD_ARG;
+  const int N = S * S;
+  dim3 grid((N + 31) / 32, H, B), block(256);
+  size_t lds = (size_t)32 * (d + 1) * sizeof(float);
+  if (dtype == 0)
+    hipLaunchKernelGGL((relpos_tables_kernel<bf16_t>), grid, block, lds, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(q), q_sb, q_sh, q_st, tab_h, tab_w, relh, relw, H, S, d);
+  else
+    hipLaunchKernelGGL((relpos_tables_kernel<float>), grid, block, lds, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float*>(q), q_sb, q_sh, q_st, tab_h, tab_w, relh, relw, H, S, d);
+  return haff_check_launch();
+}

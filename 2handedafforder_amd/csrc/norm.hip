@@ -1,0 +1,130 @@
+// Row normalisation kernels (HBM-bound): one 64-lane wave per row, 16-byte vector loads, fp32 statistics.
+//
+//   haff_layernorm : nn.LayerNorm over the last dim, biased variance, y = (x-mean)/sqrt(var+eps)*w+b
+//       SAM encoder norm1/norm2 eps 1e-6 (build_sam.py:77, image_encoder.py:160,170,179,191)
+//       LayerNorm2d of the neck / upscaler on channels-last data (common.py:31-43)
+//       SAM decoder norms eps 1e-5 (transformer.py:60,134-144); CLIP pre_layrnorm / layer_norm1/2 eps 1e-5
+//     with an optional GATHER map: out row i reads in row in_map[i]; in_map[i] < 0 writes zeros. This fuses
+//     window_partition's zero padding, which the reference applies AFTER norm1 (image_encoder.py:179-183,276-288).
+//   haff_rmsnorm  : Llama RMSNorm, fp32 variance (transformers LlamaRMSNorm; input/post-attention/final norm)
+#include "haff_common.h"
+
+namespace {
+
+template <typename T, int NCH, bool RMS>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const T* x, long ldx, T* y, long ldy, const float* w,
+                                                       const float* bvec, const int* in_map, int rows, int C,
+                                                       float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long src = row;
+  if (in_map) {
+    const int mrow = in_map[row];
+    if (mrow < 0) {
+      const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < C) store8(y + (long)row * ldy + c, z);
+      }
+      return;
+    }
+    src = mrow;
+  }
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < C) {
+      load8(x + src * ldx + c, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += RMS ? v[i][j] * v[i][j] : v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  sum = wave_sum(sum);
+  float mean = 0.f, rstd;
+  if (RMS) {
+    rstd = 1.0f / sqrtf(sum / (float)C + eps);
+  } else {
+    mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dlt = v[i][j] - mean;
+          sq += dlt * dlt;
+        }
+      }
+    }
+    sq = wave_sum(sq);
+    rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < C) {
+      float wv[8], o[8];
+      load8(w + c, wv);
+      if (RMS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * wv[j];
+      } else {
+        float bb[8];
+        load8(bvec + c, bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bb[j];
+      }
+      store8(y + (long)row * ldy + c, o);
+    }
+  }
+}
+
+template <typename T, bool RMS>
+int launch_norm(const void* x, long ldx, void* y, long ldy, const float* w, const float* b, const int* in_map,
+                int rows, int C, float eps, hipStream_t s) {
+  const int nch = (C + 511) / 512;
+  dim3 grid((rows + 3) / 4), block(256);
+  const T* xp = reinterpret_cast<const T*>(x);
+  T* yp = reinterpret_cast<T*>(y);
+#define HAFF_NORM_CASE(N)                                                                                   \
+  if (nch <= N) {                                                                                           \
+    hipLaunchKernelGGL((norm_rows_kernel<T, N, RMS>), grid, block, 0, s, xp, ldx, yp, ldy, w, b, in_map, rows, C, eps); \
+    return haff_check_launch();                                                                             \
+  }
+  HAFF_NORM_CASE(1)
+  HAFF_NORM_CASE(2)
+  HAFF_NORM_CASE(3)
+  HAFF_NORM_CASE(4)
+  HAFF_NORM_CASE(8)
+  HAFF_NORM_CASE(10)
+  HAFF_NORM_CASE(16)
+#undef HAFF_NORM_CASE
+  return HAFF_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// dtype: 0 = bf16, 1 = f32 (x and y). w, b fp32 [C]. C % 8 == 0, C <= 8192, ldx/ldy % 8 == 0.
+extern "C" int haff_layernorm(const void* x, long ldx, void* y, long ldy, const float* w, const float* b,
+                              const int* in_map, int rows, int C, float eps, int dtype, void* stream) {
+  if (rows <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7) || !w || !b) return HAFF_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == 0 ? launch_norm<bf16_t, false>(x, ldx, y, ldy, w, b, in_map, rows, C, eps, s)
+                    : launch_norm<float, false>(x, ldx, y, ldy, w, b, in_map, rows, C, eps, s);
+}
+
+extern "C" int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const float* w, int rows, int C,
+                            float eps, int dtype, void* stream) {
+  if (rows <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7) || !w) return HAFF_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == 0 ? launch_norm<bf16_t, true>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s)
+                    : launch_norm<float, true>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s);
+}

@@ -1,0 +1,98 @@
+"""ctypes binding of libhaff_hip.so (the C-ABI declared in include/haff_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol is absent this module raises.
+`build_library()` compiles it in-tree with hipcc for gfx950 (works without a GPU: hipcc cross-compiles).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhaff_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes ; every entry point returns int (0 ok, <0 error) — mirrors include/haff_hip.h
+_PROTOS = {
+    "haff_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
+                       c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_gemm_f32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
+                      c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
+                            c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
+                            c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
+                            c_void_p],
+    "haff_attention_f32": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
+                           c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
+                           c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
+                           c_void_p],
+    "haff_relpos_tables": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_layernorm": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                       c_int, c_void_p],
+    "haff_rmsnorm": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    "haff_patchify_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                           c_void_p],
+    "haff_patchify_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                         c_int, c_void_p],
+    "haff_im2col3x3": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_embed_splice": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                          c_void_p],
+    "haff_rope_cache": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                        c_int, c_int, c_void_p],
+    "haff_argmax_rows": [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p],
+    "haff_add_bcast": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
+    "haff_softmax_rows": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "haff_upscale_mask": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                          c_float, c_int, c_void_p],
+    "haff_resize_bilinear": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_threshold_masks": [c_void_p, c_void_p, c_long, c_float, c_void_p],
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))
+
+_lib = None
+
+
+class HaffLibraryError(RuntimeError):
+    pass
+
+
+def build_library(verbose=False):
+    """Compile every HIP source for gfx950 into lib/libhaff_hip.so (in-tree, so it travels with the repo)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j8"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-8000:])
+    if res.returncode != 0:
+        raise HaffLibraryError("hipcc build of libhaff_hip.so failed")
+    return LIB_PATH
+
+
+def load_library():
+    """dlopen the library and attach prototypes. Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HaffLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU or eager fallback for the hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HaffLibraryError(f"symbol {name} missing from {LIB_PATH}") from e
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HaffLibraryError(f"{what} failed with code {rc} "
+                               "(-1 bad argument, -2 unsupported shape, -3 launch error)")

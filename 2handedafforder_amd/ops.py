@@ -1,0 +1,272 @@
+"""Tensor-level wrappers over the C-ABI of libhaff_hip.so.
+
+torch is used here only for device memory and the current HIP stream; every arithmetic op below is a
+hand-written HIP kernel. All functions require CUDA(HIP) tensors and raise if the library is missing.
+dtype policy: torch.bfloat16 = throughput mode (bf16 MFMA, fp32 accumulate), torch.float32 = parity mode.
+"""
+import torch
+
+from .lib import check, load_library
+
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3, 4
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return 0
+    if t.dtype == torch.float32:
+        return 1
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live in HBM (cuda tensor); the hot path has no CPU fallback")
+
+
+def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, out_rows=None, out_dtype=None,
+           swiglu=False):
+    """y = epi(x @ w.T): x [M,K] (row stride free, unit inner stride), w [N,K], bias fp32 [N] or None.
+
+    epilogue order: +bias -> act -> +resid (resid indexed like out). row_map (int32 [M]) redirects output
+    (and residual) rows, negative entries are dropped. swiglu: w rows interleaved [gate x16 | up x16], N -> N/2.
+    """
+    lib = load_library()
+    _req(x, "x")
+    assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (x.shape, w.shape)
+    n_out = N // 2 if swiglu else N
+    if out_dtype is None:
+        out_dtype = x.dtype
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else M, n_out), dtype=out_dtype, device=x.device)
+    assert out.stride(1) == 1 and out.shape[1] == n_out
+    if resid is not None:
+        assert resid.dtype == out.dtype and resid.stride(1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    if row_map is not None:
+        assert row_map.dtype == torch.int32 and row_map.numel() == M
+    if x.dtype == torch.bfloat16:
+        assert w.dtype == torch.bfloat16
+        rc = lib.haff_gemm_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                                _p(bias), _p(resid), 0 if resid is None else resid.stride(0), _p(row_map),
+                                M, N, K, act, 1 if out.dtype == torch.float32 else 0, 1 if swiglu else 0, _stream())
+    else:
+        assert w.dtype == torch.float32 and out.dtype == torch.float32
+        rc = lib.haff_gemm_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                               _p(bias), _p(resid), 0 if resid is None else resid.stride(0), _p(row_map),
+                               M, N, K, act, 1 if swiglu else 0, _stream())
+    check(rc, "haff_gemm")
+    return out
+
+
+def attention(q, k, v, scale, causal=False, q_pos0=0, relh=None, relw=None, S=0, out=None):
+    """q [B,H,Nq,d], k/v [B,H,Nk,d] strided views (unit stride on d). Returns out [B,Nq,H*d] (token-major)."""
+    lib = load_library()
+    _req(q, "q")
+    B, H, Nq, d = q.shape
+    Nk = k.shape[2]
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    if out is None:
+        out = torch.empty((B, Nq, H * d), dtype=q.dtype, device=q.device)
+    o4 = out.view(B, Nq, H, d).permute(0, 2, 1, 3)
+    args = [q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+            k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+            v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+            out.data_ptr(), o4.stride(0), o4.stride(1), o4.stride(2),
+            B, H, Nq, Nk, d, float(scale), 1 if causal else 0, int(q_pos0), _p(relh), _p(relw), int(S), _stream()]
+    if relh is not None:
+        assert relh.dtype == torch.float32 and relh.is_contiguous() and relw.is_contiguous()
+    if q.dtype == torch.bfloat16:
+        rc = lib.haff_attention_bf16(*args)
+    else:
+        rc = lib.haff_attention_f32(*args)
+    check(rc, "haff_attention")
+    return out
+
+
+def relpos_tables(q, tab_h, tab_w, S):
+    """q [B,H,N,d] view with N == S*S; tab_* fp32 [2S-1,d]. Returns relh, relw fp32 [B*H,N,S]."""
+    lib = load_library()
+    B, H, N, d = q.shape
+    assert N == S * S and tab_h.shape == (2 * S - 1, d) and tab_h.dtype == torch.float32
+    relh = torch.empty((B * H, N, S), dtype=torch.float32, device=q.device)
+    relw = torch.empty_like(relh)
+    rc = lib.haff_relpos_tables(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(),
+                                tab_w.data_ptr(), relh.data_ptr(), relw.data_ptr(), B, H, S, d, _dt(q), _stream())
+    check(rc, "haff_relpos_tables")
+    return relh, relw
+
+
+def layernorm(x, w, b, eps, in_map=None, out=None):
+    """x [R,C]; optional gather map (int32 [R_out], <0 -> zero row)."""
+    lib = load_library()
+    _req(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows = x.shape[0] if in_map is None else in_map.numel()
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty((rows, C), dtype=x.dtype, device=x.device)
+    rc = lib.haff_layernorm(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), w.data_ptr(), b.data_ptr(),
+                            _p(in_map), rows, C, float(eps), _dt(x), _stream())
+    check(rc, "haff_layernorm")
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    lib = load_library()
+    _req(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x)
+    rc = lib.haff_rmsnorm(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), w.data_ptr(), x.shape[0],
+                          x.shape[1], float(eps), _dt(x), _stream())
+    check(rc, "haff_rmsnorm")
+    return out
+
+
+def patchify_nchw(x, P, gh, gw, Kp, out_dtype):
+    lib = load_library()
+    _req(x, "x")
+    x = x.contiguous()
+    B, Cin, Hin, Win = x.shape
+    out = torch.empty((B * gh * gw, Kp), dtype=out_dtype, device=x.device)
+    rc = lib.haff_patchify_nchw(x.data_ptr(), out.data_ptr(), B, Cin, Hin, Win, P, gh, gw, Kp, _dt(x), _dt(out),
+                                _stream())
+    check(rc, "haff_patchify_nchw")
+    return out
+
+
+def patchify_u8(frames, P, gh, gw, Kp, mean3, std3, out_dtype):
+    """frames uint8 NHWC [B,Hf,Wf,3]; mean3/std3 host sequences of 3 floats (0..255 scale)."""
+    import ctypes
+    lib = load_library()
+    _req(frames, "frames")
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.shape[3] == 3
+    B, Hf, Wf, _ = frames.shape
+    out = torch.empty((B * gh * gw, Kp), dtype=out_dtype, device=frames.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std3])
+    rc = lib.haff_patchify_u8(frames.data_ptr(), out.data_ptr(), B, Hf, Wf, P, gh, gw, Kp,
+                              ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), _dt(out), _stream())
+    check(rc, "haff_patchify_u8")
+    return out
+
+
+def im2col3x3(x):
+    """x [B,H,W,C] channels-last contiguous -> [B*H*W, 9*C]."""
+    lib = load_library()
+    _req(x, "x")
+    assert x.is_contiguous()
+    B, H, W, C = x.shape
+    out = torch.empty((B * H * W, 9 * C), dtype=x.dtype, device=x.device)
+    rc = lib.haff_im2col3x3(x.data_ptr(), out.data_ptr(), B, H, W, C, _dt(x), _stream())
+    check(rc, "haff_im2col3x3")
+    return out
+
+
+def embed_splice(ids, img_pos, embed, img):
+    """ids int64 [B,L] (sentinel < 0 at img_pos[b]); embed [V,Hd]; img [B,n_img,Hd] -> [B, L+n_img-1, Hd]."""
+    lib = load_library()
+    _req(ids, "ids")
+    B, L = ids.shape
+    n_img, Hd = img.shape[1], img.shape[2]
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and img.is_contiguous() and embed.is_contiguous()
+    assert img_pos.dtype == torch.int32
+    out = torch.empty((B, L + n_img - 1, Hd), dtype=embed.dtype, device=embed.device)
+    rc = lib.haff_embed_splice(ids.data_ptr(), img_pos.data_ptr(), embed.data_ptr(), img.data_ptr(), out.data_ptr(),
+                               B, L, n_img, Hd, _dt(embed), _stream())
+    check(rc, "haff_embed_splice")
+    return out
+
+
+def rope_cache(qkv, kcache, vcache, cos_sin, B, Tq, Hq, Hkv, d, pos0):
+    """qkv [B*Tq, (Hq+2Hkv)*d] rotated in place; k,v appended to caches [B,Tmax,Hkv*d]."""
+    lib = load_library()
+    _req(qkv, "qkv")
+    Tmax = kcache.shape[1]
+    assert kcache.is_contiguous() and vcache.is_contiguous() and cos_sin.dtype == torch.float32
+    rc = lib.haff_rope_cache(qkv.data_ptr(), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(), cos_sin.data_ptr(),
+                             B, Tq, Hq, Hkv, d, pos0, Tmax, _dt(qkv), _stream())
+    check(rc, "haff_rope_cache")
+
+
+def argmax_rows(logits):
+    lib = load_library()
+    _req(logits, "logits")
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    out = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
+    rc = lib.haff_argmax_rows(logits.data_ptr(), logits.stride(0), out.data_ptr(), logits.shape[0], logits.shape[1],
+                              _stream())
+    check(rc, "haff_argmax_rows")
+    return out
+
+
+def add_bcast(a, b, mod=None, out=None):
+    """out[r] = a[r] + b[r % mod]; a [R,C], b [mod,C]."""
+    lib = load_library()
+    _req(a, "a")
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
+    R, C = a.shape
+    mod = b.shape[0] if mod is None else mod
+    if out is None:
+        out = torch.empty_like(a)
+    rc = lib.haff_add_bcast(a.data_ptr(), b.data_ptr(), out.data_ptr(), R, C, mod, _dt(a), _stream())
+    check(rc, "haff_add_bcast")
+    return out
+
+
+def softmax_rows(x):
+    lib = load_library()
+    _req(x, "x")
+    assert x.is_contiguous() and x.dim() == 2
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    rc = lib.haff_softmax_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _dt(x), _stream())
+    check(rc, "haff_softmax_rows")
+    return out
+
+
+def upscale_mask(up1, ln_w, ln_b, w2, b2, hyper, n_prompts, h, w, eps=1e-6):
+    lib = load_library()
+    _req(up1, "up1")
+    assert up1.is_contiguous() and up1.shape == (n_prompts * h * w, 256)
+    assert hyper.dtype == torch.float32 and hyper.is_contiguous() and hyper.shape == (n_prompts, 32)
+    out = torch.empty((n_prompts, 4 * h, 4 * w), dtype=torch.float32, device=up1.device)
+    rc = lib.haff_upscale_mask(up1.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                               hyper.data_ptr(), out.data_ptr(), n_prompts, h, w, float(eps), _dt(up1), _stream())
+    check(rc, "haff_upscale_mask")
+    return out
+
+
+def resize_bilinear(x, crop_hw, out_hw):
+    """x fp32 [N,Hs,Ws]; resample its top-left crop to out_hw (F.interpolate bilinear, align_corners=False)."""
+    lib = load_library()
+    _req(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    N, Hs, Ws = x.shape
+    out = torch.empty((N, out_hw[0], out_hw[1]), dtype=torch.float32, device=x.device)
+    rc = lib.haff_resize_bilinear(x.data_ptr(), out.data_ptr(), N, Hs, Ws, int(crop_hw[0]), int(crop_hw[1]),
+                                  int(out_hw[0]), int(out_hw[1]), _stream())
+    check(rc, "haff_resize_bilinear")
+    return out
+
+
+def threshold_masks(x, logit_th=0.0):
+    lib = load_library()
+    _req(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    rc = lib.haff_threshold_masks(x.data_ptr(), out.data_ptr(), x.numel(), float(logit_th), _stream())
+    check(rc, "haff_threshold_masks")
+    return out

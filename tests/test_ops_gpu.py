@@ -1,0 +1,347 @@
+"""Op-level numerics: every HIP kernel (through the C-ABI) against a plain PyTorch fp32 reference of the same op.
+
+Tolerances: bf16 kernels read bf16-rounded inputs and round their output to bf16 once (rel 2^-8 per element);
+the reference is computed in fp32 from the SAME bf16-rounded inputs, so the bound is a few bf16 ulps of the
+output scale. fp32 (parity-mode) kernels must agree to ~1e-5 relative.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import haff  # noqa: F401
+    from haff import ops
+    return ops
+
+
+def _close(got, ref, rel, what):
+    got = got.float()
+    ref = ref.float()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert math.isfinite(err), f"{what}: non-finite output"
+    assert err <= rel * scale, f"{what}: max|err|={err:.4g} vs scale {scale:.4g} (rel {err / scale:.3g} > {rel})"
+
+
+def _rand(shape, dev, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+ACT_REF = {
+    0: lambda x: x,
+    1: lambda x: F.gelu(x),
+    2: lambda x: x * torch.sigmoid(1.702 * x),
+    3: lambda x: F.relu(x),
+    4: lambda x: F.silu(x),
+}
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1000, 384, 1280), (37, 1003, 256), (4900, 256, 128)])
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_bf16_epilogues(dev, M, N, K, act):
+    ops = _ops()
+    x = _rand((M, K), dev, torch.bfloat16, 1)
+    w = _rand((N, K), dev, torch.bfloat16, 2, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 3)
+    resid = _rand((M, N), dev, torch.bfloat16, 4)
+    ref = ACT_REF[act](x.float() @ w.float().T + bias) + resid.float()
+    got = ops.linear(x, w, bias=bias, act=act, resid=resid)
+    _close(got, ref, 1.2e-2, f"gemm_bf16 {M}x{N}x{K} act{act}")
+    got32 = ops.linear(x, w, bias=bias, act=act, out_dtype=torch.float32)
+    _close(got32, ACT_REF[act](x.float() @ w.float().T + bias), 2e-3, "gemm_bf16 f32-out")
+
+
+def test_gemm_bf16_identity_asymmetric(dev):
+    """A = I with an asymmetric W catches a swapped C layout (cdna guide §3)."""
+    ops = _ops()
+    K = 128
+    x = torch.eye(K, dtype=torch.bfloat16, device=dev)
+    w = (torch.arange(256 * K, device=dev).reshape(256, K) % 251).to(torch.bfloat16)
+    got = ops.linear(x, w, out_dtype=torch.float32)
+    assert torch.equal(got, w.float().T.contiguous())
+
+
+def test_gemm_bf16_rowmap_and_strided(dev):
+    ops = _ops()
+    M, N, K = 500, 256, 192
+    xfull = _rand((M, K + 64), dev, torch.bfloat16, 5)
+    x = xfull[:, 32:32 + K]  # strided view, 64-byte aligned start
+    w = _rand((N, K), dev, torch.bfloat16, 6, K ** -0.5)
+    perm = torch.randperm(M, device=dev).to(torch.int32)
+    perm[::7] = -1
+    resid = _rand((M, N), dev, torch.bfloat16, 7)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+    ops.linear(x, w, resid=resid, row_map=perm, out=out)
+    ref = torch.zeros((M, N), dtype=torch.float32, device=dev)
+    y = x.float() @ w.float().T
+    keep = perm >= 0
+    ref[perm[keep].long()] = y[keep] + resid.float()[perm[keep].long()]
+    _close(out, ref, 1.2e-2, "gemm row_map")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_swiglu(dev, dtype):
+    ops = _ops()
+    M, F_, K = 200, 192, 128
+    x = _rand((M, K), dev, dtype, 8)
+    wg = _rand((F_, K), dev, dtype, 9, K ** -0.5)
+    wu = _rand((F_, K), dev, dtype, 10, K ** -0.5)
+    wi = torch.stack([wg.view(F_ // 16, 16, K), wu.view(F_ // 16, 16, K)], dim=1).reshape(2 * F_, K).contiguous()
+    got = ops.linear(x, wi, swiglu=True)
+    ref = F.silu(x.float() @ wg.float().T) * (x.float() @ wu.float().T)
+    _close(got, ref, 1.2e-2 if dtype == torch.bfloat16 else 2e-5, "swiglu")
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (130, 70, 36), (300, 1003, 256)])
+def test_gemm_f32(dev, M, N, K):
+    ops = _ops()
+    x = _rand((M, K), dev, torch.float32, 11)
+    w = _rand((N, K), dev, torch.float32, 12, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 13)
+    resid = _rand((M, N), dev, torch.float32, 14)
+    got = ops.linear(x, w, bias=bias, act=1, resid=resid)
+    ref = F.gelu(x.double() @ w.double().T + bias.double()) + resid.double()
+    _close(got, ref, 2e-5, "gemm_f32")
+
+
+def _attn_ref(q, k, v, scale, causal=False, q_pos0=0, relh=None, relw=None, S=0):
+    q, k, v = q.double(), k.double(), v.double()
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    B, H, Nq, Nk = s.shape
+    if relh is not None:
+        kk = torch.arange(Nk, device=q.device)
+        bias = relh.double()[:, :, kk // S] + relw.double()[:, :, kk % S]
+        s = s + bias.view(B, H, Nq, Nk)
+    if causal:
+        qi = torch.arange(Nq, device=q.device)[:, None]
+        kj = torch.arange(Nk, device=q.device)[None, :]
+        s = s.masked_fill(kj > qi + q_pos0, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("bhqk,bhkd->bhqd", p, v)
+    return o.permute(0, 2, 1, 3).reshape(B, Nq, H * q.shape[-1])
+
+
+ATTN_CASES = [
+    # B, H, Nq, Nk, d, causal, S
+    (2, 3, 196, 196, 80, False, 14),
+    (1, 2, 49, 49, 32, False, 7),
+    (1, 2, 4096, 4096, 80, False, 64),
+    (2, 4, 257, 257, 64, False, 0),
+    (2, 4, 291, 291, 128, True, 0),
+    (3, 4, 1, 295, 128, False, 0),
+    (2, 8, 6, 4096, 16, False, 0),
+    (2, 8, 4096, 6, 16, False, 0),
+    (2, 8, 6, 6, 32, False, 0),
+    (1, 4, 40, 40, 16, True, 0),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention(dev, case, dtype):
+    ops = _ops()
+    B, H, Nq, Nk, d, causal, S = case
+    if dtype == torch.float32 and Nk > 4096:
+        pytest.skip("f32 path bounds Nk by LDS")
+    # token-major fused layout like the product: [B, N, 3, H, d]
+    if Nq == Nk:
+        qkv = _rand((B, Nq, 3, H, d), dev, dtype, 20)
+        q = qkv[:, :, 0].permute(0, 2, 1, 3)
+        k = qkv[:, :, 1].permute(0, 2, 1, 3)
+        v = qkv[:, :, 2].permute(0, 2, 1, 3)
+    else:
+        q = _rand((B, Nq, H, d), dev, dtype, 21).permute(0, 2, 1, 3)
+        k = _rand((B, Nk, H, d), dev, dtype, 22).permute(0, 2, 1, 3)
+        v = _rand((B, Nk, H, d), dev, dtype, 23).permute(0, 2, 1, 3)
+    scale = d ** -0.5
+    relh = relw = None
+    if S:
+        relh = _rand((B * H, Nq, S), dev, torch.float32, 24)
+        relw = _rand((B * H, Nq, S), dev, torch.float32, 25)
+    q_pos0 = Nk - Nq
+    got = ops.attention(q, k, v, scale, causal=causal, q_pos0=q_pos0, relh=relh, relw=relw, S=S)
+    ref = _attn_ref(q, k, v, scale, causal, q_pos0, relh, relw, S)
+    _close(got, ref, 2e-2 if dtype == torch.bfloat16 else 2e-5, f"attention {case} {dtype}")
+
+
+def test_attention_online_softmax_rescale(dev):
+    """Force the running max to jump in a late KV tile (cdna guide rule 26)."""
+    ops = _ops()
+    B, H, N, d = 1, 2, 512, 64
+    q = _rand((B, N, H, d), dev, torch.bfloat16, 30).permute(0, 2, 1, 3).contiguous()
+    k = _rand((B, N, H, d), dev, torch.bfloat16, 31).permute(0, 2, 1, 3).contiguous()
+    v = _rand((B, N, H, d), dev, torch.bfloat16, 32).permute(0, 2, 1, 3).contiguous()
+    k[:, :, 300] = q[:, :, 17] * 4.0  # spike for query 17 at key 300 (tile 4)
+    got = ops.attention(q, k, v, 0.5)
+    ref = _attn_ref(q, k, v, 0.5)
+    _close(got, ref, 2e-2, "attention rescale spike")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_relpos_tables(dev, dtype):
+    ops = _ops()
+    B, H, S, d = 2, 3, 14, 80
+    N = S * S
+    qkv = _rand((B, N, 3, H, d), dev, dtype, 40)
+    q = qkv[:, :, 0].permute(0, 2, 1, 3)
+    th = _rand((2 * S - 1, d), dev, torch.float32, 41)
+    tw = _rand((2 * S - 1, d), dev, torch.float32, 42)
+    relh, relw = ops.relpos_tables(q, th, tw, S)
+    idx = torch.arange(S, device=dev)[:, None] - torch.arange(S, device=dev)[None, :] + (S - 1)
+    Rh, Rw = th[idx], tw[idx]  # [S(q), S(k), d]
+    rq = q.float().reshape(B * H, S, S, d)
+    ref_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh).reshape(B * H, N, S)
+    ref_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw).reshape(B * H, N, S)
+    _close(relh, ref_h, 1e-5, "relh")
+    _close(relw, ref_w, 1e-5, "relw")
+
+
+@pytest.mark.parametrize("C", [64, 256, 1024, 1280, 4096, 5120])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_norms(dev, C, dtype):
+    ops = _ops()
+    R = 77
+    x = _rand((R, C), dev, dtype, 50, 2.0) + 0.3
+    w = _rand((C,), dev, torch.float32, 51) + 1.0
+    b = _rand((C,), dev, torch.float32, 52)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    got = ops.layernorm(x, w, b, 1e-6)
+    _close(got, F.layer_norm(x.float(), (C,), w, b, 1e-6), tol, "layernorm")
+    xf = x.float()
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * w
+    _close(ops.rmsnorm(x, w, 1e-5), ref, tol, "rmsnorm")
+    m = torch.randint(0, R, (100,), device=dev).to(torch.int32)
+    m[::5] = -1
+    got = ops.layernorm(x, w, b, 1e-6, in_map=m)
+    ref = F.layer_norm(xf, (C,), w, b, 1e-6)[m.clamp(min=0).long()]
+    ref[m < 0] = 0
+    _close(got, ref, tol, "layernorm gather")
+    assert (got[m < 0] == 0).all()
+
+
+def test_patchify_and_im2col(dev):
+    ops = _ops()
+    B, P, g = 2, 16, 5
+    x = _rand((B, 3, g * P, g * P), dev, torch.float32, 60)
+    w = _rand((32, 3, P, P), dev, torch.float32, 61, 0.05)
+    rows = ops.patchify_nchw(x, P, g, g, 3 * P * P, torch.float32)
+    got = (rows @ w.reshape(32, -1).T).view(B, g, g, 32)
+    ref = F.conv2d(x, w, stride=P).permute(0, 2, 3, 1)
+    _close(got, ref, 1e-5, "patchify conv")
+    # CLIP-style 14x14 patches with K padded to a multiple of 8
+    xc = _rand((B, 3, 28, 28), dev, torch.bfloat16, 62)
+    rows = ops.patchify_nchw(xc, 14, 2, 2, 592, torch.bfloat16)
+    ref = F.unfold(xc.float(), 14, stride=14).transpose(1, 2).reshape(B * 4, 588)
+    assert torch.equal(rows[:, :588].float(), ref) and (rows[:, 588:] == 0).all()
+    # uint8 NHWC ingest with SAM normalisation and zero pad
+    fr = torch.randint(0, 256, (B, 70, 60, 3), dtype=torch.uint8, device=dev)
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    rows = ops.patchify_u8(fr, P, g, g, 3 * P * P, mean, std, torch.float32)
+    xn = (fr.float().permute(0, 3, 1, 2) - torch.tensor(mean, device=dev).view(1, 3, 1, 1)) / torch.tensor(std, device=dev).view(1, 3, 1, 1)
+    xn = F.pad(xn, (0, g * P - 60, 0, g * P - 70))
+    ref = ops.patchify_nchw(xn, P, g, g, 3 * P * P, torch.float32)
+    _close(rows, ref, 1e-6, "patchify_u8")
+    # 3x3 im2col, channels-last
+    xi = _rand((B, 6, 7, 16), dev, torch.float32, 63)
+    wi = _rand((8, 16, 3, 3), dev, torch.float32, 64, 0.1)
+    cols = ops.im2col3x3(xi)
+    got = (cols @ wi.permute(0, 2, 3, 1).reshape(8, -1).T).view(B, 6, 7, 8)
+    ref = F.conv2d(xi.permute(0, 3, 1, 2), wi, padding=1).permute(0, 2, 3, 1)
+    _close(got, ref, 1e-5, "im2col3x3 conv")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_embed_splice_rope_argmax(dev, dtype):
+    ops = _ops()
+    B, L, n_img, Hd, V = 3, 12, 16, 64, 50
+    ids = torch.randint(0, V, (B, L), device=dev)
+    pos = torch.tensor([2, 2, 5], dtype=torch.int32, device=dev)
+    for b in range(B):
+        ids[b, pos[b]] = -200
+    emb = _rand((V, Hd), dev, dtype, 70)
+    img = _rand((B, n_img, Hd), dev, dtype, 71)
+    got = ops.embed_splice(ids, pos, emb, img)
+    for b in range(B):
+        p = int(pos[b])
+        ref = torch.cat([emb[ids[b, :p]], img[b], emb[ids[b, p + 1:]]], 0)
+        assert torch.equal(got[b], ref)
+    # rope
+    Bq, Tq, Hq, d, pos0, Tmax = 2, 5, 4, 32, 3, 16
+    qkv = _rand((Bq * Tq, 3 * Hq * d), dev, dtype, 72)
+    orig = qkv.clone().float().view(Bq, Tq, 3, Hq, d)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, device=dev).float() / d))
+    ang = torch.arange(Tmax, device=dev).float()[:, None] * inv[None, :]
+    cs = torch.cat([ang.cos(), ang.sin()], 1).contiguous()
+    kc = torch.zeros((Bq, Tmax, Hq * d), dtype=dtype, device=dev)
+    vc = torch.zeros_like(kc)
+    ops.rope_cache(qkv, kc, vc, cs, Bq, Tq, Hq, Hq, d, pos0)
+    cos = torch.cat([ang.cos(), ang.cos()], 1)[pos0:pos0 + Tq].view(1, Tq, 1, d)
+    sin = torch.cat([ang.sin(), ang.sin()], 1)[pos0:pos0 + Tq].view(1, Tq, 1, d)
+
+    def rot(x):
+        return torch.cat([-x[..., d // 2:], x[..., :d // 2]], -1)
+    qr = orig[:, :, 0] * cos + rot(orig[:, :, 0]) * sin
+    kr = orig[:, :, 1] * cos + rot(orig[:, :, 1]) * sin
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
+    out = qkv.float().view(Bq, Tq, 3, Hq, d)
+    _close(out[:, :, 0], qr, tol, "rope q")
+    _close(out[:, :, 1], kr, tol, "rope k")
+    _close(kc.view(Bq, Tmax, Hq, d)[:, pos0:pos0 + Tq], kr, tol, "k cache")
+    assert torch.equal(vc.view(Bq, Tmax, Hq, d)[:, pos0:pos0 + Tq].float(), orig[:, :, 2])
+    assert (kc[:, :pos0] == 0).all() and (kc[:, pos0 + Tq:] == 0).all()
+    # argmax (first index on ties)
+    lg = _rand((5, 32003), dev, torch.float32, 73)
+    lg[2, 100] = lg[2, 31999] = 50.0
+    got = ops.argmax_rows(lg)
+    assert torch.equal(got, lg.argmax(-1)) or int(got[2]) == 100
+    assert int(got[2]) == 100
+
+
+def test_add_softmax(dev):
+    ops = _ops()
+    a = _rand((4096 * 2, 256), dev, torch.bfloat16, 80)
+    pe = _rand((4096, 256), dev, torch.bfloat16, 81)
+    _close(ops.add_bcast(a, pe), a.float() + pe.float().repeat(2, 1), 1e-2, "add_bcast")
+    x = _rand((7, 4), dev, torch.float32, 82)
+    _close(ops.softmax_rows(x), torch.softmax(x, -1), 1e-6, "softmax")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_upscale_mask_and_resize(dev, dtype):
+    ops = _ops()
+    n, h, w = 2, 14, 14
+    src = _rand((n, 256, h, w), dev, torch.float32, 90)
+    ct1 = torch.nn.ConvTranspose2d(256, 64, 2, 2).to(dev).float()
+    ct2 = torch.nn.ConvTranspose2d(64, 32, 2, 2).to(dev).float()
+    ln_w = _rand((64,), dev, torch.float32, 91) + 1.0
+    ln_b = _rand((64,), dev, torch.float32, 92)
+    hyper = _rand((n, 32), dev, torch.float32, 93)
+    with torch.no_grad():
+        u = ct1(src)
+        mu = u.mean(1, keepdim=True)
+        var = (u - mu).pow(2).mean(1, keepdim=True)
+        u = (u - mu) / torch.sqrt(var + 1e-6) * ln_w[:, None, None] + ln_b[:, None, None]
+        u = F.gelu(ct2(F.gelu(u)))
+        ref = torch.einsum("nc,nchw->nhw", hyper, u)
+        # product path: first ConvT as GEMM with columns (dy,dx,co)
+        w1 = ct1.weight.permute(2, 3, 1, 0).reshape(256, 256).contiguous()  # [(dy,dx,co), ci]
+        b1 = ct1.bias.repeat(4).contiguous()
+        x = src.permute(0, 2, 3, 1).reshape(n * h * w, 256).contiguous().to(dtype)
+        up1 = ops.linear(x, w1.to(dtype), bias=b1)
+        w2 = ct2.weight.permute(0, 2, 3, 1).reshape(64, 128).contiguous()  # [co][(dy2,dx2,c2)]
+        got = ops.upscale_mask(up1, ln_w, ln_b, w2, ct2.bias.contiguous(), hyper, n, h, w)
+    _close(got, ref, 3e-2 if dtype == torch.bfloat16 else 1e-4, "upscale_mask")
+    m = _rand((3, 56, 56), dev, torch.float32, 94)
+    up = ops.resize_bilinear(m, (56, 56), (224, 224))
+    _close(up, F.interpolate(m[:, None], (224, 224), mode="bilinear", align_corners=False)[:, 0], 1e-6, "resize x4")
+    crop = ops.resize_bilinear(up, (224, 168), (120, 90))
+    ref = F.interpolate(up[:, None, :224, :168], (120, 90), mode="bilinear", align_corners=False)[:, 0]
+    _close(crop, ref, 1e-6, "resize crop")
+    th = ops.threshold_masks(crop, 0.0)
+    assert torch.equal(th, ((crop > 0).to(torch.uint8) * 255))
