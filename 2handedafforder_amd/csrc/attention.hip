@@ -20,7 +20,7 @@
 // (K: 2D+16 B, V: 2D+32 B) so ds_read_b128 / tr reads are bank-conflict free.
 // Rel-pos bias comes from per-query tables relh[q][kh], relw[q][kw] (haff_relpos_tables): BIAS=2 keeps
 // relw in registers when a KV tile is exactly one key-grid row (global attention, S=64); BIAS=1 looks
-// both terms up in an LDS copy (windows, S<=16).
+// both terms up in an LDS copy (windows, S<=32).
 #include "haff_common.h"
 
 namespace {
@@ -53,12 +53,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   constexpr int CPR = DP / 8;           // chunks per row
   constexpr int ND = DP / 16;           // output d-tiles
   constexpr int NKD = DP / 32;          // k-steps over head dim
-  constexpr int SMAX = 16;
+  constexpr int SMAX = 32;
+  constexpr int RSTRIDE = 2 * SMAX + 1;  // odd stride: the 16 query lanes of a tile hit 16 different banks
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* sK = smem_raw;
   unsigned char* sV = smem_raw + KT * KSTRIDE;
-  float* sRel = reinterpret_cast<float*>(smem_raw + KT * KSTRIDE + KT * VSTRIDE);  // [QB][2*SMAX] when BIAS==1
+  float* sRel = reinterpret_cast<float*>(smem_raw + KT * KSTRIDE + KT * VSTRIDE);  // [QB][2*SMAX+1] when BIAS==1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       const int j = i - ql * 2 * p.S;
       const int qc = min(q0 + ql, p.Nq - 1);
       const float val = (j < p.S) ? p.relh[(bh * p.Nq + qc) * p.S + j] : p.relw[(bh * p.Nq + qc) * p.S + (j - p.S)];
-      sRel[ql * 2 * SMAX + j] = val;
+      sRel[ql * RSTRIDE + j] = val;
     }
   }
 
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             const int kc = min(key, p.Nk - 1);
             const int kh = kc / p.S;
             const int kw = kc - kh * p.S;
-            v += sRel[ql * 2 * SMAX + kh] + sRel[ql * 2 * SMAX + p.S + kw];
+            v += sRel[ql * RSTRIDE + kh] + sRel[ql * RSTRIDE + p.S + kw];
           }
           bool ok = key < p.Nk;
           if (CAUSAL) ok = ok && (key <= qrow[qt] + p.q_pos0);
@@ -290,7 +291,7 @@ template <int DP, int BIAS, bool CAUSAL>
 int launch_attn(const AttnArgs& p, hipStream_t s) {
   constexpr int KSTRIDE = DP * 2 + 16, VSTRIDE = DP * 2 + 32;
   size_t lds = (size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE;
-  if (BIAS == 1) lds += (size_t)QB * 2 * 16 * sizeof(float);
+  if (BIAS == 1) lds += (size_t)QB * (2 * 32 + 1) * sizeof(float);
   dim3 grid((p.Nq + QB - 1) / QB, p.H, p.B), block(256);
   hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL>), grid, block, lds, s, p);
   return haff_check_launch();
@@ -321,7 +322,7 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   const int dp = d <= 64 ? 64 : (d <= 96 ? 96 : 128);
   if (rel) {
     const int mode = (S == 64) ? 2 : 1;
-    if (mode == 1 && S > 16) return HAFF_ERR_UNSUPPORTED;
+    if (mode == 1 && S > 32) return HAFF_ERR_UNSUPPORTED;
     if (dp == 64) return mode == 2 ? launch_attn<64, 2, false>(p, s) : launch_attn<64, 1, false>(p, s);
     if (dp == 96) return mode == 2 ? launch_attn<96, 2, false>(p, s) : launch_attn<96, 1, false>(p, s);
     return mode == 2 ? launch_attn<128, 2, false>(p, s) : launch_attn<128, 1, false>(p, s);

@@ -1,0 +1,217 @@
+"""Generates tests/golden/*.npz — run ONLY in the build container (needs /root/reference and transformers).
+
+    python oracle/make_golden.py
+
+What is captured (inputs + expected outputs + intermediate taps, NO weights: weights are rebuilt from
+(config, seed) by 2handedafforder_amd/weights.py, whose keys are the reference's state-dict keys):
+
+  * from the REFERENCE'S OWN modules, imported by file path from
+    /root/reference/2Haff/model/segment_anything/modeling/ (pure torch; the package __init__ of
+    segment_anything is bypassed because it pulls torchvision): ImageEncoderViT, PromptEncoder (text path +
+    get_dense_pe), MaskDecoder left (taxonomy_on) / right, Sam.postprocess_masks.
+  * from the container's `transformers` (the reference's Llama/CLIP arithmetic is that third-party library,
+    pinned ==4.31.0 in 2Haff/requirements.txt:20 and absent from /root/reference; 5.x implements the same
+    published math for Llama-1/2-style configs): LlamaModel + lm_head, CLIPVisionModel hidden_states[-2][:,1:].
+
+Nothing from the reference is copied into the repo; fixtures are data only.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import haff  # noqa: E402,F401
+from haff import config as hcfg  # noqa: E402
+from haff import weights as hw  # noqa: E402
+
+REF_MODELING = "/root/reference/2Haff/model/segment_anything/modeling"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def load_ref_modeling():
+    spec = importlib.util.spec_from_file_location(
+        "ref_sam_modeling", os.path.join(REF_MODELING, "__init__.py"), submodule_search_locations=[REF_MODELING])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_sam_modeling"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build_ref_sam(ref, s):
+    """Same constructor arguments as build_sam.py:_build_sam (:59-117), with parametric sizes."""
+    from functools import partial
+    g = s.grid
+    return ref.Sam(
+        image_encoder=ref.ImageEncoderViT(
+            depth=s.depth, embed_dim=s.embed_dim, img_size=s.img_size, mlp_ratio=s.mlp_ratio,
+            norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=s.heads, patch_size=s.patch, qkv_bias=True,
+            use_rel_pos=True, global_attn_indexes=list(s.global_idx), window_size=s.window, out_chans=s.out_chans),
+        prompt_encoder=ref.PromptEncoder(embed_dim=s.out_chans, image_embedding_size=(g, g),
+                                         input_image_size=(s.img_size, s.img_size), mask_in_chans=16),
+        mask_decoder_left=ref.MaskDecoder(
+            num_multimask_outputs=3,
+            transformer=ref.TwoWayTransformer(depth=2, embedding_dim=s.out_chans, mlp_dim=2048, num_heads=8),
+            transformer_dim=s.out_chans, iou_head_depth=3, iou_head_hidden_dim=256, taxonomy_on=True),
+        mask_decoder_right=ref.MaskDecoder(
+            num_multimask_outputs=3,
+            transformer=ref.TwoWayTransformer(depth=2, embedding_dim=s.out_chans, mlp_dim=2048, num_heads=8),
+            transformer_dim=s.out_chans, iou_head_depth=3, iou_head_hidden_dim=256, taxonomy_on=False),
+    ).eval()
+
+
+def sam_goldens(ref, name, cfg, seed, n_prompts, input_size, original_size):
+    s = cfg.sam
+    shapes = hw.sam_shapes(s)
+    sd = hw.make_state_dict(cfg, seed, shapes)
+    sam = build_ref_sam(ref, s)
+    missing, unexpected = sam.load_state_dict({k[len("model.visual_model."):]: v for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    # the only reference parameters our inventory omits are prompt types LISA never uses
+    assert all(("point_embeddings" in m or "not_a_point" in m or "mask_downscaling" in m) for m in missing), missing
+    rng = np.random.default_rng(seed + 1000)
+    x = torch.from_numpy(rng.standard_normal((2, 3, s.img_size, s.img_size), dtype=np.float32))
+    text = torch.from_numpy(rng.standard_normal((n_prompts, 1, s.out_chans), dtype=np.float32))
+    taps = {}
+    hooks = []
+    for i, blk in enumerate(sam.image_encoder.blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"block{i}", o.detach().numpy())))
+    hooks.append(sam.image_encoder.patch_embed.register_forward_hook(
+        lambda m, a, o: taps.__setitem__("patch_proj", o.detach().numpy())))
+    with torch.no_grad():
+        emb = sam.image_encoder(x)
+        sparse, dense = sam.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text)
+        pe = sam.prompt_encoder.get_dense_pe()
+        lo_l, iou_l, tax = sam.mask_decoder_left(image_embeddings=emb[0:1], image_pe=pe, sparse_prompt_embeddings=sparse,
+                                                 dense_prompt_embeddings=dense, multimask_output=False)
+        lo_r, iou_r = sam.mask_decoder_right(image_embeddings=emb[0:1], image_pe=pe, sparse_prompt_embeddings=sparse,
+                                             dense_prompt_embeddings=dense, multimask_output=False)
+        post_l = sam.postprocess_masks(lo_l, input_size=input_size, original_size=original_size)
+        post_r = sam.postprocess_masks(lo_r, input_size=input_size, original_size=original_size)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), seed=seed, images=x.numpy(), text_embeds=text.numpy(),
+        image_embeddings=emb.numpy(), dense_pe=pe.numpy(), sparse=sparse.detach().numpy(), dense_row=dense[:, :, 0, 0].detach().numpy(),
+        low_res_left=lo_l.numpy(), iou_left=iou_l.numpy(), taxonomy=tax.numpy(), low_res_right=lo_r.numpy(),
+        iou_right=iou_r.numpy(), post_left=post_l.numpy(), post_right=post_r.numpy(),
+        input_size=np.array(input_size), original_size=np.array(original_size),
+        **{"tap_" + k: v for k, v in taps.items()})
+    print(name, "emb", tuple(emb.shape), "low_res", tuple(lo_l.shape), "post", tuple(post_l.shape),
+          "logit std %.3f" % lo_l.std().item())
+
+
+def llama_golden(name, cfg, seed):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    l = cfg.llm
+    hc = LlamaConfig(vocab_size=l.vocab, hidden_size=l.hidden, intermediate_size=l.ffn, num_hidden_layers=l.layers,
+                     num_attention_heads=l.heads, num_key_value_heads=l.heads, rms_norm_eps=l.rms_eps,
+                     rope_theta=l.rope_theta, max_position_embeddings=2048, attention_bias=False, mlp_bias=False,
+                     tie_word_embeddings=False, attn_implementation="eager")
+    model = LlamaForCausalLM(hc).eval()
+    sd = hw.make_state_dict(cfg, seed, hw.llm_shapes(cfg))
+    own = {k: v for k, v in sd.items() if not (k.startswith("model.mm_projector") or k.startswith("model.text_hidden"))}
+    missing, unexpected = model.load_state_dict(own, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    rng = np.random.default_rng(seed + 2000)
+    x = torch.from_numpy(rng.standard_normal((2, 40, l.hidden), dtype=np.float32))
+    with torch.no_grad():
+        out = model(inputs_embeds=x, output_hidden_states=True, use_cache=False)
+        # KV-cached continuation: prefill 36, then 4 single-token steps
+        o2 = model(inputs_embeds=x[:, :36], use_cache=True, output_hidden_states=True)
+        hs = [o2.hidden_states[-1]]
+        past = o2.past_key_values
+        for t in range(36, 40):
+            o3 = model(inputs_embeds=x[:, t:t + 1], past_key_values=past, use_cache=True, output_hidden_states=True)
+            past = o3.past_key_values
+            hs.append(o3.hidden_states[-1])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, inputs_embeds=x.numpy(),
+                        hidden=out.hidden_states[-1].numpy(), layer0=out.hidden_states[1].numpy(),
+                        logits=out.logits.numpy(), hidden_cached=torch.cat(hs, 1).numpy())
+    print(name, "hidden", tuple(out.hidden_states[-1].shape), "cached-vs-full",
+          (torch.cat(hs, 1) - out.hidden_states[-1]).abs().max().item())
+
+
+def clip_golden(name, cfg, seed):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    c = cfg.clip
+    hc = CLIPVisionConfig(hidden_size=c.hidden, intermediate_size=c.mlp, num_hidden_layers=c.layers,
+                          num_attention_heads=c.heads, image_size=c.image, patch_size=c.patch, hidden_act="quick_gelu",
+                          layer_norm_eps=c.eps, attn_implementation="eager")
+    model = CLIPVisionModel(hc).eval()
+    sd = hw.make_state_dict(cfg, seed, hw.clip_shapes(c))
+    pre = "model.vision_tower.vision_tower."
+    own = {k[len(pre):]: v for k, v in sd.items()}
+    if not any(k.startswith("vision_model.") for k in model.state_dict()):  # transformers 5.x flattened the prefix
+        own = {k[len("vision_model."):]: v for k, v in own.items()}
+    missing, unexpected = model.load_state_dict(own, strict=False)
+    assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
+    rng = np.random.default_rng(seed + 3000)
+    x = torch.from_numpy(rng.standard_normal((2, 3, c.image, c.image), dtype=np.float32))
+    with torch.no_grad():
+        out = model(x, output_hidden_states=True)
+    feat = out.hidden_states[c.select_layer][:, 1:]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, images=x.numpy(), features=feat.numpy(),
+                        hidden0=out.hidden_states[0].numpy())
+    print(name, "features", tuple(feat.shape))
+
+
+def host_goldens():
+    """tokenizer_image_token (llava/mm_utils.py:19-44) with a stub tokenizer and conv_llava_v1.get_prompt()
+    (llava/conversation.py) — pure-Python reference helpers, imported by path."""
+    base = "/root/reference/2Haff/model/llava"
+    pkg = importlib.util.module_from_spec(importlib.util.spec_from_file_location(
+        "ref_llava", os.path.join(base, "__init__.py"), submodule_search_locations=[base]))
+    sys.modules["ref_llava"] = pkg  # do NOT exec the package __init__ (it imports the model code)
+    const = importlib.util.spec_from_file_location("ref_llava.constants", os.path.join(base, "constants.py"))
+    cm = importlib.util.module_from_spec(const)
+    sys.modules["ref_llava.constants"] = cm
+    const.loader.exec_module(cm)
+    spec = importlib.util.spec_from_file_location("ref_llava.mm_utils", os.path.join(base, "mm_utils.py"))
+    mm = importlib.util.module_from_spec(spec)
+    sys.modules["ref_llava.mm_utils"] = mm
+    spec.loader.exec_module(mm)
+    spec = importlib.util.spec_from_file_location("ref_llava.conversation", os.path.join(base, "conversation.py"))
+    conv = importlib.util.module_from_spec(spec)
+    sys.modules["ref_llava.conversation"] = conv
+    spec.loader.exec_module(conv)
+
+    class StubTok:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [1] + [3 + (ord(ch) % 300) for ch in text]
+            return r
+    prompts = ["<im_start><image><im_end>\nWhere would you interact with the object to perform action open drawer",
+               "no image here", "<image> leading", "a<image>b<image>c"]
+    ids = [mm.tokenizer_image_token(p, StubTok()) for p in prompts]
+    c = conv.conv_templates["llava_v1"].copy()
+    c.messages = []
+    c.append_message(c.roles[0], "<im_start><image><im_end>\nWhere would you hold the mug?")
+    c.append_message(c.roles[1], "")
+    import json
+    with open(os.path.join(OUT, "host_helpers.json"), "w") as f:
+        json.dump({"prompts": prompts, "ids": ids, "conv_llava_v1_prompt": c.get_prompt(),
+                   "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2}, f, indent=1)
+    print("host helpers ok:", c.get_prompt()[:80].replace("\n", "\\n"))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    ref = load_ref_modeling()
+    sam_goldens(ref, "sam_tiny", hcfg.tiny(), seed=11, n_prompts=2, input_size=(224, 168), original_size=(120, 90))
+    sam_goldens(ref, "sam_mid", hcfg.mid(), seed=12, n_prompts=1, input_size=(320, 320), original_size=(320, 320))
+    llama_golden("llama_tiny", hcfg.tiny(), seed=13)
+    clip_golden("clip_tiny", hcfg.tiny(), seed=14)
+    host_goldens()
+
+
+if __name__ == "__main__":
+    main()

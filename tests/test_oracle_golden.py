@@ -1,0 +1,120 @@
+"""Pins the oracle (oracle/lisa_oracle.py) against golden vectors captured from the reference's own SAM
+modules and from transformers' Llama/CLIP (oracle/make_golden.py, run in the build container).
+CPU-only; weights are rebuilt from (config, seed) — fixtures carry inputs/outputs only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import haff  # noqa: F401
+from haff import config as hcfg
+from haff import weights as hw
+from oracle import lisa_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+V = "model.visual_model"
+
+
+def _load(name):
+    return {k: v for k, v in np.load(os.path.join(GOLD, name + ".npz")).items()}
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _maxerr(a, b):
+    return (a - _t(b)).abs().max().item()
+
+
+@pytest.mark.parametrize("name,cfg", [("sam_tiny", hcfg.tiny()), ("sam_mid", hcfg.mid())])
+def test_sam_against_reference_modules(name, cfg):
+    g = _load(name)
+    sd = hw.make_state_dict(cfg, int(g["seed"]), hw.sam_shapes(cfg.sam))
+    taps = {}
+    with torch.no_grad():
+        emb = O.sam_image_encoder(sd, V + ".image_encoder", _t(g["images"]), cfg.sam, taps)
+    for i in range(cfg.sam.depth):
+        assert _maxerr(taps[f"block{i}"], g[f"tap_block{i}"]) < 2e-4, f"block {i}"
+    assert _maxerr(emb, g["image_embeddings"]) < 2e-4
+    grid = (cfg.sam.grid, cfg.sam.grid)
+    pe = O.sam_dense_pe(sd, V + ".prompt_encoder", grid)
+    assert _maxerr(pe, g["dense_pe"]) < 1e-5
+    sparse, dense = O.sam_prompt_encoder_text(sd, V + ".prompt_encoder", _t(g["text_embeds"]), grid)
+    assert _maxerr(sparse, g["sparse"]) == 0 and _maxerr(dense[:, :, 0, 0], g["dense_row"]) == 0
+    e0 = _t(g["image_embeddings"])[0:1]
+    with torch.no_grad():
+        lo_l, iou_l, tax = O.sam_mask_decoder(sd, V + ".mask_decoder_left", e0, pe, sparse, dense, True)
+        lo_r, iou_r = O.sam_mask_decoder(sd, V + ".mask_decoder_right", e0, pe, sparse, dense, False)
+    assert _maxerr(lo_l, g["low_res_left"]) < 2e-4 and _maxerr(lo_r, g["low_res_right"]) < 2e-4
+    assert _maxerr(iou_l, g["iou_left"]) < 1e-4 and _maxerr(tax, g["taxonomy"]) < 1e-5
+    inp, orig = tuple(int(v) for v in g["input_size"]), tuple(int(v) for v in g["original_size"])
+    post = O.sam_postprocess_masks(_t(g["low_res_left"]), cfg.sam.img_size, inp, orig)
+    assert _maxerr(post, g["post_left"]) < 1e-5
+    # sign (argmax) masks identical wherever the reference logit is not within float noise of zero
+    ref = _t(g["low_res_left"])
+    safe = ref.abs() > 1e-3
+    assert torch.equal((lo_l > 0)[safe], (ref > 0)[safe])
+
+
+def test_llama_against_transformers():
+    cfg = hcfg.tiny()
+    g = _load("llama_tiny")
+    sd = hw.make_state_dict(cfg, int(g["seed"]), hw.llm_shapes(cfg))
+    x = _t(g["inputs_embeds"])
+    taps = {}
+    with torch.no_grad():
+        h = O.llama_forward(sd, x, cfg.llm, taps=taps)
+        logits = torch.nn.functional.linear(h, sd["lm_head.weight"])
+    assert _maxerr(taps["layer0"], g["layer0"]) < 1e-4
+    assert _maxerr(h, g["hidden"]) < 1e-4 and _maxerr(logits, g["logits"]) < 2e-4
+    # KV-cached schedule == full recompute
+    cache = [None] * cfg.llm.layers
+    with torch.no_grad():
+        hs = [O.llama_forward(sd, x[:, :36], cfg.llm, cache)]
+        for t in range(36, 40):
+            hs.append(O.llama_forward(sd, x[:, t:t + 1], cfg.llm, cache))
+    assert _maxerr(torch.cat(hs, 1), g["hidden_cached"]) < 1e-4
+    assert _maxerr(torch.cat(hs, 1), g["hidden"]) < 1e-4
+
+
+def test_clip_against_transformers():
+    cfg = hcfg.tiny()
+    g = _load("clip_tiny")
+    sd = hw.make_state_dict(cfg, int(g["seed"]), hw.clip_shapes(cfg.clip))
+    with torch.no_grad():
+        f = O.clip_vision_features(sd, "model.vision_tower.vision_tower", _t(g["images"]), cfg.clip)
+    assert f.shape == (2, 256, cfg.clip.hidden)
+    assert _maxerr(f, g["features"]) < 1e-4
+
+
+def test_seg_token_rule_and_losses_closed_form():
+    """LISA.py:457-465 — position 255+j is selected iff token j+1 is [SEG]."""
+    ids = torch.tensor([[1, 321, -200, 322, 7, 8, 320, 9, 2], [1, 321, -200, 322, 320, 5, 6, 320, 2]])
+    m = O.seg_token_mask(ids, 320)
+    assert m.shape == (2, 255 + 8)
+    assert m[0].nonzero().flatten().tolist() == [255 + 5] and m[1].nonzero().flatten().tolist() == [255 + 3, 255 + 6]
+
+
+def test_host_helpers_match_reference():
+    from haff import prompt as P
+    with open(os.path.join(GOLD, "host_helpers.json")) as f:
+        g = json.load(f)
+
+    class StubTok:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [1] + [3 + (ord(ch) % 300) for ch in text]
+            return r
+    for p, ids in zip(g["prompts"], g["ids"]):
+        assert P.tokenizer_image_token(p, StubTok()) == ids
+    conv = P.conv_llava_v1()
+    conv.append_message(conv.roles[0], "<im_start><image><im_end>\nWhere would you hold the mug?")
+    conv.append_message(conv.roles[1], "")
+    assert conv.get_prompt() == g["conv_llava_v1_prompt"]
