@@ -1,0 +1,169 @@
+"""LLaVA half of the 2Haff hot path on MI355X: CLIP ViT-L/14 tower -> linear projector -> embedding splice ->
+Llama decoder with a KV cache -> greedy token. Host-side orchestration of the HIP kernels (no torch math).
+
+Mirrors the reference's
+  2Haff/model/llava/model/multimodal_encoder/clip_encoder.py:31-60 (hidden_states[select_layer][:,1:])
+  2Haff/model/llava/model/llava_arch.py:35,93-96 (projector), :185-208,252-256 (splice)
+  2Haff/model/llava/model/language_model/llava_llama.py:55-135 (forward; eval returns post-norm hidden)
+whose arithmetic lives in transformers' CLIPVisionModel / LlamaModel. Unlike the reference (config.use_cache =
+False, LISA.py:115 — every generated token re-runs CLIP and the whole prefix) the decoder here keeps K/V
+resident in HBM; a causal model makes the two schedules numerically equivalent.
+"""
+import torch
+
+from . import ops
+
+CLIP = "model.vision_tower.vision_tower.vision_model"
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _pad_cols(w, mult):
+    k = w.shape[1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return w
+    return torch.nn.functional.pad(w, (0, kp - k))
+
+
+class ClipTowerHip:
+    def __init__(self, sd, cfg, dtype, device):
+        c = self.cfg = cfg
+        self.dtype, self.device = dtype, device
+        dev = device
+        self.hd = c.hidden // c.heads
+        wp = sd[CLIP + ".embeddings.patch_embedding.weight"].reshape(c.hidden, -1)
+        self.w_patch = _pad_cols(wp, 8).to(dev, dtype).contiguous()  # K = 3*14*14 = 588 -> 592
+        self.cls = sd[CLIP + ".embeddings.class_embedding"].to(dev, dtype)
+        self.pos = sd[CLIP + ".embeddings.position_embedding.weight"].to(dev, dtype).contiguous()
+        self.pre = (_f32(sd[CLIP + ".pre_layrnorm.weight"], dev), _f32(sd[CLIP + ".pre_layrnorm.bias"], dev))
+        self.n_run = c.layers + 1 + c.select_layer if c.select_layer < 0 else c.select_layer
+        self.layers = []
+        for i in range(self.n_run):
+            L = f"{CLIP}.encoder.layers.{i}"
+            wq = torch.cat([sd[f"{L}.self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
+            bq = torch.cat([sd[f"{L}.self_attn.{n}_proj.bias"] for n in ("q", "k", "v")], 0)
+            self.layers.append({
+                "n1": (_f32(sd[L + ".layer_norm1.weight"], dev), _f32(sd[L + ".layer_norm1.bias"], dev)),
+                "wqkv": wq.to(dev, dtype).contiguous(), "bqkv": _f32(bq, dev),
+                "wo": sd[L + ".self_attn.out_proj.weight"].to(dev, dtype).contiguous(),
+                "bo": _f32(sd[L + ".self_attn.out_proj.bias"], dev),
+                "n2": (_f32(sd[L + ".layer_norm2.weight"], dev), _f32(sd[L + ".layer_norm2.bias"], dev)),
+                "w1": sd[L + ".mlp.fc1.weight"].to(dev, dtype).contiguous(), "b1": _f32(sd[L + ".mlp.fc1.bias"], dev),
+                "w2": sd[L + ".mlp.fc2.weight"].to(dev, dtype).contiguous(), "b2": _f32(sd[L + ".mlp.fc2.bias"], dev)})
+        self._maps = {}
+
+    def _maps_for(self, B):
+        if B not in self._maps:
+            n = self.cfg.n_patches
+            into = (torch.arange(B)[:, None] * (n + 1) + 1 + torch.arange(n)[None, :]).reshape(-1)
+            outof = torch.full((B, n + 1), -1, dtype=torch.int64)
+            outof[:, 1:] = torch.arange(B)[:, None] * n + torch.arange(n)[None, :]
+            self._maps[B] = (into.to(torch.int32).to(self.device), outof.reshape(-1).to(torch.int32).to(self.device))
+        return self._maps[B]
+
+    def hidden(self, images):
+        """[B,3,224,224] -> residual stream [B*(n+1), C] after n_run layers (cls row included)."""
+        c = self.cfg
+        B = images.shape[0]
+        g = c.image // c.patch
+        n, C, H, hd = c.n_patches, c.hidden, c.heads, self.hd
+        rows = ops.patchify_nchw(images.to(self.dtype), c.patch, g, g, self.w_patch.shape[1], self.dtype)
+        into, _ = self._maps_for(B)
+        h = torch.empty((B * (n + 1), C), dtype=self.dtype, device=self.device)
+        h.view(B, n + 1, C)[:, 0] = self.cls
+        ops.linear(rows, self.w_patch, row_map=into, out=h)
+        ops.add_bcast(h, self.pos, mod=n + 1, out=h)
+        h = ops.layernorm(h, self.pre[0], self.pre[1], c.eps)
+        for L in self.layers:
+            y = ops.layernorm(h, L["n1"][0], L["n1"][1], c.eps)
+            qkv = ops.linear(y, L["wqkv"], bias=L["bqkv"]).view(B, n + 1, 3, H, hd)
+            a = ops.attention(qkv[:, :, 0].permute(0, 2, 1, 3), qkv[:, :, 1].permute(0, 2, 1, 3),
+                              qkv[:, :, 2].permute(0, 2, 1, 3), hd ** -0.5)
+            ops.linear(a.view(B * (n + 1), C), L["wo"], bias=L["bo"], resid=h, out=h)
+            y = ops.layernorm(h, L["n2"][0], L["n2"][1], c.eps)
+            y = ops.linear(y, L["w1"], bias=L["b1"], act=ops.ACT_QUICK_GELU)
+            ops.linear(y, L["w2"], bias=L["b2"], resid=h, out=h)
+        return h
+
+    def project(self, h, B, w_proj, b_proj):
+        """mm_projector on the patch rows only (drop cls): -> [B, n, H_llm] contiguous."""
+        _, outof = self._maps_for(B)
+        n = self.cfg.n_patches
+        out = ops.linear(h, w_proj, bias=b_proj, row_map=outof, out_rows=B * n)
+        return out.view(B, n, -1)
+
+
+class LlamaHip:
+    def __init__(self, sd, cfg, dtype, device):
+        l = self.cfg = cfg
+        self.dtype, self.device = dtype, device
+        dev = device
+        self.hd = l.hidden // l.heads
+        self.embed = sd["model.embed_tokens.weight"].to(dev, dtype).contiguous()
+        self.layers = []
+        F = l.ffn
+        assert F % 16 == 0, "SwiGLU interleave needs ffn % 16 == 0"
+        for i in range(l.layers):
+            L = f"model.layers.{i}"
+            wqkv = torch.cat([sd[f"{L}.self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
+            wg, wu = sd[L + ".mlp.gate_proj.weight"], sd[L + ".mlp.up_proj.weight"]
+            # rows interleaved in 16-row groups [gate x16 | up x16] so the GEMM epilogue sees (gate, up) pairs
+            wgu = torch.stack([wg.view(F // 16, 16, -1), wu.view(F // 16, 16, -1)], dim=1).reshape(2 * F, -1)
+            self.layers.append({
+                "n1": _f32(sd[L + ".input_layernorm.weight"], dev),
+                "wqkv": wqkv.to(dev, dtype).contiguous(),
+                "wo": sd[L + ".self_attn.o_proj.weight"].to(dev, dtype).contiguous(),
+                "n2": _f32(sd[L + ".post_attention_layernorm.weight"], dev),
+                "wgu": wgu.to(dev, dtype).contiguous(),
+                "wd": sd[L + ".mlp.down_proj.weight"].to(dev, dtype).contiguous()})
+            del wqkv, wgu
+        self.norm = _f32(sd["model.norm.weight"], dev)
+        self.lm_head = sd["lm_head.weight"].to(dev, dtype).contiguous()
+        self._cs = None
+
+    def _cos_sin(self, tmax):
+        if self._cs is None or self._cs.shape[0] < tmax:
+            d = self.hd
+            inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+            ang = torch.arange(tmax, dtype=torch.float32)[:, None] * inv[None, :]
+            self._cs = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous().to(self.device)
+        return self._cs
+
+    def new_cache(self, B, tmax):
+        H = self.cfg.hidden
+        return {"k": [torch.empty((B, tmax, H), dtype=self.dtype, device=self.device) for _ in self.layers],
+                "v": [torch.empty((B, tmax, H), dtype=self.dtype, device=self.device) for _ in self.layers],
+                "len": 0, "tmax": tmax}
+
+    def forward(self, x, cache):
+        """x [B,T,H] embeddings of the next T positions; appends to the cache; returns post-norm hidden [B,T,H]."""
+        l = self.cfg
+        B, T, H = x.shape
+        nh, hd = l.heads, self.hd
+        pos0 = cache["len"]
+        assert pos0 + T <= cache["tmax"]
+        cs = self._cos_sin(cache["tmax"])
+        x = x.reshape(B * T, H).clone() if not x.is_contiguous() else x.reshape(B * T, H)
+        for li, L in enumerate(self.layers):
+            h = ops.rmsnorm(x, L["n1"], l.rms_eps)
+            qkv = ops.linear(h, L["wqkv"])
+            kc, vc = cache["k"][li], cache["v"][li]
+            ops.rope_cache(qkv, kc, vc, cs, B, T, nh, nh, hd, pos0)
+            tk = pos0 + T
+            q = qkv.view(B, T, 3, nh, hd)[:, :, 0].permute(0, 2, 1, 3)
+            k = kc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)[:, :, :tk]
+            v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)[:, :, :tk]
+            a = ops.attention(q, k, v, hd ** -0.5, causal=T > 1, q_pos0=tk - T)
+            x = ops.linear(a.view(B * T, H), L["wo"], resid=x, out=x)
+            h = ops.rmsnorm(x, L["n2"], l.rms_eps)
+            g = ops.linear(h, L["wgu"], swiglu=True)
+            x = ops.linear(g, L["wd"], resid=x, out=x)
+        cache["len"] = pos0 + T
+        return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, T, H)
+
+    def next_token_logits(self, hidden_last):
+        """hidden_last [B,H] -> fp32 logits [B,V] (lm_head, no bias; llava_llama.py:105)."""
+        return ops.linear(hidden_last, self.lm_head, out_dtype=torch.float32)

@@ -1,0 +1,272 @@
+"""SAM half of the 2Haff hot path on MI355X: ViT image encoder, text-prompt encoder, left/right two-way mask
+decoders and mask post-processing — host-side orchestration of the HIP kernels in csrc/ (no torch math).
+
+Mirrors (same parameter names, same numerics contract) the reference's
+  2Haff/model/segment_anything/modeling/image_encoder.py  (ImageEncoderViT.forward :110-125, Block :177-193)
+  .../prompt_encoder.py (text path :140-186, get_dense_pe :67-76), .../mask_decoder.py (:79-178),
+  .../transformer.py (:62-106,151-182), .../sam.py postprocess_masks (:155-189)
+but batched over frames and prompts, channels-last everywhere, weights re-laid-out once at load time.
+"""
+import math
+
+import torch
+
+from . import ops
+
+V = "model.visual_model"
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class SamEncoderHip:
+    """ImageEncoderViT: [B,3,S,S] normalised frames (or uint8 NHWC frames) -> [B, g*g, out_chans] channels-last."""
+
+    def __init__(self, sd, cfg, dtype, device):
+        s = self.cfg = cfg
+        self.dtype, self.device = dtype, device
+        E = V + ".image_encoder"
+        C = s.embed_dim
+        g = s.grid
+        dev = device
+        self.hd = C // s.heads
+        self.w_patch = sd[E + ".patch_embed.proj.weight"].reshape(C, -1).to(dev, dtype).contiguous()
+        self.b_patch = _f32(sd[E + ".patch_embed.proj.bias"], dev)
+        self.pos = sd[E + ".pos_embed"].reshape(g * g, C).to(dev, dtype).contiguous()
+        self.blocks = []
+        for i in range(s.depth):
+            B = f"{E}.blocks.{i}"
+            is_global = i in s.global_idx
+            S = g if is_global else s.window
+            blk = {
+                "global": is_global, "S": S,
+                "n1w": _f32(sd[B + ".norm1.weight"], dev), "n1b": _f32(sd[B + ".norm1.bias"], dev),
+                "wqkv": sd[B + ".attn.qkv.weight"].to(dev, dtype).contiguous(), "bqkv": _f32(sd[B + ".attn.qkv.bias"], dev),
+                "wproj": sd[B + ".attn.proj.weight"].to(dev, dtype).contiguous(), "bproj": _f32(sd[B + ".attn.proj.bias"], dev),
+                "rel_h": _f32(self._fit_rel_pos(sd[B + ".attn.rel_pos_h"], S), dev),
+                "rel_w": _f32(self._fit_rel_pos(sd[B + ".attn.rel_pos_w"], S), dev),
+                "n2w": _f32(sd[B + ".norm2.weight"], dev), "n2b": _f32(sd[B + ".norm2.bias"], dev),
+                "w1": sd[B + ".mlp.lin1.weight"].to(dev, dtype).contiguous(), "b1": _f32(sd[B + ".mlp.lin1.bias"], dev),
+                "w2": sd[B + ".mlp.lin2.weight"].to(dev, dtype).contiguous(), "b2": _f32(sd[B + ".mlp.lin2.bias"], dev),
+            }
+            self.blocks.append(blk)
+        self.w_neck0 = sd[E + ".neck.0.weight"].reshape(s.out_chans, C).to(dev, dtype).contiguous()
+        self.neck1 = (_f32(sd[E + ".neck.1.weight"], dev), _f32(sd[E + ".neck.1.bias"], dev))
+        # 3x3 conv as GEMM over (ky, kx, cin) columns — matches haff_im2col3x3
+        self.w_neck2 = sd[E + ".neck.2.weight"].permute(0, 2, 3, 1).reshape(s.out_chans, -1).to(dev, dtype).contiguous()
+        self.neck3 = (_f32(sd[E + ".neck.3.weight"], dev), _f32(sd[E + ".neck.3.bias"], dev))
+        self._maps = {}
+
+    @staticmethod
+    def _fit_rel_pos(table, S):
+        """get_rel_pos's interpolation branch (image_encoder.py:333-344); a no-op for SAM checkpoints."""
+        L = 2 * S - 1
+        if table.shape[0] == L:
+            return table
+        t = torch.nn.functional.interpolate(table.float().reshape(1, table.shape[0], -1).permute(0, 2, 1), size=L, mode="linear")
+        return t.reshape(-1, L).permute(1, 0)
+
+    def _window_maps(self, B):
+        """Gather map (window row -> image token row, -1 = zero pad) used both ways (image_encoder.py:263-318)."""
+        if B in self._maps:
+            return self._maps[B]
+        s = self.cfg
+        g, ws = s.grid, s.window
+        gp = (g + ws - 1) // ws * ws
+        nw = gp // ws
+        idx = torch.full((B, gp, gp), -1, dtype=torch.int64)
+        base = torch.arange(g * g).view(g, g)
+        for b in range(B):
+            idx[b, :g, :g] = base + b * g * g
+        win = idx.view(B, nw, ws, nw, ws).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.int32).to(self.device)
+        self._maps[B] = (win, nw * nw)
+        return self._maps[B]
+
+    def patch_rows_from_nchw(self, images):
+        s = self.cfg
+        return ops.patchify_nchw(images, s.patch, s.grid, s.grid, 3 * s.patch * s.patch, self.dtype)
+
+    def patch_rows_from_u8(self, frames, mean, std):
+        s = self.cfg
+        return ops.patchify_u8(frames, s.patch, s.grid, s.grid, 3 * s.patch * s.patch, mean, std, self.dtype)
+
+    def forward_rows(self, rows, B, taps=None):
+        s = self.cfg
+        C, g, H, hd = s.embed_dim, s.grid, s.heads, self.hd
+        N = g * g
+        x = ops.linear(rows, self.w_patch, bias=self.b_patch)
+        x = ops.add_bcast(x, self.pos, mod=N, out=x)
+        scale = hd ** -0.5
+        for i, blk in enumerate(self.blocks):
+            if blk["global"]:
+                xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6)
+                nb, ntok, S, row_map = B, N, g, None
+            else:
+                win, nw2 = self._window_maps(B)
+                xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, in_map=win)
+                nb, ntok, S, row_map = B * nw2, s.window * s.window, s.window, win
+            qkv = ops.linear(xn, blk["wqkv"], bias=blk["bqkv"])
+            q5 = qkv.view(nb, ntok, 3, H, hd)
+            q = q5[:, :, 0].permute(0, 2, 1, 3)
+            k = q5[:, :, 1].permute(0, 2, 1, 3)
+            v = q5[:, :, 2].permute(0, 2, 1, 3)
+            relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
+            a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
+            del relh, relw, qkv
+            ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
+            h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6)
+            h = ops.linear(h, blk["w1"], bias=blk["b1"], act=ops.ACT_GELU)
+            ops.linear(h, blk["w2"], bias=blk["b2"], resid=x, out=x)
+            if taps is not None:
+                taps[f"block{i}"] = x.float().view(B, g, g, C).cpu()
+        y = ops.linear(x, self.w_neck0)
+        y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
+        cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
+        y = ops.linear(cols, self.w_neck2)
+        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6)
+        return y.view(B, N, s.out_chans)
+
+    def __call__(self, images, taps=None):
+        """images [B,3,S,S] already normalised/padded (the evaluate() contract, LISA.py:487)."""
+        images = images.to(self.dtype)
+        return self.forward_rows(self.patch_rows_from_nchw(images), images.shape[0], taps)
+
+
+class SamDecoderSideHip:
+    """One MaskDecoder (left: taxonomy head on; right: off), batched over prompts."""
+
+    def __init__(self, sd, pfx, cfg, dtype, device, taxonomy_on):
+        self.dtype, self.device, self.taxonomy_on = dtype, device, taxonomy_on
+        self.C = C = cfg.out_chans
+        dev = device
+
+        def lin(name):
+            return sd[name + ".weight"].to(dev, dtype).contiguous(), _f32(sd[name + ".bias"], dev)
+
+        def norm(name):
+            return _f32(sd[name + ".weight"], dev), _f32(sd[name + ".bias"], dev)
+
+        def attn(name):
+            return {n: lin(f"{name}.{n}_proj") for n in ("q", "k", "v", "out")}
+        self.out_tokens = torch.cat([sd[pfx + ".iou_token.weight"], sd[pfx + ".mask_tokens.weight"]], 0).to(dev, dtype)
+        T = pfx + ".transformer"
+        self.layers = []
+        for l in range(2):
+            L = f"{T}.layers.{l}"
+            self.layers.append({
+                "self": attn(L + ".self_attn"), "t2i": attn(L + ".cross_attn_token_to_image"),
+                "i2t": attn(L + ".cross_attn_image_to_token"),
+                "n1": norm(L + ".norm1"), "n2": norm(L + ".norm2"), "n3": norm(L + ".norm3"), "n4": norm(L + ".norm4"),
+                "lin1": lin(L + ".mlp.lin1"), "lin2": lin(L + ".mlp.lin2")})
+        self.final = attn(T + ".final_attn_token_to_image")
+        self.nf = norm(T + ".norm_final_attn")
+        # ConvTranspose2d(C -> C/4, k2 s2) as a per-pixel GEMM: output column (dy*2+dx)*C/4 + co
+        w = sd[pfx + ".output_upscaling.0.weight"]  # [ci, co, dy, dx]
+        self.w_up1 = w.permute(2, 3, 1, 0).reshape(4 * (C // 4), C).to(dev, dtype).contiguous()
+        self.b_up1 = _f32(sd[pfx + ".output_upscaling.0.bias"].repeat(4), dev)
+        self.ln_up = norm(pfx + ".output_upscaling.1")
+        w = sd[pfx + ".output_upscaling.3.weight"]  # [co, c2, dy2, dx2] -> [co][(dy2,dx2,c2)]
+        self.w_up2 = _f32(w.permute(0, 2, 3, 1).reshape(C // 4, 4 * (C // 8)), dev)
+        self.b_up2 = _f32(sd[pfx + ".output_upscaling.3.bias"], dev)
+        self.hyper = [[lin(f"{pfx}.output_hypernetworks_mlps.{i}.layers.{j}") for j in range(3)] for i in range(4)]
+        self.iou_head = [lin(f"{pfx}.iou_prediction_head.layers.{j}") for j in range(3)]
+        if taxonomy_on:
+            self.tax = [lin(f"{pfx}.taxonomy_embed.layers.{j}") for j in range(3)]
+
+    def _attend(self, w, q_in, k_in, v_in, P, nq, nk, heads=8):
+        qp = ops.linear(q_in, *w["q"])
+        kp = ops.linear(k_in, *w["k"])
+        vp = ops.linear(v_in, *w["v"])
+        d = qp.shape[1] // heads
+        q = qp.view(P, nq, heads, d).permute(0, 2, 1, 3)
+        k = kp.view(P, nk, heads, d).permute(0, 2, 1, 3)
+        v = vp.view(P, nk, heads, d).permute(0, 2, 1, 3)
+        a = ops.attention(q, k, v, 1.0 / math.sqrt(d))
+        return a.view(P * nq, heads * d), w["out"]
+
+    def _mlp3(self, layers, x, last_f32=True):
+        x = ops.linear(x, *layers[0], act=ops.ACT_RELU)
+        x = ops.linear(x, *layers[1], act=ops.ACT_RELU)
+        return ops.linear(x, *layers[2], out_dtype=torch.float32 if last_f32 else None)
+
+    def __call__(self, src, key_pe, text, grid, taps=None):
+        """src [P, N, C] (image embedding + dense prompt), key_pe [N, C], text [P, C] -> low-res logits [P,4g,4g]."""
+        P, N, C = src.shape
+        nt = 6
+        tokens = torch.cat([self.out_tokens.unsqueeze(0).expand(P, -1, -1), text.view(P, 1, C).to(self.dtype)], dim=1)
+        tokens = tokens.contiguous().view(P * nt, C)
+        queries = tokens
+        keys = src.reshape(P * N, C)
+        for li, L in enumerate(self.layers):
+            if li == 0:
+                a, wo = self._attend(L["self"], queries, queries, queries, P, nt, nt)
+                queries = ops.linear(a, *wo)
+            else:
+                q = ops.add_bcast(queries, tokens)
+                a, wo = self._attend(L["self"], q, q, queries, P, nt, nt)
+                queries = ops.linear(a, *wo, resid=queries)
+            queries = ops.layernorm(queries, *L["n1"], 1e-5)
+            q = ops.add_bcast(queries, tokens)
+            k = ops.add_bcast(keys, key_pe, mod=N)
+            a, wo = self._attend(L["t2i"], q, k, keys, P, nt, N)
+            queries = ops.layernorm(ops.linear(a, *wo, resid=queries), *L["n2"], 1e-5)
+            h = ops.linear(queries, *L["lin1"], act=ops.ACT_RELU)
+            queries = ops.layernorm(ops.linear(h, *L["lin2"], resid=queries), *L["n3"], 1e-5)
+            q = ops.add_bcast(queries, tokens)
+            a, wo = self._attend(L["i2t"], k, q, queries, P, N, nt)
+            keys = ops.layernorm(ops.linear(a, *wo, resid=keys), *L["n4"], 1e-5)
+            if taps is not None:
+                taps[f"layer{li}.queries"] = queries.float().view(P, nt, C).cpu()
+                taps[f"layer{li}.keys"] = keys.float().view(P, N, C).cpu()
+        q = ops.add_bcast(queries, tokens)
+        k = ops.add_bcast(keys, key_pe, mod=N)
+        a, wo = self._attend(self.final, q, k, keys, P, nt, N)
+        queries = ops.layernorm(ops.linear(a, *wo, resid=queries), *self.nf, 1e-5)
+        hs = queries.view(P, nt, C)
+        up1 = ops.linear(keys, self.w_up1, bias=self.b_up1)
+        hyper0 = self._mlp3(self.hyper[0], hs[:, 1])
+        low_res = ops.upscale_mask(up1, self.ln_up[0], self.ln_up[1], self.w_up2, self.b_up2, hyper0, P, grid, grid)
+        iou = self._mlp3(self.iou_head, hs[:, 0])[:, 0:1]
+        tax = None
+        if self.taxonomy_on:
+            tax = ops.softmax_rows(self._mlp3(self.tax, hs[:, 1:5].reshape(P, 4 * C)).contiguous())
+        return low_res, iou, tax
+
+
+class SamPromptDecoderHip:
+    """PromptEncoder text path + both decoders + postprocess (LISA.py:494-532), batched over all prompts."""
+
+    def __init__(self, sd, cfg, dtype, device):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        P = V + ".prompt_encoder"
+        g = cfg.grid
+        C = cfg.out_chans
+        # dense PE is input-independent: compute once (prompt_encoder.py:203-229), x first then y
+        G = sd[P + ".pe_layer.positional_encoding_gaussian_matrix"].float()
+        ys = (torch.arange(g, dtype=torch.float32) + 0.5) / g
+        xs = (torch.arange(g, dtype=torch.float32) + 0.5) / g
+        coords = torch.stack([xs[None, :].expand(g, g), ys[:, None].expand(g, g)], dim=-1)
+        c = 2 * math.pi * ((2 * coords - 1) @ G)
+        self.key_pe = torch.cat([torch.sin(c), torch.cos(c)], dim=-1).reshape(g * g, C).to(device, dtype).contiguous()
+        self.no_mask = sd[P + ".no_mask_embed.weight"].reshape(1, C).to(device, dtype).contiguous()
+        self.left = SamDecoderSideHip(sd, V + ".mask_decoder_left", cfg, dtype, device, True)
+        self.right = SamDecoderSideHip(sd, V + ".mask_decoder_right", cfg, dtype, device, False)
+
+    def decode(self, emb, frame_idx, text, taps=None):
+        """emb [Bf, N, C]; frame_idx int64 [P] (prompt -> frame); text [P, C]."""
+        P = text.shape[0]
+        N, C = emb.shape[1], emb.shape[2]
+        src = emb.index_select(0, frame_idx).reshape(P * N, C)
+        src = ops.add_bcast(src, self.no_mask, mod=1).view(P, N, C)
+        lo_l, iou_l, tax = self.left(src, self.key_pe, text, self.cfg.grid, taps)
+        lo_r, iou_r, _ = self.right(src, self.key_pe, text, self.cfg.grid)
+        return lo_l, lo_r, tax, iou_l, iou_r
+
+    def postprocess(self, low_res, input_size, original_size):
+        """Sam.postprocess_masks (sam.py:177-188): x4 bilinear to img_size, crop, bilinear to original size."""
+        S = self.cfg.img_size
+        m = ops.resize_bilinear(low_res, low_res.shape[-2:], (S, S))
+        if tuple(input_size) == (S, S) and tuple(original_size) == (S, S):
+            return m  # second interpolate is the identity (scale 1, lambda 0)
+        return ops.resize_bilinear(m, input_size, original_size)

@@ -1,0 +1,178 @@
+"""End-to-end and stage-level parity of the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded weights/inputs (BASELINE.json configs[0] "tiny" plus a "mid" geometry with window padding, d=80, d=128).
+
+Tolerances (stated per BASELINE.json north_star):
+  * fp32 parity mode: final mask logits within 1e-3 abs of the oracle; binary masks (logit > 0) bit-exact wherever
+    the oracle logit is farther than 1e-3 from zero; taxonomy within 1e-4.
+  * bf16 throughput mode: the oracle runs on the SAME bf16-rounded weights/inputs in fp32; bf16 storage of
+    activations bounds the error by a few percent of the logit scale, checked as rel <= 6e-2 of the max |logit|
+    and mask IoU >= 0.97 on these random-weight models (random logits are dense around 0; SURVEY §7 hard part 3).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+V = "model.visual_model"
+
+
+def _setup(cfg_name, mode, seed=5, B=2, n_gen=4, prompt_len=8):
+    import haff  # noqa: F401
+    from haff import config as hcfg
+    from haff import weights as hw
+    cfg = getattr(hcfg, cfg_name)()
+    sd = hw.make_state_dict(cfg, seed)
+    rng = np.random.default_rng(seed + 7)
+    S = cfg.sam.img_size
+    images = torch.from_numpy(rng.standard_normal((B, 3, S, S), dtype=np.float32))
+    images_clip = torch.from_numpy(rng.standard_normal((B, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)
+        images = images.to(torch.bfloat16).float()
+        images_clip = images_clip.to(torch.bfloat16).float()
+    text = torch.from_numpy(rng.integers(3, cfg.llm.vocab - 3, size=(B, prompt_len))).long()
+    ids = torch.cat([torch.tensor([[cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]]).expand(B, -1), text], 1)
+    forced = torch.from_numpy(rng.integers(3, cfg.llm.vocab - 3, size=(B, n_gen))).long()
+    forced[:, 1] = cfg.seg_token_idx
+    forced[:, -1] = cfg.eos_token_id
+    return cfg, sd, images, images_clip, ids, forced
+
+
+def _iou(a, b):
+    inter = (a & b).sum().item()
+    union = (a | b).sum().item()
+    return inter / union if union else 1.0
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "mid"])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_evaluate_matches_oracle(dev, cfg_name, mode):
+    from haff.lisa import LisaMI355
+    from oracle import lisa_oracle as O
+    cfg, sd, images, images_clip, ids, forced = _setup(cfg_name, mode)
+    S = cfg.sam.img_size
+    B = ids.shape[0]
+    resize = [(S, S), (S, S - 32)]
+    orig = [(S, S), (S // 2 + 3, S // 2 - 10)]
+    with torch.no_grad():
+        ref_ids, ref_l, ref_r, ref_t = O.lisa_evaluate(sd, cfg, images_clip, images, ids, resize, orig,
+                                                       max_new_tokens=forced.shape[1], forced_answer=forced, use_cache=False)
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
+    out_ids, left, right, tax = model.evaluate(images_clip.to(dev), images.to(dev), ids.to(dev), resize, orig,
+                                               max_new_tokens=forced.shape[1], forced_answer=forced)
+    assert torch.equal(out_ids.cpu(), ref_ids)
+    assert len(left) == len(right) == len(tax) == B
+    for i in range(B):
+        for got, ref, name in ((left[i], ref_l[i], "left"), (right[i], ref_r[i], "right")):
+            assert got.shape == ref.shape and got.dtype == torch.float32
+            g = got.cpu()
+            err = (g - ref).abs().max().item()
+            scale = ref.abs().max().item()
+            iou = _iou(g > 0, ref > 0)
+            print(f"{cfg_name}/{mode} frame{i} {name}: max|err|={err:.3e} scale={scale:.3f} std={ref.std():.3f} IoU={iou:.5f}")
+            if mode == "f32":
+                assert err <= 1e-3, f"{name} logits off by {err}"
+                safe = ref.abs() > 1e-3
+                assert torch.equal((g > 0)[safe], (ref > 0)[safe])
+            else:
+                assert err <= 6e-2 * scale, f"{name} logits rel err {err / scale}"
+                assert iou >= 0.97
+        terr = (tax[i].cpu() - ref_t[i]).abs().max().item()
+        print(f"{cfg_name}/{mode} frame{i} taxonomy err {terr:.3e}")
+        assert terr <= (1e-4 if mode == "f32" else 3e-2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_stages_match_oracle(dev, mode):
+    """Stage taps on the mid geometry: SAM encoder blocks, CLIP features, projector, Llama hidden (prefill +
+    KV-cached steps vs the oracle's no-cache recompute), decoder low-res logits."""
+    from haff.lisa import LisaMI355
+    from oracle import lisa_oracle as O
+    cfg, sd, images, images_clip, ids, forced = _setup("mid", mode)
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    tol = 2e-4 if mode == "f32" else 5e-2
+    model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
+
+    def rel(got, ref):
+        return ((got.float().cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+    with torch.no_grad():
+        taps_ref, taps = {}, {}
+        emb_ref = O.sam_image_encoder(sd, V + ".image_encoder", images, cfg.sam, taps_ref)
+        emb = model.sam_encoder(images.to(dev), taps)
+        g = cfg.sam.grid
+        for i in range(cfg.sam.depth):
+            r = rel(taps[f"block{i}"], taps_ref[f"block{i}"])
+            print(f"{mode} sam block{i} rel {r:.3e}")
+            assert r <= tol
+        r = rel(emb.view(-1, g, g, cfg.sam.out_chans).permute(0, 3, 1, 2), emb_ref)
+        print(f"{mode} sam neck rel {r:.3e}")
+        assert r <= tol * 2
+        f_ref = O.encode_images(sd, cfg, images_clip)
+        f = model.encode_images(images_clip.to(dev))
+        r = rel(f, f_ref)
+        print(f"{mode} clip+projector rel {r:.3e}")
+        assert r <= tol
+        ids_ref, hid_ref = O.lisa_generate(sd, cfg, images_clip, ids, forced.shape[1], forced, use_cache=False)
+        out_ids, hid = model.generate(images_clip.to(dev), ids.to(dev), forced.shape[1], forced)
+        assert torch.equal(out_ids.cpu(), ids_ref) and hid.shape == hid_ref.shape
+        r = rel(hid, hid_ref)
+        print(f"{mode} llama hidden rel {r:.3e}")
+        assert r <= tol
+        # decoder fed with the ORACLE's embedding and text so this stage is checked in isolation
+        text = torch.from_numpy(np.random.default_rng(3).standard_normal((3, cfg.out_dim), dtype=np.float32))
+        if mode == "bf16":
+            text = text.to(torch.bfloat16).float()
+            emb_ref = emb_ref.to(torch.bfloat16).float()
+        pe = O.sam_dense_pe(sd, V + ".prompt_encoder", (g, g))
+        fidx = torch.tensor([0, 1, 1])
+        emb_cl = emb_ref.flatten(2).permute(0, 2, 1).contiguous().to(dev, dtype)
+        lo_l, lo_r, tax, iou_l, iou_r = model.sam_decoder.decode(emb_cl, fidx.to(dev), text.to(dev, dtype))
+        for p in range(3):
+            sp, de = O.sam_prompt_encoder_text(sd, V + ".prompt_encoder", text[p:p + 1, None], (g, g))
+            rl, ril, rt = O.sam_mask_decoder(sd, V + ".mask_decoder_left", emb_ref[fidx[p]:fidx[p] + 1], pe, sp, de, True)
+            rr, rir = O.sam_mask_decoder(sd, V + ".mask_decoder_right", emb_ref[fidx[p]:fidx[p] + 1], pe, sp, de, False)
+            e1, e2 = rel(lo_l[p], rl[0, 0]), rel(lo_r[p], rr[0, 0])
+            print(f"{mode} decoder prompt{p} rel L {e1:.3e} R {e2:.3e} tax {rel(tax[p], rt[0]):.3e} iou {rel(iou_l[p], ril[0]):.3e}")
+            assert max(e1, e2) <= tol * 2 and rel(tax[p], rt[0]) <= tol * 2 and rel(iou_l[p], ril[0]) <= tol * 2
+
+
+def test_u8_ingest_equals_float_contract(dev):
+    """uint8 NHWC frame ingest (fused normalise+pad+patchify) == the evaluate() float-tensor contract."""
+    from haff.lisa import LisaMI355
+    from haff.preprocess import sam_preprocess
+    cfg, sd, _, images_clip, ids, forced = _setup("tiny", "bf16")
+    S = cfg.sam.img_size
+    rng = np.random.default_rng(0)
+    frames = torch.from_numpy(rng.integers(0, 256, size=(2, S, S, 3), dtype=np.uint8))
+    images = torch.stack([sam_preprocess(f, S) for f in frames])
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev)
+    a = model.get_visual_embs(images.to(dev))
+    b = model.get_visual_embs_u8(frames.to(dev), (123.675, 116.28, 103.53), (58.395, 57.12, 57.375))
+    assert torch.equal(a, b)
+
+
+def test_no_seg_token_gives_empty_masks(dev):
+    from haff.lisa import LisaMI355
+    cfg, sd, images, images_clip, ids, forced = _setup("tiny", "bf16")
+    forced[:, 1] = 5  # no [SEG] anywhere
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev)
+    S = cfg.sam.img_size
+    _, left, right, tax = model.evaluate(images_clip.to(dev), images.to(dev), ids.to(dev), [(S, S)] * 2, [(S, S)] * 2,
+                                         max_new_tokens=4, forced_answer=forced)
+    assert all(m.shape == (0, S, S) for m in left + right) and all(t.shape == (0, 4) for t in tax)
+
+
+def test_batch_invariance_and_determinism(dev):
+    """Frame i's masks do not depend on its batch neighbours, and repeated runs are bitwise identical."""
+    from haff.lisa import LisaMI355
+    cfg, sd, images, images_clip, ids, forced = _setup("tiny", "bf16", B=3)
+    S = cfg.sam.img_size
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev)
+    args = lambda sl: (images_clip[sl].to(dev), images[sl].to(dev), ids[sl].to(dev), [(S, S)] * len(ids[sl]), [(S, S)] * len(ids[sl]))
+    _, l3, r3, t3 = model.evaluate(*args(slice(0, 3)), max_new_tokens=4, forced_answer=forced)
+    _, l3b, _, _ = model.evaluate(*args(slice(0, 3)), max_new_tokens=4, forced_answer=forced)
+    _, l1, r1, t1 = model.evaluate(*args(slice(1, 2)), max_new_tokens=4, forced_answer=forced[1:2])
+    assert all(torch.equal(a, b) for a, b in zip(l3, l3b))
+    assert torch.equal(l3[1], l1[0]) and torch.equal(r3[1], r1[0]) and torch.equal(t3[1], t1[0])
