@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Benchmark of the 2Haff per-frame affordance path on MI355X (contract: see the task's bench.py section).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (LisaMI355.evaluate: CLIP -> projector -> Llama prefill + KV-cached greedy
+decode -> [SEG] -> SAM ViT-H encoder -> left/right mask decoders -> postprocess) over one batch of synthetic
+frames already resident in HBM. Default workload = BASELINE.json configs[2]: 2HandedAfforder-7B, 64 x 1024^2
+uint8 NHWC frames, 32-token prompts (L=36, T=291), 8 forced answer tokens with [SEG], bf16. Frames are
+independent units: for N>1 every rank processes its own batch (weak scaling, no data-path collective).
+One JSON line on rank 0: metric/value (+ roofline of the dominant kernel, + cpu_baseline = the CPU oracle
+timed on a bounded, depth-reduced sample and extrapolated by layer counts).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import haff  # noqa: E402,F401
+from haff import config as hcfg  # noqa: E402
+from haff import flops as hflops  # noqa: E402
+from haff import ops  # noqa: E402
+from haff import weights as hw  # noqa: E402
+from haff.lisa import LisaMI355  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md §Chip-level parameters)
+SURVEY_FLOPS = {"2HandedAfforder-7B": 10.01e12, "2HandedAfforder-13B": 13.73e12}
+
+
+def make_inputs(cfg, B, text_tokens, n_gen, device, seed=1234):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    S = cfg.sam.img_size
+    noise = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.int32).float()
+    yy = torch.linspace(0, 255, S).view(1, S, 1, 1)
+    xx = torch.linspace(255, 0, S).view(1, 1, S, 1)
+    frames = (0.5 * noise + 0.25 * yy + 0.25 * xx).round().clamp(0, 255).to(torch.uint8)
+    images_clip = torch.randn((B, 3, cfg.clip.image, cfg.clip.image), generator=g).to(torch.bfloat16)
+    hi = min(cfg.llm.vocab, cfg.seg_token_idx) - 1
+    text = torch.randint(3, hi, (B, text_tokens), generator=g)
+    head = torch.tensor([[cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]]).expand(B, -1)
+    ids = torch.cat([head, text], 1).long()
+    forced = torch.randint(3, hi, (B, n_gen), generator=g).long()
+    forced[:, 2] = cfg.seg_token_idx
+    forced[:, -1] = cfg.eos_token_id
+    return frames.to(device), images_clip.to(device), ids.to(device), forced.to(device)
+
+
+class GemmMeter:
+    """HIP-event pairs around every bf16 GEMM launch (torch's current stream IS the launch stream)."""
+
+    def __init__(self):
+        self.records = []
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = ops.linear
+        meter = self
+
+        def timed(x, w, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = meter._orig(x, w, *a, **kw)
+            e1.record()
+            meter.records.append((e0, e1, 2.0 * x.shape[0] * x.shape[1] * w.shape[0]))
+            return out
+        ops.linear = timed
+        return self
+
+    def __exit__(self, *exc):
+        ops.linear = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), ms, fl
+
+
+def cpu_baseline(cfg, text_tokens, n_gen, threads):
+    """The CPU oracle (fp32 torch eager restatement of the reference) on a bounded sample: full-width layers,
+    reduced depth, one 1024^2 frame; per-layer times are extrapolated to the full depth."""
+    import copy
+    from oracle import lisa_oracle as O
+    torch.set_num_threads(threads)
+    V = "model.visual_model"
+    s = copy.deepcopy(cfg.sam)
+    s.depth, s.global_idx = 2, (1,)
+    c = copy.deepcopy(cfg.clip)
+    c.layers, c.select_layer = 2, 2
+    small = copy.deepcopy(cfg)
+    small.sam, small.clip = s, c
+    small.llm = copy.deepcopy(cfg.llm)
+    small.llm.layers = 1
+    shapes = hw.all_shapes(small)
+    sd = hw.make_state_dict(small, 99, shapes)
+    g = torch.Generator().manual_seed(0)
+
+    def tm(fn, reps=1):
+        best = 1e30
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t)
+        return best
+    with torch.no_grad():
+        S, gr, C = s.img_size, s.grid, s.embed_dim
+        img = torch.randn((1, 3, S, S), generator=g)
+        x = torch.randn((1, gr, gr, C), generator=g)
+        E = V + ".image_encoder"
+        t_all = tm(lambda: O.sam_image_encoder(sd, E, img, s))
+        t_win = tm(lambda: O.sam_block(sd, E + ".blocks.0", x, s.heads, s.window))
+        t_glob = tm(lambda: O.sam_block(sd, E + ".blocks.1", x, s.heads, 0))
+        n_glob = len(cfg.sam.global_idx)
+        t_sam = max(t_all - t_win - t_glob, 0.0) + (cfg.sam.depth - n_glob) * t_win + n_glob * t_glob
+        ic = torch.randn((1, 3, c.image, c.image), generator=g)
+        c1 = copy.deepcopy(c)
+        c1.select_layer = 1
+        t_c2 = tm(lambda: O.clip_vision_features(sd, "model.vision_tower.vision_tower", ic, c), 2)
+        t_c1 = tm(lambda: O.clip_vision_features(sd, "model.vision_tower.vision_tower", ic, c1), 2)
+        per_clip = max(t_c2 - t_c1, 1e-6)
+        n_clip = cfg.clip.layers + 1 + cfg.clip.select_layer if cfg.clip.select_layer < 0 else cfg.clip.select_layer
+        t_clip = max(t_c1 - per_clip, 0.0) + n_clip * per_clip
+        T = 4 + text_tokens + cfg.clip.n_patches - 1
+        xe = torch.randn((1, T, cfg.llm.hidden), generator=g)
+        cache = [None]
+        t_pre = tm(lambda: O.llama_forward(sd, xe, small.llm, [None]))
+        O.llama_forward(sd, xe, small.llm, cache)
+        x1 = torch.randn((1, 1, cfg.llm.hidden), generator=g)
+        kv = cache[0]
+
+        def dec():
+            O.llama_forward(sd, x1, small.llm, [kv])
+        t_dec = tm(dec, 3)
+        hrow = torch.randn((1, cfg.llm.hidden), generator=g)
+        t_head = tm(lambda: torch.nn.functional.linear(hrow, sd["lm_head.weight"]), 3)
+        t_llm = cfg.llm.layers * (t_pre + (n_gen - 1) * t_dec) + n_gen * t_head
+        t_llm_ref = cfg.llm.layers * n_gen * t_pre + n_gen * t_head  # reference: no KV cache (LISA.py:115)
+        emb = torch.randn((1, s.out_chans, gr, gr), generator=g)
+        pe = O.sam_dense_pe(sd, V + ".prompt_encoder", (gr, gr))
+        txt = torch.randn((1, 1, s.out_chans), generator=g)
+
+        def decs():
+            sp, de = O.sam_prompt_encoder_text(sd, V + ".prompt_encoder", txt, (gr, gr))
+            for side, tax in (("left", True), ("right", False)):
+                lo = O.sam_mask_decoder(sd, f"{V}.mask_decoder_{side}", emb, pe, sp, de, tax)[0]
+                O.sam_postprocess_masks(lo, S, (S, S), (S, S))
+        t_dec2 = tm(decs)
+    t_frame = t_sam + t_clip + t_llm + t_dec2
+    t_frame_ref = t_sam + n_gen * t_clip + t_llm_ref + t_dec2
+    return {
+        "value": 1.0 / t_frame, "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": ("CPU oracle (oracle/lisa_oracle.py, fp32 torch eager) on ONE 1024^2 frame with full-width, "
+                   "reduced-depth stacks (SAM: patch+neck + 1 windowed + 1 global block; CLIP: 1-2 layers; Llama: 1 "
+                   "layer prefill T=%d + 1 cached step + lm_head; both mask decoders + postprocess), each per-layer "
+                   "time multiplied by the full layer count; KV-cached schedule" % T),
+        "seconds_per_frame": t_frame,
+        "reference_semantics_value": 1.0 / t_frame_ref,
+        "reference_semantics_note": "no KV cache and CLIP re-run per generated token (LISA.py:115, llava_llama.py:82-90)",
+        "parts_s": {"sam_encoder": t_sam, "clip": t_clip, "llm": t_llm, "decoders": t_dec2},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="7b", choices=["7b", "13b", "tiny", "mid"])
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--text-tokens", type=int, default=32)
+    ap.add_argument("--n-gen", type=int, default=8)
+    ap.add_argument("--sam-chunk", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
+    sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=device, sam_chunk=args.sam_chunk)
+    del sd
+    torch.cuda.empty_cache()
+    B, S = args.batch, cfg.sam.img_size
+    frames, images_clip, ids, forced = make_inputs(cfg, B, args.text_tokens, args.n_gen, device, seed=1234 + rank)
+    sizes = [(S, S)] * B
+
+    def step(n=B):
+        return model.evaluate(images_clip[:n], None, ids[:n], sizes[:n], sizes[:n], max_new_tokens=args.n_gen,
+                              forced_answer=forced[:n], frames_u8=frames[:n])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    fps = world * B * args.steps / elapsed
+
+    if rank == 0:
+        flops_frame = SURVEY_FLOPS.get(cfg.name) or hflops.frame_flops(cfg, args.text_tokens, args.n_gen)["total"]
+        with GemmMeter() as meter:
+            step()
+        n_launch, gemm_ms, gemm_fl = meter.summary()
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": "gemm_bf16_kernel (haff_gemm_bf16, all epilogue variants)",
+            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+            "traffic": None,
+            "launches_per_step": n_launch, "avg_launch_us": 1e3 * gemm_ms / n_launch,
+            "flops_per_launch_avg": gemm_fl / n_launch, "gemm_share_of_step": gemm_ms / ms_per_step,
+            "whole_path": {"flops_per_frame": flops_frame, "achieved": fps / world * flops_frame / 1e12,
+                           "frac": fps / world * flops_frame / 1e12 / PEAK_BF16_TFLOPS},
+        }
+        line = {
+            "metric": "affordance frames/sec/GPU @1024^2, 32-tok prompt; mask IoU vs ref",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: %s, %d x %dx%d uint8 NHWC frames/step/GPU, %d-token prompt "
+                                   "(T=%d), %d forced answer tokens with [SEG], KV-cached greedy decode, random-init weights"
+                                   % (cfg.name, B, S, S, args.text_tokens, 4 + args.text_tokens + cfg.clip.n_patches - 1, args.n_gen),
+                       "frames_per_step_per_gpu": B, "parallelism": "frame-sharded replicas x%d (no collective)" % world},
+            "frames_per_s_per_gpu": fps / world,
+            "roofline": roofline,
+        }
+        # sanity of the produced masks (finite, right shapes)
+        ok = all(m.shape == (1, S, S) and bool(torch.isfinite(m).all()) for m in out[1] + out[2])
+        line["outputs_finite"] = ok
+        if not args.no_b1:
+            for _ in range(2):
+                step(1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                step(1)
+            torch.cuda.synchronize()
+            line["latency_batch1_ms"] = 1e3 * (time.perf_counter() - t1) / 5
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(len(os.sched_getaffinity(0)), 32)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.text_tokens, args.n_gen, threads)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
