@@ -243,7 +243,7 @@ class SamPromptDecoderHip:
         g = cfg.grid
         C = cfg.out_chans
         # dense PE is input-independent: compute once (prompt_encoder.py:203-229), x first then y
-        G = sd[P + ".pe_layer.positional_encoding_gaussian_matrix"].float()
+        G = sd[P + ".pe_layer.positional_encoding_gaussian_matrix"].float().cpu()
         ys = (torch.arange(g, dtype=torch.float32) + 0.5) / g
         xs = (torch.arange(g, dtype=torch.float32) + 0.5) / g
         coords = torch.stack([xs[None, :].expand(g, g), ys[:, None].expand(g, g)], dim=-1)
