@@ -46,7 +46,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 typedef __attribute__((address_space(3))) bf16x4* lds_v4_ptr;
 
 template <int DP, int BIAS, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int KSTRIDE = DP * 2 + 16;  // bytes
   constexpr int VSTRIDE = DP * 2 + 32;
   constexpr int NCH = DP / 32;          // 16-B chunks per thread per operand per tile
@@ -89,6 +89,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
   }
 
+  const float sl2 = p.scale * LOG2E;            // scores are kept in the log2 domain
+  const float inv_S = p.S > 0 ? 1.0f / (float)p.S : 0.f;
   // ---- bias setup ----
   float relw_r[2][4][4];
   const float* relh_row[2];
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float4 f = *reinterpret_cast<const float4*>(rw + 16 * t + 4 * fh);
-        relw_r[qt][t][0] = f.x; relw_r[qt][t][1] = f.y; relw_r[qt][t][2] = f.z; relw_r[qt][t][3] = f.w;
+        relw_r[qt][t][0] = f.x * LOG2E; relw_r[qt][t][1] = f.y * LOG2E;
+        relw_r[qt][t][2] = f.z * LOG2E; relw_r[qt][t][3] = f.w * LOG2E;
       }
     }
   }
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       const int j = i - ql * 2 * p.S;
       const int qc = min(q0 + ql, p.Nq - 1);
       const float val = (j < p.S) ? p.relh[(bh * p.Nq + qc) * p.S + j] : p.relw[(bh * p.Nq + qc) * p.S + (j - p.S)];
-      sRel[ql * RSTRIDE + j] = val;
+      sRel[ql * RSTRIDE + j] = val * LOG2E;
     }
   }
 
@@ -187,56 +190,79 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       }
     }
 
-    // ---- scale, bias, mask, online softmax (lane owns query column fr of each q-tile) ----
+    // ---- scale, bias, mask, online softmax in the log2 domain (lane owns query column fr of each q-tile) ----
+    // wave-uniform: does any element of this tile need masking?
+    bool need_mask = (kt * KT + KT > p.Nk);
+    if (CAUSAL) need_mask = need_mask || (kt * KT + KT - 1 > q0 + wave * 32 + p.q_pos0);
+    int off_h[4][4], off_w[4][4];
+    if (BIAS == 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kc = min(kt * KT + 16 * t + 4 * fh + r, p.Nk - 1);
+          const int kh = (int)(((float)kc + 0.5f) * inv_S);  // exact for kc < 2^20
+          off_h[t][r] = kh;
+          off_w[t][r] = p.S + kc - kh * p.S;
+        }
+    }
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float s[4][4];
       float relh_v = 0.f;
-      if (BIAS == 2) relh_v = relh_row[qt][kt];
-      const int ql = wave * 32 + qt * 16 + fr;
+      if (BIAS == 2) relh_v = relh_row[qt][kt] * LOG2E;
+      const float* rel_q = sRel + (wave * 32 + qt * 16 + fr) * RSTRIDE;
       float mx = -1e30f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * KT + 16 * t + 4 * fh + r;
-          float v = sacc[t][qt][r] * p.scale;
-          if (BIAS == 2) v += relh_v + relw_r[qt][t][r];
-          if (BIAS == 1) {
-            const int kc = min(key, p.Nk - 1);
-            const int kh = kc / p.S;
-            const int kw = kc - kh * p.S;
-            v += sRel[ql * RSTRIDE + kh] + sRel[ql * RSTRIDE + p.S + kw];
-          }
-          bool ok = key < p.Nk;
-          if (CAUSAL) ok = ok && (key <= qrow[qt] + p.q_pos0);
-          v = ok ? v : -INFINITY;
+          float v;
+          if (BIAS == 2) v = fmaf(sacc[t][qt][r], sl2, relw_r[qt][t][r]) + relh_v;
+          else if (BIAS == 1) v = fmaf(sacc[t][qt][r], sl2, rel_q[off_h[t][r]] + rel_q[off_w[t][r]]);
+          else v = sacc[t][qt][r] * sl2;
           s[t][r] = v;
-          mx = fmaxf(mx, v);
         }
       }
+      if (need_mask) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * KT + 16 * t + 4 * fh + r;
+            bool ok = key < p.Nk;
+            if (CAUSAL) ok = ok && (key <= qrow[qt] + p.q_pos0);
+            s[t][r] = ok ? s[t][r] : -INFINITY;
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f((m_run[qt] - m_new) * LOG2E);
-      m_run[qt] = m_new;
+      if (__any(mx > m_run[qt])) {  // exact lazy rescale: most tiles do not raise the running max
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = exp2f(m_run[qt] - m_new);
+        m_run[qt] = m_new;
+        l_run[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+          oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
+          oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+        }
+      }
       float psum = 0.f;
-      const float mb = m_new * LOG2E;
+      const float mb = m_run[qt];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[t][r] * LOG2E - mb);
+          const float e = exp2f(s[t][r] - mb);
           s[t][r] = e;
           psum += e;
         }
-      l_run[qt] = l_run[qt] * alpha + psum;
-#pragma unroll
-      for (int dt = 0; dt < ND; ++dt) {
-        oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
-        oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
-      }
+      l_run[qt] += psum;
       // P^T fragment for k-step ks: slots j<4 <- tile 2ks (keys 4fh+j), j>=4 <- tile 2ks+1
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -374,6 +400,98 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(const T* q, long q_s
   }
 }
 }  // namespace
+
+// bf16 MFMA version (throughput mode). Per wave: 16 queries. P_h[q][r] = q . Th[r], P_w[q][r] = q . Tw[r] for ALL
+// table rows r < 2S-1 come out of v_mfma_f32_16x16x32_bf16 (A = table rows, B = query rows, head dim zero-padded
+// to a multiple of 32), land in LDS, and the diagonal gather relh[q][kh] = P_h[q][qh - kh + S - 1] (same for w)
+// writes coalesced rows. ~50 MFMAs per 16 queries at S=64 instead of 10k scalar FMAs per query.
+namespace {
+template <int NKD>  // k-steps of 32 over the (padded) head dim
+__global__ __launch_bounds__(256) void relpos_tables_mfma_kernel(const bf16_t* q, long q_sb, long q_sh, long q_st,
+                                                               const bf16_t* tab_h, const bf16_t* tab_w,
+                                                               float* relh, float* relw, int H, int S, int d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = S * S;
+  const int L = 2 * S - 1;
+  const int RT = (L + 15) / 16;       // 16-row table tiles
+  const int PS = RT * 16 + 4;         // LDS row stride (floats)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fh = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  float* sP = reinterpret_cast<float*>(smem_raw) + (long)wave * 2 * 16 * PS;  // [table][q][PS]
+  const bf16_t* qb = q + (long)b * q_sb + (long)h * q_sh;
+  if (q0 < N) {
+    bf16x8 qf[NKD];
+    const int qi = min(q0 + fr, N - 1);
+#pragma unroll
+    for (int kd = 0; kd < NKD; ++kd) {
+      const int col = kd * 32 + fh * 8;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (col < d) r = *reinterpret_cast<const uint4*>(qb + (long)qi * q_st + col);
+      qf[kd] = __builtin_bit_cast(bf16x8, r);
+    }
+    for (int tb = 0; tb < 2; ++tb) {
+      const bf16_t* tab = tb == 0 ? tab_h : tab_w;
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = min(rt * 16 + fr, L - 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd) {
+          const int col = kd * 32 + fh * 8;
+          uint4 r = make_uint4(0, 0, 0, 0);
+          if (col < d) r = *reinterpret_cast<const uint4*>(tab + (long)row * d + col);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r), qf[kd], acc, 0, 0, 0);
+        }
+        // D[i = table row 4fh + reg][j = query fr]
+        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+        store4(sP + ((long)tb * 16 + fr) * PS + rt * 16 + fh * 4, v);
+      }
+    }
+  }
+  __syncthreads();
+  if (q0 >= N) return;
+  const long bh = (long)b * H + h;
+  const int per_q = 2 * S;
+  for (int idx = lane; idx < 16 * per_q; idx += 64) {
+    const int ql = idx / per_q;
+    const int j = idx - ql * per_q;
+    const int qi = q0 + ql;
+    if (qi >= N) continue;
+    const int qh = qi / S, qw = qi - qh * S;
+    if (j < S) relh[(bh * N + qi) * S + j] = sP[(long)ql * PS + (qh - j + S - 1)];
+    else relw[(bh * N + qi) * S + (j - S)] = sP[((long)16 + ql) * PS + (qw - (j - S) + S - 1)];
+  }
+}
+}  // namespace
+
+// tab_h/tab_w: bf16 [2S-1][d]; q bf16; d % 8 == 0, d <= 128.
+extern "C" int haff_relpos_tables_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* tab_h,
+                                       const void* tab_w, float* relh, float* relw, int B, int H, int S, int d,
+                                       void* stream) {
+  if (B <= 0 || H <= 0 || S <= 0 || d <= 0 || d > 128 || (d & 7) || (q_st & 7) || (q_sh & 7) || (q_sb & 7)) return HAFF_ERR_BAD_ARG;
+  const int N = S * S;
+  const int RT = (2 * S - 1 + 15) / 16;
+  const size_t lds = (size_t)4 * 2 * 16 * (RT * 16 + 4) * sizeof(float);
+  if (lds > 150 * 1024) return HAFF_ERR_UNSUPPORTED;
+  dim3 grid((N + 63) / 64, H, B), block(256);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (lds > 64 * 1024) {  // S = 64 needs 66 KiB of the CU's 160 KiB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_tables_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_tables_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_tables_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_tables_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const bf16_t* qp = reinterpret_cast<const bf16_t*>(q);
+  const bf16_t* th = reinterpret_cast<const bf16_t*>(tab_h);
+  const bf16_t* tw = reinterpret_cast<const bf16_t*>(tab_w);
+  const int nkd = (d + 31) / 32;
+  if (nkd == 1) hipLaunchKernelGGL((relpos_tables_mfma_kernel<1>), grid, block, lds, s, qp, q_sb, q_sh, q_st, th, tw, relh, relw, H, S, d);
+  else if (nkd == 2) hipLaunchKernelGGL((relpos_tables_mfma_kernel<2>), grid, block, lds, s, qp, q_sb, q_sh, q_st, th, tw, relh, relw, H, S, d);
+  else if (nkd == 3) hipLaunchKernelGGL((relpos_tables_mfma_kernel<3>), grid, block, lds, s, qp, q_sb, q_sh, q_st, th, tw, relh, relw, H, S, d);
+  else hipLaunchKernelGGL((relpos_tables_mfma_kernel<4>), grid, block, lds, s, qp, q_sb, q_sh, q_st, th, tw, relh, relw, H, S, d);
+  return haff_check_launch();
+}
 
 extern "C" int haff_relpos_tables(const void* q, long q_sb, long q_sh, long q_st,
                                   const float* tab_h, const float* tab_w, float* relh, float* relw,

@@ -23,9 +23,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int NTHREADS = 256;
-constexpr int TILE_ELEMS = BM * BK;  // per operand per buffer (BM == BN)
+constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
 __device__ __attribute__((aligned(16))) unsigned int haff_zero_page[8];  // 32 B of zeros for K-tail chunks
@@ -41,12 +39,41 @@ struct GemmArgs {
   int act, out_f32, swiglu;
 };
 
+// Epilogue activations of the throughput (bf16) path. GELU uses the Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7,
+// far below the bf16 output rounding) instead of ocml erff: ~10 VALU ops + v_exp + v_rcp per element, which matters
+// for the K=1280 SAM MLP GEMM whose epilogue touches 5120 columns per row. The fp32 parity kernel keeps erff.
+__device__ __forceinline__ float gemm_act(float x, int act) {
+  switch (act) {
+    case HAFF_ACT_GELU: {
+      const float z = fabsf(x) * 0.70710678118654752440f;
+      const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+      const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+      const float erf_abs = 1.0f - poly * __expf(-z * z);
+      return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    }
+    case HAFF_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    case HAFF_ACT_RELU: return fmaxf(x, 0.0f);
+    case HAFF_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    default: return x;
+  }
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <bool OUT_F32, bool SWIGLU>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * TILE_ELEMS];  // [buf][A|W][128][64] = 64 KiB
+// BM x BN output tile per workgroup, WM x WN waves (each wave owns (BM/WM) x (BN/WN), BN/WN == 64).
+//   <128,128,2,2>: 256 threads, 64 KiB LDS, 2 workgroups/CU  — small / ragged problems
+//   <256,256,2,4>: 512 threads, 128 KiB LDS, 1 workgroup/CU  — half the L2->LDS bytes per MFMA (the 128^2 tile needs
+//                  ~64 B/clk/CU from L2 at full MFMA rate, more than the ~56 B/clk/CU the L2 can deliver)
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
+  constexpr int NTHREADS = 64 * WM * WN;
+  constexpr int A_ELEMS = BM * BK, W_ELEMS = BN * BK;
+  constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;
+  constexpr int NA = BM * 8 / NTHREADS, NW = BN * 8 / NTHREADS;  // 16-B chunks per thread per K-tile
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;             // 16x16 MFMA tiles per wave
+  static_assert(BN / WN == 64, "epilogue assumes a 64-column wave tile");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS];  // [buf][A | W]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,46 +103,52 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
 
   // ---- per-thread staging coordinates: 4 chunks of 16 B per operand per K-tile ----
   // LDS position pos = i*256 + tid (lane-linear); row = pos>>3; logical chunk = (pos&7) ^ (row&7)
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
-  int kcol[4];
+  const bf16_t* a_src[NA];
+  const bf16_t* w_src[NW];
+  int a_kcol[NA], w_kcol[NW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NA; ++i) {
     const int pos = i * NTHREADS + tid;
     const int row = pos >> 3;
     const int c = (pos & 7) ^ (row & 7);
-    kcol[i] = c * 8;
-    const int am = min(m0 + row, p.M - 1);
-    const int wn_ = min(n0 + row, p.N - 1);
-    a_src[i] = p.A + (long)am * p.lda + c * 8;
-    w_src[i] = p.W + (long)wn_ * p.ldw + c * 8;
+    a_kcol[i] = c * 8;
+    a_src[i] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int pos = i * NTHREADS + tid;
+    const int row = pos >> 3;
+    const int c = (pos & 7) ^ (row & 7);
+    w_kcol[i] = c * 8;
+    w_src[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + c * 8;
   }
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(haff_zero_page);
 
   auto stage = [&](int buf, int k0) {
-    bf16_t* sA = smem + buf * 2 * TILE_ELEMS;
-    bf16_t* sW = sA + TILE_ELEMS;
+    bf16_t* sA = smem + buf * STAGE_ELEMS;
+    bf16_t* sW = sA + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool in_k = (k0 + kcol[i]) < p.K;
-      const bf16_t* ga = in_k ? a_src[i] + k0 : zero_src;
-      const bf16_t* gw = in_k ? w_src[i] + k0 : zero_src;
-      // wave-uniform LDS base; hardware adds lane*16
-      bf16_t* la = sA + (i * NTHREADS + wave * 64) * 8;
-      bf16_t* lw = sW + (i * NTHREADS + wave * 64) * 8;
+    for (int i = 0; i < NA; ++i) {
+      const bf16_t* ga = (k0 + a_kcol[i]) < p.K ? a_src[i] + k0 : zero_src;
+      bf16_t* la = sA + (i * NTHREADS + wave * 64) * 8;  // wave-uniform LDS base; hardware adds lane*16
       __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)la, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const bf16_t* gw = (k0 + w_kcol[i]) < p.K ? w_src[i] + k0 : zero_src;
+      bf16_t* lw = sW + (i * NTHREADS + wave * 64) * 8;
       __builtin_amdgcn_global_load_lds((gptr_t)gw, (lptr_t)lw, 16, 0, 0);
     }
   };
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fh = lane >> 4;
 
-  f32x4 acc[4][4];  // [ni][mi]
+  f32x4 acc[TN][TM];  // [ni][mi]
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TN; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
   stage(0, 0);
@@ -123,110 +156,144 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
       stage(cur ^ 1, (kt + 1) * BK);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if constexpr (NA + NW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
 
-    const bf16_t* sA = smem + cur * 2 * TILE_ELEMS;
-    const bf16_t* sW = sA + TILE_ELEMS;
+    const bf16_t* sA = smem + cur * STAGE_ELEMS;
+    const bf16_t* sW = sA + A_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[4], af[4];
+      bf16x8 wf[TN], af[TM];
       const int c = ks * 4 + fh;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int rw = wn * 64 + t * 16 + fr;
-        const int ra = wm * 64 + t * 16 + fr;
+      for (int t = 0; t < TN; ++t) {
+        const int rw = wn * (BN / WN) + t * 16 + fr;
         wf[t] = *reinterpret_cast<const bf16x8*>(sW + rw * BK + ((c ^ (rw & 7)) << 3));
+      }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int ra = wm * (BM / WM) + t * 16 + fr;
         af[t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
       }
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < TN; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
     }
     __builtin_amdgcn_s_barrier();
   }
 
-  // ---- epilogue: lane holds D[n = 4*fh + reg][m = fr] of each 16x16 tile ----
+  // ---- epilogue, staged through LDS so global traffic is whole 128-B row segments ----
+  // lane holds D[n = 4*fh + reg][m = fr] of each 16x16 tile -> (+bias, act) -> fp32 LDS image [32 rows][WCOLS]
+  // per wave -> read back 8 consecutive columns per lane -> (+residual) -> 16-B stores.
+  constexpr int WCOLS = SWIGLU ? 32 : 64;   // output columns owned by a wave
+  constexpr int RS = WCOLS + 4;             // LDS row stride in floats (pad keeps b128 accesses conflict-free)
+  constexpr int LPR = WCOLS / 8;            // lanes per output row on the read-back side
+  constexpr int RPS = 64 / LPR;             // rows per read-back step
+  float* sEp = reinterpret_cast<float*>(smem) + wave * (32 * RS);
+  const int n_wave_in = n0 + wn * 64;                           // first (interleaved) input column of the wave
+  const int n_wave_out = SWIGLU ? (n_wave_in >> 1) : n_wave_in;
+  const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
+  const bool c_vec = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((p.ldc & 7) == 0);
+  const bool r_vec = p.resid && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) && ((p.ldr & 7) == 0);
+
+  float bias_r[TN][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + fr;
-    if (m >= p.M) continue;
-    long orow = m;
-    if (p.row_map) {
-      const int mapped = p.row_map[m];
-      if (mapped < 0) continue;
-      orow = mapped;
+  for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n_wave_in + ni * 16 + fh * 4 + r;
+      bias_r[ni][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
-    if (!SWIGLU) {
+
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + fh * 4;
-        if (n >= p.N) continue;
-        float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-        const bool full = (n + 4 <= p.N);
-        if (p.bias) {
+  for (int pi = 0; pi < TM / 2; ++pi) {
+    __syncthreads();  // previous pass fully read back (pass 0: every wave is past its last operand read)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (full || n + r < p.N) v[r] += p.bias[n + r];
+    for (int ml = 0; ml < 2; ++ml) {
+      const int mi = pi * 2 + ml;
+      float* row = sEp + (ml * 16 + fr) * RS + fh * 4;
+      if (!SWIGLU) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gemm_act(acc[ni][mi][r] + bias_r[ni][r], p.act);
+          store4(row + ni * 16, v);
         }
-        if (p.act != HAFF_ACT_NONE) {
+      } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-        }
-        if (OUT_F32) {
-          float* crow = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
-          if (p.resid) {
-            const float* rrow = reinterpret_cast<const float*>(p.resid) + orow * p.ldr + n;
+        for (int nj = 0; nj < TN / 2; ++nj) {
+          float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (full || n + r < p.N) v[r] += rrow[r];
+          for (int r = 0; r < 4; ++r) {
+            const float g = acc[2 * nj][mi][r] + bias_r[2 * nj][r];
+            const float u = acc[2 * nj + 1][mi][r] + bias_r[2 * nj + 1][r];
+            v[r] = (g / (1.0f + __expf(-g))) * u;
           }
-          if (full && ((p.ldc & 3) == 0)) {
-            store4(crow, v);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) crow[r] = v[r];
-          }
-        } else {
-          bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + orow * p.ldc + n;
-          if (p.resid) {
-            const bf16_t* rrow = reinterpret_cast<const bf16_t*>(p.resid) + orow * p.ldr + n;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (full || n + r < p.N) v[r] += bf16_to_f32(rrow[r]);
-          }
-          if (full && ((p.ldc & 3) == 0)) {
-            store4(crow, v);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) crow[r] = f32_to_bf16(v[r]);
-          }
+          store4(row + nj * 16, v);
         }
       }
-    } else {
-      // W rows are interleaved in 16-row groups [gate x16 | up x16]; output width N/2
+    }
+    __syncthreads();
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        const int n_in = n0 + wn * 64 + nj * 32 + fh * 4;  // gate column (interleaved index)
-        if (n_in >= p.N) continue;
-        const int n_out = ((n0 + wn * 64) >> 1) + nj * 16 + fh * 4;
-        float v[4];
+    for (int st = 0; st < 32 / RPS; ++st) {
+      const int r = st * RPS + lane / LPR;
+      const int c = (lane % LPR) * 8;
+      const int m = m0 + wm * (BM / WM) + pi * 32 + r;
+      const int n = n_wave_out + c;
+      if (m >= p.M || n >= n_total_out) continue;
+      long orow = m;
+      if (p.row_map) {
+        const int mapped = p.row_map[m];
+        if (mapped < 0) continue;
+        orow = mapped;
+      }
+      float v[8];
+      load8(sEp + r * RS + c, v);
+      const bool full = n + 8 <= n_total_out;
+      if (OUT_F32) {
+        float* crow = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+        if (p.resid) {
+          const float* rrow = reinterpret_cast<const float*>(p.resid) + orow * p.ldr + n;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float g = acc[2 * nj][mi][r];
-          float u = acc[2 * nj + 1][mi][r];
-          if (p.bias) { g += p.bias[n_in + r]; u += p.bias[n_in + 16 + r]; }
-          v[r] = (g / (1.0f + __expf(-g))) * u;
+          for (int j = 0; j < 8; ++j)
+            if (full || n + j < n_total_out) v[j] += rrow[j];
         }
-        if (OUT_F32) store4(reinterpret_cast<float*>(p.C) + orow * p.ldc + n_out, v);
-        else store4(reinterpret_cast<bf16_t*>(p.C) + orow * p.ldc + n_out, v);
+        if (full && c_vec) {
+          store8(crow, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (n + j < n_total_out) crow[j] = v[j];
+        }
+      } else {
+        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + orow * p.ldc + n;
+        if (p.resid) {
+          const bf16_t* rrow = reinterpret_cast<const bf16_t*>(p.resid) + orow * p.ldr + n;
+          if (full && r_vec) {
+            float rr[8];
+            load8(rrow, rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (n + j < n_total_out) v[j] += bf16_to_f32(rrow[j]);
+          }
+        }
+        if (full && c_vec) {
+          store8(crow, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (n + j < n_total_out) crow[j] = f32_to_bf16(v[j]);
+        }
       }
     }
   }
@@ -234,24 +301,43 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
 
 }  // namespace
 
-extern "C" int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
-                              const float* bias, const void* resid, long ldr, const int* row_map,
-                              int M, int N, int K, int act, int out_f32, int swiglu, void* stream) {
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmArgs& p, hipStream_t s) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles), block(64 * WM * WN);
+  if (p.swiglu) {
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
+  } else {
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
+  }
+  return haff_check_launch();
+}
+
+// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (for A/B measurements)
+extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                                  const float* bias, const void* resid, long ldr, const int* row_map,
+                                  int M, int N, int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return HAFF_ERR_BAD_ARG;
   if ((K & 7) || (lda & 7) || (ldw & 7)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || (ldc & 3) || resid)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
              bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu};
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid(tiles), block(NTHREADS);
-  if (swiglu) {
-    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
-  } else {
-    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
+  bool big = tile_cfg == 2;
+  if (tile_cfg == 0) {
+    // the 256^2 tile needs enough tiles to fill 256 CUs at one workgroup per CU
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    big = t256 >= 256 && N >= 256 && K >= 8192;  // measured (tools/gemm_bench.py): 256^2 wins only for very long K
   }
-  return haff_check_launch();
+  return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
+}
+
+extern "C" int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                              const float* bias, const void* resid, long ldr, const int* row_map,
+                              int M, int N, int K, int act, int out_f32, int swiglu, void* stream) {
+  return haff_gemm_bf16_cfg(A, lda, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0, stream);
 }

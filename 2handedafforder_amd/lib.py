@@ -17,6 +17,8 @@ c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int,
 _PROTOS = {
     "haff_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                        c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_gemm_bf16_cfg": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
+                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_f32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                       c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
@@ -29,6 +31,8 @@ _PROTOS = {
                            c_void_p],
     "haff_relpos_tables": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_relpos_tables_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_int, c_void_p],
     "haff_layernorm": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                        c_int, c_void_p],
     "haff_rmsnorm": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_int, c_void_p],

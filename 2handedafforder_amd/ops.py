@@ -33,7 +33,7 @@ def _req(t, name):
 
 
 def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, out_rows=None, out_dtype=None,
-           swiglu=False):
+           swiglu=False, tile_cfg=0):
     """y = epi(x @ w.T): x [M,K] (row stride free, unit inner stride), w [N,K], bias fp32 [N] or None.
 
     epilogue order: +bias -> act -> +resid (resid indexed like out). row_map (int32 [M]) redirects output
@@ -59,9 +59,10 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
         assert row_map.dtype == torch.int32 and row_map.numel() == M
     if x.dtype == torch.bfloat16:
         assert w.dtype == torch.bfloat16
-        rc = lib.haff_gemm_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
-                                _p(bias), _p(resid), 0 if resid is None else resid.stride(0), _p(row_map),
-                                M, N, K, act, 1 if out.dtype == torch.float32 else 0, 1 if swiglu else 0, _stream())
+        rc = lib.haff_gemm_bf16_cfg(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
+                                    out.stride(0), _p(bias), _p(resid), 0 if resid is None else resid.stride(0),
+                                    _p(row_map), M, N, K, act, 1 if out.dtype == torch.float32 else 0,
+                                    1 if swiglu else 0, tile_cfg, _stream())
     else:
         assert w.dtype == torch.float32 and out.dtype == torch.float32
         rc = lib.haff_gemm_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
@@ -96,6 +97,17 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, relh=None, relw=None, S=0,
     return out
 
 
+_BF16_TABLES = {}
+
+
+def _bf16_table(t):
+    key = (t.data_ptr(), tuple(t.shape))
+    hit = _BF16_TABLES.get(key)
+    if hit is None or hit[0] is not t:
+        _BF16_TABLES[key] = (t, t.to(torch.bfloat16).contiguous())
+    return _BF16_TABLES[key][1]
+
+
 def relpos_tables(q, tab_h, tab_w, S):
     """q [B,H,N,d] view with N == S*S; tab_* fp32 [2S-1,d]. Returns relh, relw fp32 [B*H,N,S]."""
     lib = load_library()
@@ -103,6 +115,13 @@ def relpos_tables(q, tab_h, tab_w, S):
     assert N == S * S and tab_h.shape == (2 * S - 1, d) and tab_h.dtype == torch.float32
     relh = torch.empty((B * H, N, S), dtype=torch.float32, device=q.device)
     relw = torch.empty_like(relh)
+    if q.dtype == torch.bfloat16:
+        # throughput mode: MFMA kernel on bf16 tables (the reference's bf16 checkpoint stores them in bf16 too)
+        th, tw = _bf16_table(tab_h), _bf16_table(tab_w)
+        rc = lib.haff_relpos_tables_bf16(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), th.data_ptr(),
+                                         tw.data_ptr(), relh.data_ptr(), relw.data_ptr(), B, H, S, d, _stream())
+        check(rc, "haff_relpos_tables_bf16")
+        return relh, relw
     rc = lib.haff_relpos_tables(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(),
                                 tab_w.data_ptr(), relh.data_ptr(), relw.data_ptr(), B, H, S, d, _dt(q), _stream())
     check(rc, "haff_relpos_tables")

@@ -183,15 +183,18 @@ def test_attention_online_softmax_rescale(dev):
     _close(got, ref, 2e-2, "attention rescale spike")
 
 
+@pytest.mark.parametrize("S,d", [(14, 80), (7, 32), (64, 80), (20, 80)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_relpos_tables(dev, dtype):
+def test_relpos_tables(dev, dtype, S, d):
     ops = _ops()
-    B, H, S, d = 2, 3, 14, 80
+    B, H = 2, 3
     N = S * S
     qkv = _rand((B, N, 3, H, d), dev, dtype, 40)
     q = qkv[:, :, 0].permute(0, 2, 1, 3)
     th = _rand((2 * S - 1, d), dev, torch.float32, 41)
     tw = _rand((2 * S - 1, d), dev, torch.float32, 42)
+    if dtype == torch.bfloat16:  # the bf16 path multiplies bf16 tables on the MFMA units
+        th, tw = th.to(torch.bfloat16).float(), tw.to(torch.bfloat16).float()
     relh, relw = ops.relpos_tables(q, th, tw, S)
     idx = torch.arange(S, device=dev)[:, None] - torch.arange(S, device=dev)[None, :] + (S - 1)
     Rh, Rw = th[idx], tw[idx]  # [S(q), S(k), d]
