@@ -192,7 +192,7 @@ def make_state_dict(cfg, seed, shapes=None, dtype=torch.float32):
 
 def round_to_bf16_(sd):
     """Round every tensor to bf16-representable values in place (kept as fp32): throughput-mode weights are
-    stored in bf16, and the oracle must see exactly those values for parity checks."""
+    stored in bf16, and any fp32 checker must see exactly those values for parity checks."""
     for k in sd:
         sd[k] = sd[k].to(torch.bfloat16).to(torch.float32)
     return sd

@@ -1,0 +1,123 @@
+/*
+ * haff_hip.h — C-ABI of libhaff_hip.so, the MI355X (gfx950 / CDNA4) hot path of pearl-robot-lab/2HandedAfforder.
+ *
+ * The reference has no FFI / plugin boundary of its own: its per-frame path is Python
+ * (`LISAForCausalLM.evaluate`, 2Haff/model/LISA.py:432-534) over torch + transformers. This library sits UNDER
+ * that Python boundary: each entry point replaces the torch / transformers op(s) cited next to it, and is what a
+ * maintainer binds with ctypes from the reference's own modules.
+ *
+ * Conventions
+ *   - all pointers are caller-owned DEVICE pointers (HBM) unless marked "host"; no internal allocation, no global
+ *     state, re-entrant; `stream` is a hipStream_t passed as void* (0 = null stream); kernels are only enqueued.
+ *   - return value: 0 ok, -1 bad argument, -2 unsupported shape, -3 launch error. No exceptions cross the ABI.
+ *   - dtype codes: 0 = bf16 (raw 16-bit payload), 1 = f32. bf16 = throughput mode (bf16 MFMA, fp32 accumulate,
+ *     fp32 softmax/norm statistics); f32 = parity mode (every op in fp32, for the 1e-3 mask-logit criterion).
+ *   - strides/leading dimensions are in ELEMENTS.
+ *   - activation codes: 0 none, 1 GELU(erf), 2 quick-GELU (x*sigmoid(1.702x)), 3 ReLU, 4 SiLU.
+ */
+#ifndef HAFF_HIP_H
+#define HAFF_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- GEMM with fused epilogue: C[M,N] = act(A[M,K] . W[N,K]^T + bias) + resid -------------------------------
+ * Replaces every nn.Linear / 1x1 conv / patchify conv on the path: SAM qkv/proj/MLP (image_encoder.py:223-224,258;
+ * common.py:13-26), CLIP & Llama linears (transformers, reached from clip_encoder.py:53-56 / llava_llama.py:93-105),
+ * mm_projector (llava_arch.py:35), text_hidden_fcs (LISA.py:95-101), SAM decoder linears (transformer.py:206-209),
+ * first ConvTranspose2d of the upscaler (mask_decoder.py:55-57) as a per-pixel GEMM.
+ * row_map (int32[M], may be null): output AND residual row = row_map[m]; negative = row dropped (fuses
+ * window_unpartition, image_encoder.py:291-318). swiglu != 0: W rows interleaved in 16-row groups
+ * [gate x16 | up x16], output width N/2 = silu(gate)*up (LlamaMLP). out_f32: C (and resid) are f32.
+ * Requirements: K % 8 == 0, lda % 8 == 0, ldw % 8 == 0, A and W 16-byte aligned. */
+int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                   const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
+                   int swiglu, void* stream);
+/* same, with an explicit tile choice for measurements: 0 auto, 1 = 128x128, 2 = 256x256 workgroup tile */
+int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                       const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
+                       int swiglu, int tile_cfg, void* stream);
+/* parity-mode twin: everything f32. K % 4 == 0, lda/ldw % 4 == 0. */
+int haff_gemm_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, const float* bias,
+                  const float* resid, long ldr, const int* row_map, int M, int N, int K, int act, int swiglu,
+                  void* stream);
+
+/* ---- fused attention: out = softmax(scale * q.k^T + bias [+ causal mask]) . v ---------------------------------
+ * Replaces SAM Attention.forward + add_decomposed_rel_pos (image_encoder.py:235-260,354-392), CLIPAttention,
+ * LlamaAttention (prefill and KV-cached decode) and the SAM decoder Attention (transformer.py:220-242).
+ * q/k/v/o: [B][H][N][d] views given by (batch, head, token) strides, unit stride on d; d % 8 == 0 (bf16: d <= 128).
+ * causal != 0: key j visible to query i iff j <= i + q_pos0.
+ * relh/relw (null = no bias): f32 [B*H][Nq][S] from haff_relpos_tables; key j -> (kh, kw) = (j / S, j % S).
+ * bf16 kernel supports S == 64 (one KV tile per key-grid row) or S <= 32. */
+int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* k, long k_sb, long k_sh, long k_st,
+                        const void* v, long v_sb, long v_sh, long v_st, void* o, long o_sb, long o_sh, long o_st,
+                        int B, int H, int Nq, int Nk, int d, float scale, int causal, int q_pos0,
+                        const float* relh, const float* relw, int S, void* stream);
+int haff_attention_f32(const float* q, long q_sb, long q_sh, long q_st, const float* k, long k_sb, long k_sh, long k_st,
+                       const float* v, long v_sb, long v_sh, long v_st, float* o, long o_sb, long o_sh, long o_st,
+                       int B, int H, int Nq, int Nk, int d, float scale, int causal, int q_pos0,
+                       const float* relh, const float* relw, int S, void* stream);
+
+/* decomposed rel-pos terms (image_encoder.py:376-384, from the UNSCALED q, :244-248):
+ * relh[bh][q][kh] = q . Rh[qh - kh + S - 1], relw[bh][q][kw] = q . Rw[qw - kw + S - 1]; N = S*S queries.
+ * tab_*: [2S-1][d] (f32 for the generic entry, bf16 for the MFMA entry). */
+int haff_relpos_tables(const void* q, long q_sb, long q_sh, long q_st, const float* tab_h, const float* tab_w,
+                       float* relh, float* relw, int B, int H, int S, int d, int dtype, void* stream);
+int haff_relpos_tables_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* tab_h, const void* tab_w,
+                            float* relh, float* relw, int B, int H, int S, int d, void* stream);
+
+/* ---- row norms ----------------------------------------------------------------------------------------------
+ * haff_layernorm: nn.LayerNorm / LayerNorm2d on channels-last rows (common.py:31-43; image_encoder.py:179,191;
+ * transformer.py:134-144; CLIP layer norms). in_map (int32[rows], may be null): out row i normalises in row
+ * in_map[i]; negative = zero row (window_partition's zero pad AFTER norm1, image_encoder.py:179-183,276-288).
+ * haff_rmsnorm: LlamaRMSNorm (fp32 variance). w, b: f32[C]. C % 8 == 0, C <= 8192. */
+int haff_layernorm(const void* x, long ldx, void* y, long ldy, const float* w, const float* b, const int* in_map,
+                   int rows, int C, float eps, int dtype, void* stream);
+int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const float* w, int rows, int C, float eps, int dtype,
+                 void* stream);
+
+/* ---- data movement ------------------------------------------------------------------------------------------ */
+/* conv(k=s=P) rows: x [B][Cin][Hin][Win] -> out [B*gh*gw][Kp], column (c*P+ky)*P+kx, zero beyond Cin*P*P.
+ * SAM PatchEmbed.proj (image_encoder.py:418-426), CLIP patch_embedding. */
+int haff_patchify_nchw(const void* x, void* out, int B, int Cin, int Hin, int Win, int P, int gh, int gw, int Kp,
+                       int in_dtype, int out_dtype, void* stream);
+/* same rows straight from uint8 NHWC frames [B][Hf][Wf][3]: (x-mean)/std, zero pad right/bottom
+ * (inference.preprocess, inference.py:91-105). mean3/std3: HOST pointers to 3 floats (0..255 scale). */
+int haff_patchify_u8(const void* frames, void* out, int B, int Hf, int Wf, int P, int gh, int gw, int Kp,
+                     const float* mean3, const float* std3, int out_dtype, void* stream);
+/* neck 3x3 conv pad 1 (image_encoder.py:100-106): x [B][H][W][C] -> [B*H*W][9*C], column (ky*3+kx)*C+c */
+int haff_im2col3x3(const void* x, void* out, int B, int H, int W, int C, int dtype, void* stream);
+/* embed_tokens gather + image-feature splice (llava_arch.py:185-208,252-256): ids int64 [B][L] with the sentinel
+ * at img_pos[b]; out [B][L+n_img-1][Hd] */
+int haff_embed_splice(const long* ids, const int* img_pos, const void* embed, const void* img, void* out, int B, int L,
+                      int n_img, int Hd, int dtype, void* stream);
+/* rotate-half RoPE on q,k in place (qkv [B*Tq][ld]: q | k | v) + KV-cache append at positions pos0..pos0+Tq-1
+ * (caches [B][Tmax][Hkv*d]); cos_sin f32 [Tmax][d] = cos(d/2) | sin(d/2). d % 16 == 0. */
+int haff_rope_cache(void* qkv, long ld, void* kcache, void* vcache, const float* cos_sin, int B, int Tq, int Hq, int Hkv,
+                    int d, int pos0, int Tmax, int dtype, void* stream);
+/* greedy token: first index of the row maximum (generate(num_beams=1), LISA.py:443-450) */
+int haff_argmax_rows(const float* x, long ld, long* out, int rows, int V, void* stream);
+/* out[r] = a[r] + b[r % mod]  (PE adds, transformer.py:166-178; src + dense prompt, mask_decoder.py:141) */
+int haff_add_bcast(const void* a, const void* b, void* out, long rows, int C, int mod, int dtype, void* stream);
+/* row softmax to f32 (taxonomy head, mask_decoder.py:177) */
+int haff_softmax_rows(const void* x, float* out, int rows, int C, int dtype, void* stream);
+
+/* ---- SAM decoder tail + post-processing ------------------------------------------------------------------------
+ * haff_upscale_mask: LayerNorm2d(64) -> GELU -> ConvTranspose2d(64->32,k2,s2) -> GELU -> dot with the hypernetwork
+ * vector of mask token 0 (mask_decoder.py:58-64,153-165,110-114). up1 [n*h*w][4*64] = output of the first
+ * transposed conv as GEMM, columns (dy*2+dx)*64+co; w2 f32 [64][4*32] column (dy2*2+dx2)*32+c2; hyper f32 [n][32];
+ * out f32 [n][4h][4w]. */
+int haff_upscale_mask(const void* up1, const float* ln_w, const float* ln_b, const float* w2, const float* b2,
+                      const float* hyper, float* out, int n_prompts, int h, int w, float eps, int dtype, void* stream);
+/* F.interpolate(bilinear, align_corners=False) of the top-left [Hc][Wc] crop of in [N][Hs][Ws] -> out [N][Ho][Wo]
+ * (both stages of Sam.postprocess_masks, sam.py:177-188) */
+int haff_resize_bilinear(const float* in, float* out, int N, int Hs, int Ws, int Hc, int Wc, int Ho, int Wo,
+                         void* stream);
+/* mask > logit_th -> 0/255 bytes (inference.py:294-301 with logit_th = logit(th); chat.py:226 with 0) */
+int haff_threshold_masks(const float* in, void* out, long total, float logit_th, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAFF_HIP_H */

@@ -1,0 +1,88 @@
+"""CPU-side checks: the C-ABI library builds/loads here (hipcc cross-compiles gfx950 without a GPU) and exports
+exactly the entry points include/haff_hip.h declares; host-side helpers behave; nothing computes on a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import haff
+from haff import config as hcfg
+from haff import flops, preprocess, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "haff_hip.h")).read()
+    return sorted(set(re.findall(r"^int (haff_\w+)\(", text, flags=re.M)))
+
+
+def test_header_matches_python_prototypes():
+    assert _declared() == sorted(haff.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(haff.LIB_PATH):
+        haff.build_library()
+    lib = ctypes.CDLL(haff.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    haff.load_library()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from haff import ops
+    from haff.lisa import LisaMI355
+    with pytest.raises(RuntimeError):
+        LisaMI355(hcfg.tiny(), {}, device="cuda:0")
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "2handedafforder_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, f"{f} mentions the oracle"
+
+
+def test_weight_filler_is_deterministic_and_complete():
+    cfg = hcfg.tiny()
+    a = weights.make_state_dict(cfg, 7)
+    b = weights.make_state_dict(cfg, 7)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    c = weights.make_state_dict(cfg, 8)
+    assert not torch.equal(a["lm_head.weight"], c["lm_head.weight"])
+    sub = weights.make_state_dict(cfg, 7, weights.clip_shapes(cfg.clip))
+    assert set(sub) == set(weights.clip_shapes(cfg.clip))
+    assert a["model.visual_model.image_encoder.blocks.0.attn.rel_pos_h"].shape == (13, 32)
+    assert a["model.visual_model.image_encoder.blocks.1.attn.rel_pos_h"].shape == (27, 32)
+
+
+def test_flop_model_matches_survey():
+    assert abs(flops.frame_flops(hcfg.haff_7b())["total"] / 10.01e12 - 1) < 5e-3
+    assert abs(flops.frame_flops(hcfg.haff_13b())["total"] / 13.73e12 - 1) < 5e-3
+    assert abs(flops.frame_flops(hcfg.haff_7b())["sam_encoder"] / 5.961e12 - 1) < 1e-3
+
+
+def test_preprocess_contracts():
+    rng = np.random.default_rng(0)
+    fr = rng.integers(0, 256, size=(50, 64, 3), dtype=np.uint8)
+    x = preprocess.sam_preprocess(torch.from_numpy(fr), 64)
+    assert x.shape == (3, 64, 64) and torch.all(x[:, 50:] == 0)
+    ref = (torch.from_numpy(fr).permute(2, 0, 1).float() - torch.tensor(preprocess.SAM_MEAN).view(3, 1, 1)) / torch.tensor(preprocess.SAM_STD).view(3, 1, 1)
+    assert torch.equal(x[:, :50], ref)
+    assert preprocess.get_preprocess_shape(480, 640, 1024) == (768, 1024)
+    assert preprocess.clip_preprocess(torch.from_numpy(fr)).shape == (3, 224, 224)
+    ml, mr = torch.tensor([[1.0, -1.0]]), torch.tensor([[-2.0, 3.0]])
+    l, r, t = preprocess.gate_and_threshold(ml, mr, torch.tensor([[0.1, 0.7, 0.1, 0.1]]))
+    assert t == 1 and not l.any() and r.tolist() == [[False, True]]
+    l, r, t = preprocess.gate_and_threshold(ml, mr, torch.tensor([[0.7, 0.1, 0.1, 0.1]]), mode="inference", threshold=0.5)
+    assert t == 0 and l.tolist() == [[True, False]] and not r.any()
