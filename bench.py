@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import haff  # noqa: E402,F401
 from haff import config as hcfg  # noqa: E402
+from haff import dist as hdist  # noqa: E402
 from haff import flops as hflops  # noqa: E402
 from haff import ops  # noqa: E402
 from haff import weights as hw  # noqa: E402
@@ -180,16 +181,11 @@ def main():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    rank, world, local_rank = hdist.init_from_env("nccl")  # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
     cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
     sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
     model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=device, sam_chunk=args.sam_chunk)
@@ -203,26 +199,11 @@ def main():
         return model.evaluate(images_clip[:n], None, ids[:n], sizes[:n], sizes[:n], max_new_tokens=args.n_gen,
                               forced_answer=forced[:n], frames_u8=frames[:n])
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    outs = []
+    elapsed = hdist.timed_steps(lambda: outs.append(step()), args.steps, device)  # fence | K steps | fence | max over ranks
+    out = outs[-1]
     ms_per_step = 1e3 * elapsed / args.steps
     fps = world * B * args.steps / elapsed
 
