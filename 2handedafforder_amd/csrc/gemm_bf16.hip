@@ -165,26 +165,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 
     const bf16_t* sA = smem + cur * STAGE_ELEMS;
     const bf16_t* sW = sA + A_ELEMS;
+    // issue every fragment read of the K-tile up front (both 32-deep k-steps), consume in issue order: only the
+    // first read's latency is exposed, the compiler places counted lgkmcnt waits in front of each MFMA group
+    bf16x8 wf[2][TN], af[2][TM];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[TN], af[TM];
       const int c = ks * 4 + fh;
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         const int rw = wn * (BN / WN) + t * 16 + fr;
-        wf[t] = *reinterpret_cast<const bf16x8*>(sW + rw * BK + ((c ^ (rw & 7)) << 3));
+        wf[ks][t] = *reinterpret_cast<const bf16x8*>(sW + rw * BK + ((c ^ (rw & 7)) << 3));
       }
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         const int ra = wm * (BM / WM) + t * 16 + fr;
-        af[t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
+        af[ks][t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler would re-batch them)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-    }
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[ks][mi], acc[ni][mi], 0, 0, 0);
     __builtin_amdgcn_s_barrier();
   }
 
@@ -329,9 +334,14 @@ extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long l
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   bool big = tile_cfg == 2;
   if (tile_cfg == 0) {
-    // the 256^2 tile needs enough tiles to fill 256 CUs at one workgroup per CU
+    // Pick the tile by wave-quantisation efficiency (tiles / slots rounded up) times the measured per-tile
+    // advantage of the 256^2 kernel (tools/gemm_bench.py: ~6 % at K=1280, ~10 % at K>=2048): 128^2 runs 2
+    // workgroups per CU (512 slots), 256^2 one (256 slots).
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    big = t256 >= 256 && N >= 256 && K >= 8192;  // measured (tools/gemm_bench.py): 256^2 wins only for very long K
+    const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+    const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256) * (K >= 2048 ? 1.10 : 1.06);
+    big = (M >= 256 && N >= 256 && e256 > e128);
   }
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
