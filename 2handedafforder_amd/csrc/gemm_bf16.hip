@@ -182,7 +182,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         af[ks][t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
       }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler would re-batch them)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -190,6 +189,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[ks][mi], acc[ni][mi], 0, 0, 0);
+    // Schedule: k-step-0 reads first, then the k-step-1 reads trickle in between the k-step-0 MFMA groups, so at
+    // most 15 LDS reads are outstanding (lgkmcnt is 4 bits: more forces a full drain) and the compiler can place
+    // counted waits; only the first group's read latency is exposed per K-tile.
+    __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);
+#pragma unroll
+    for (int g = 0; g < TM; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (TN + TM + TM - 1) / TM, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);
     __builtin_amdgcn_s_barrier();
   }
 
