@@ -109,6 +109,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       }
     }
   }
+  // BIAS == 3 (S <= 16, SAM windows): keys are visited as a grid with rows padded to 16 (virtual key v -> kh = v>>4,
+  // kw = v&15, real key kh*S+kw, kw >= S masked). A 64-key tile is then 4 whole grid rows, so the lane's 4 relw terms
+  // are tile-invariant and the 4 relh terms of a tile are picked from 16 registers: no LDS lookups, no index math.
+  float relh3[2][16], relw3[2][4];
+  bool kw_ok[4];
+  if (BIAS == 3) {
+    const long bh = (long)b * p.H + h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kw_ok[r] = (4 * fh + r) < p.S;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qc = min(qrow[qt], p.Nq - 1);
+      const float* rh = p.relh + (bh * p.Nq + qc) * p.S;
+      const float* rw = p.relw + (bh * p.Nq + qc) * p.S;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) relh3[qt][j] = rh[min(j, p.S - 1)] * LOG2E;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) relw3[qt][r] = rw[min(4 * fh + r, p.S - 1)] * LOG2E;
+    }
+  }
   if (BIAS == 1) {
     const long bh = (long)b * p.H + h;
     for (int i = tid; i < QB * 2 * p.S; i += 256) {
@@ -132,7 +152,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int key = min(kt * KT + st_row[i], p.Nk - 1);
+      int key = kt * KT + st_row[i];
+      if (BIAS == 3) key = min(key >> 4, p.S - 1) * p.S + min(key & 15, p.S - 1);
+      key = min(key, p.Nk - 1);
       const int col = st_c[i] * 8;
       kreg[i] = make_uint4(0, 0, 0, 0);
       vreg[i] = make_uint4(0, 0, 0, 0);
@@ -160,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   float l_run[2] = {0.f, 0.f};
 
   int nkt = (p.Nk + KT - 1) / KT;
+  if (BIAS == 3) nkt = (16 * p.S + KT - 1) / KT;
   if (CAUSAL) {
     const int last_q = min(q0 + QB - 1, p.Nq - 1);
     const int last_key = min(last_q + p.q_pos0, p.Nk - 1);
@@ -213,6 +236,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       float relh_v = 0.f;
       if (BIAS == 2) relh_v = relh_row[qt][kt] * LOG2E;
       const float* rel_q = sRel + (wave * 32 + qt * 16 + fr) * RSTRIDE;
+      float rh3[4] = {0.f, 0.f, 0.f, 0.f};
+      if (BIAS == 3) {
+        switch (kt) {
+          case 0: rh3[0] = relh3[qt][0]; rh3[1] = relh3[qt][1]; rh3[2] = relh3[qt][2]; rh3[3] = relh3[qt][3]; break;
+          case 1: rh3[0] = relh3[qt][4]; rh3[1] = relh3[qt][5]; rh3[2] = relh3[qt][6]; rh3[3] = relh3[qt][7]; break;
+          case 2: rh3[0] = relh3[qt][8]; rh3[1] = relh3[qt][9]; rh3[2] = relh3[qt][10]; rh3[3] = relh3[qt][11]; break;
+          default: rh3[0] = relh3[qt][12]; rh3[1] = relh3[qt][13]; rh3[2] = relh3[qt][14]; rh3[3] = relh3[qt][15]; break;
+        }
+      }
       float mx = -1e30f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -220,12 +252,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) {
           float v;
           if (BIAS == 2) v = fmaf(sacc[t][qt][r], sl2, relw_r[qt][t][r]) + relh_v;
+          else if (BIAS == 3) v = fmaf(sacc[t][qt][r], sl2, relw3[qt][r]) + rh3[t];
           else if (BIAS == 1) v = fmaf(sacc[t][qt][r], sl2, rel_q[off_h[t][r]] + rel_q[off_w[t][r]]);
           else v = sacc[t][qt][r] * sl2;
           s[t][r] = v;
         }
       }
-      if (need_mask) {
+      if (BIAS == 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool row_ok = (4 * kt + t) < p.S;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][r] = (row_ok && kw_ok[r]) ? s[t][r] : -INFINITY;
+        }
+      } else if (need_mask) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -347,8 +387,13 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int dp = d <= 64 ? 64 : (d <= 96 ? 96 : 128);
   if (rel) {
-    const int mode = (S == 64) ? 2 : 1;
+    const int mode = (S == 64) ? 2 : (S <= 16 && Nk == S * S ? 3 : 1);
     if (mode == 1 && S > 32) return HAFF_ERR_UNSUPPORTED;
+    if (mode == 3) {
+      if (dp == 64) return launch_attn<64, 3, false>(p, s);
+      if (dp == 96) return launch_attn<96, 3, false>(p, s);
+      return launch_attn<128, 3, false>(p, s);
+    }
     if (dp == 64) return mode == 2 ? launch_attn<64, 2, false>(p, s) : launch_attn<64, 1, false>(p, s);
     if (dp == 96) return mode == 2 ? launch_attn<96, 2, false>(p, s) : launch_attn<96, 1, false>(p, s);
     return mode == 2 ? launch_attn<128, 2, false>(p, s) : launch_attn<128, 1, false>(p, s);
