@@ -57,21 +57,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int RSTRIDE = 2 * SMAX + 1;  // odd stride: the 16 query lanes of a tile hit 16 different banks
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char* sK = smem_raw;
-  unsigned char* sV = smem_raw + KT * KSTRIDE;
-  float* sRel = reinterpret_cast<float*>(smem_raw + KT * KSTRIDE + KT * VSTRIDE);  // [QB][2*SMAX+1] when BIAS==1
+  constexpr int STAGE_BYTES = KT * KSTRIDE + KT * VSTRIDE;  // one K tile + one V tile
+  unsigned char* sKV = smem_raw;                             // two stages (double buffer: one barrier per tile)
+  float* sRel = reinterpret_cast<float*>(smem_raw + 2 * STAGE_BYTES);  // [QB][2*SMAX+1] when BIAS==1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int fr = lane & 15, fh = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * QB;
+  // XCD-aware decode of the 1-D grid (speed only): workgroups are dealt round-robin over the 8 XCDs, so ids that
+  // are equal mod 8 share an L2. All query blocks of one (batch, head) are given ids equal mod 8 and adjacent in
+  // that XCD's order: its K/V (N*d*4 B, 1.3 MB for the SAM global layers) is then fetched from HBM once per XCD
+  // and re-read from that XCD's 4 MiB L2 by the other query blocks.
+  const int nqb = (p.Nq + QB - 1) / QB;
+  const int nbh = p.B * p.H;
+  int bh_id, qblk;
+  {
+    const int id = blockIdx.x;
+    if ((nbh & 7) == 0) {
+      bh_id = (id & 7) + 8 * (id / (8 * nqb));
+      qblk = (id >> 3) % nqb;
+    } else {
+      bh_id = id / nqb;
+      qblk = id - bh_id * nqb;
+    }
+  }
+  const int b = bh_id / p.H, h = bh_id - b * p.H;
+  const int q0 = qblk * QB;
 
   const bf16_t* qb = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
   const bf16_t* kb = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
   const bf16_t* vb = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
 
+  const float sl2 = p.scale * LOG2E;            // scores are kept in the log2 domain
   // ---- Q fragments (B operand: lane = (query fr, d-chunk fh)) ----
   bf16x8 qf[2][NKD];
   int qrow[2];
@@ -84,12 +102,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     for (int kd = 0; kd < NKD; ++kd) {
       const int col = kd * 32 + fh * 8;
       uint4 r = make_uint4(0, 0, 0, 0);
-      if (col < p.d) r = *reinterpret_cast<const uint4*>(qb + (long)qc * p.q_st + col);
+      if (col < p.d) {
+        // q is pre-multiplied by scale*log2(e) (rounded to bf16 once per workgroup, like the reference's bf16
+        // `q * self.scale`): scores then leave the MFMA already in the log2 domain with the bias folded into
+        // the accumulator's initial value — no per-element fma/zero-fill in the tile loop.
+        float qv[8];
+        load8(qb + (long)qc * p.q_st + col, qv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] *= sl2;
+        r.x = pack_bf16x2(qv[0], qv[1]); r.y = pack_bf16x2(qv[2], qv[3]);
+        r.z = pack_bf16x2(qv[4], qv[5]); r.w = pack_bf16x2(qv[6], qv[7]);
+      }
       qf[qt][kd] = __builtin_bit_cast(bf16x8, r);
     }
   }
 
-  const float sl2 = p.scale * LOG2E;            // scores are kept in the log2 domain
   const float inv_S = p.S > 0 ? 1.0f / (float)p.S : 0.f;
   // ---- bias setup ----
   float relw_r[2][4][4];
@@ -140,6 +167,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     }
   }
 
+  float relh_next[2] = {0.f, 0.f};
+  if (BIAS == 2) {
+    relh_next[0] = relh_row[0][0];
+    relh_next[1] = relh_row[1][0];
+  }
+
   // ---- K/V staging coordinates ----
   int st_row[NCH], st_c[NCH];
 #pragma unroll
@@ -149,26 +182,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     st_c[i] = id - st_row[i] * CPR;
   }
   uint4 kreg[NCH], vreg[NCH];
+  const bf16_t* kptr[NCH];
+  const bf16_t* vptr[NCH];
+  bool col_ok[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    col_ok[i] = st_c[i] * 8 < p.d;
+    kptr[i] = kb + (long)st_row[i] * p.k_st + st_c[i] * 8;
+    vptr[i] = vb + (long)st_row[i] * p.v_st + st_c[i] * 8;
+  }
+  const long k_step = (long)KT * p.k_st, v_step = (long)KT * p.v_st;
   auto load_tile = [&](int kt) {
+    const bool plain = (BIAS != 3) && (kt * KT + KT <= p.Nk);  // wave-uniform: whole tile in range, no remap
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      int key = kt * KT + st_row[i];
-      if (BIAS == 3) key = min(key >> 4, p.S - 1) * p.S + min(key & 15, p.S - 1);
-      key = min(key, p.Nk - 1);
-      const int col = st_c[i] * 8;
       kreg[i] = make_uint4(0, 0, 0, 0);
       vreg[i] = make_uint4(0, 0, 0, 0);
-      if (col < p.d) {
-        kreg[i] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st + col);
-        vreg[i] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st + col);
+      if (col_ok[i]) {
+        if (plain) {
+          kreg[i] = *reinterpret_cast<const uint4*>(kptr[i] + kt * k_step);
+          vreg[i] = *reinterpret_cast<const uint4*>(vptr[i] + kt * v_step);
+        } else {
+          int key = kt * KT + st_row[i];
+          if (BIAS == 3) key = min(key >> 4, p.S - 1) * p.S + min(key & 15, p.S - 1);
+          key = min(key, p.Nk - 1);
+          kreg[i] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st + st_c[i] * 8);
+          vreg[i] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st + st_c[i] * 8);
+        }
       }
     }
   };
-  auto write_tile = [&]() {
+  auto write_tile = [&](int buf) {
+    unsigned char* wK = sKV + buf * STAGE_BYTES;
+    unsigned char* wV = wK + KT * KSTRIDE;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      *reinterpret_cast<uint4*>(sK + st_row[i] * KSTRIDE + st_c[i] * 16) = kreg[i];
-      *reinterpret_cast<uint4*>(sV + st_row[i] * VSTRIDE + st_c[i] * 16) = vreg[i];
+      *reinterpret_cast<uint4*>(wK + st_row[i] * KSTRIDE + st_c[i] * 16) = kreg[i];
+      *reinterpret_cast<uint4*>(wV + st_row[i] * VSTRIDE + st_c[i] * 16) = vreg[i];
     }
   };
 
@@ -190,18 +240,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
 
   load_tile(0);
+  write_tile(0);
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // previous tile's LDS reads are done
-    write_tile();
-    __syncthreads();
-    if (kt + 1 < nkt) load_tile(kt + 1);  // in flight during the MFMAs below
+    const unsigned char* sK = sKV + (kt & 1) * STAGE_BYTES;
+    const unsigned char* sV = sK + KT * KSTRIDE;
+    if (kt + 1 < nkt) load_tile(kt + 1);  // HBM -> registers, in flight during the MFMAs below
 
-    // ---- S^T = K . Q^T ----
+    // ---- S^T = K . Q^T, accumulators start at the (log2-domain) bias ----
     f32x4 sacc[4][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      sacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      sacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < 2; ++qt) {
+      float rh3[4] = {0.f, 0.f, 0.f, 0.f};
+      if (BIAS == 3) {
+        switch (kt) {
+          case 0: rh3[0] = relh3[qt][0]; rh3[1] = relh3[qt][1]; rh3[2] = relh3[qt][2]; rh3[3] = relh3[qt][3]; break;
+          case 1: rh3[0] = relh3[qt][4]; rh3[1] = relh3[qt][5]; rh3[2] = relh3[qt][6]; rh3[3] = relh3[qt][7]; break;
+          case 2: rh3[0] = relh3[qt][8]; rh3[1] = relh3[qt][9]; rh3[2] = relh3[qt][10]; rh3[3] = relh3[qt][11]; break;
+          default: rh3[0] = relh3[qt][12]; rh3[1] = relh3[qt][13]; rh3[2] = relh3[qt][14]; rh3[3] = relh3[qt][15]; break;
+        }
+      }
+      const float rhv = relh_next[qt] * LOG2E;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (BIAS == 2) sacc[t][qt] = f32x4{relw_r[qt][t][0] + rhv, relw_r[qt][t][1] + rhv, relw_r[qt][t][2] + rhv, relw_r[qt][t][3] + rhv};
+        else if (BIAS == 3) sacc[t][qt] = f32x4{relw3[qt][0] + rh3[t], relw3[qt][1] + rh3[t], relw3[qt][2] + rh3[t], relw3[qt][3] + rh3[t]};
+        else sacc[t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (BIAS == 2 && kt + 1 < nkt) relh_next[qt] = relh_row[qt][kt + 1];  // one tile ahead: latency hidden
     }
 #pragma unroll
     for (int kd = 0; kd < NKD; ++kd) {
@@ -233,28 +299,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float s[4][4];
-      float relh_v = 0.f;
-      if (BIAS == 2) relh_v = relh_row[qt][kt] * LOG2E;
       const float* rel_q = sRel + (wave * 32 + qt * 16 + fr) * RSTRIDE;
-      float rh3[4] = {0.f, 0.f, 0.f, 0.f};
-      if (BIAS == 3) {
-        switch (kt) {
-          case 0: rh3[0] = relh3[qt][0]; rh3[1] = relh3[qt][1]; rh3[2] = relh3[qt][2]; rh3[3] = relh3[qt][3]; break;
-          case 1: rh3[0] = relh3[qt][4]; rh3[1] = relh3[qt][5]; rh3[2] = relh3[qt][6]; rh3[3] = relh3[qt][7]; break;
-          case 2: rh3[0] = relh3[qt][8]; rh3[1] = relh3[qt][9]; rh3[2] = relh3[qt][10]; rh3[3] = relh3[qt][11]; break;
-          default: rh3[0] = relh3[qt][12]; rh3[1] = relh3[qt][13]; rh3[2] = relh3[qt][14]; rh3[3] = relh3[qt][15]; break;
-        }
-      }
       float mx = -1e30f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v;
-          if (BIAS == 2) v = fmaf(sacc[t][qt][r], sl2, relw_r[qt][t][r]) + relh_v;
-          else if (BIAS == 3) v = fmaf(sacc[t][qt][r], sl2, relw3[qt][r]) + rh3[t];
-          else if (BIAS == 1) v = fmaf(sacc[t][qt][r], sl2, rel_q[off_h[t][r]] + rel_q[off_w[t][r]]);
-          else v = sacc[t][qt][r] * sl2;
+          float v = sacc[t][qt][r];
+          if (BIAS == 1) v += rel_q[off_h[t][r]] + rel_q[off_w[t][r]];
           s[t][r] = v;
         }
       }
@@ -283,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       if (__any(mx > m_run[qt])) {  // exact lazy rescale: most tiles do not raise the running max
         const float m_new = fmaxf(m_run[qt], mx);
-        const float alpha = exp2f(m_run[qt] - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
         m_run[qt] = m_new;
         l_run[qt] *= alpha;
 #pragma unroll
@@ -298,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[t][r] - mb);
+          const float e = __builtin_amdgcn_exp2f(s[t][r] - mb);  // raw v_exp_f32: arguments are <= 0, tiny results may flush
           s[t][r] = e;
           psum += e;
         }
@@ -330,6 +382,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         oacc[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][ks], oacc[dt][1], 0, 0, 0);
       }
     }
+    // registers -> the OTHER stage (last read one iteration ago, every wave is past that barrier), then ONE barrier:
+    // it publishes the new tile and fences this tile's reads before the next iteration overwrites its stage
+    if (kt + 1 < nkt) write_tile((kt + 1) & 1);
+    __syncthreads();
   }
 
   // ---- finalize: out[q][16dt + 4fh + r] = O^T / l ----
@@ -356,9 +412,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 template <int DP, int BIAS, bool CAUSAL>
 int launch_attn(const AttnArgs& p, hipStream_t s) {
   constexpr int KSTRIDE = DP * 2 + 16, VSTRIDE = DP * 2 + 32;
-  size_t lds = (size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE;
+  size_t lds = 2 * ((size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE);
   if (BIAS == 1) lds += (size_t)QB * (2 * 32 + 1) * sizeof(float);
-  dim3 grid((p.Nq + QB - 1) / QB, p.H, p.B), block(256);
+  dim3 grid(((p.Nq + QB - 1) / QB) * p.H * p.B), block(256);
   hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL>), grid, block, lds, s, p);
   return haff_check_launch();
 }
