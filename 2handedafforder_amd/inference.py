@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Batch inference CLI — same flags, directory walk, prompt and output files as the reference's 2Haff/inference.py
+(:20-49 flags, :199-334 loop), running the model on MI355X through LisaMI355.evaluate().
+
+  python -m 2handedafforder_amd.inference ...   (or: python 2handedafforder_amd/inference.py ...)
+
+Offline extras: --synthetic (seeded random weights + byte tokenizer, for plumbing runs without checkpoints).
+Images are read/written with PIL (cv2 is not a dependency here); thresholds and file names follow :197,299,331.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import haff  # noqa: F401
+    from haff import checkpoint, config as hcfg, preprocess, prompt as hprompt
+    from haff.lisa import LisaMI355
+else:
+    from . import checkpoint, config as hcfg, preprocess, prompt as hprompt
+    from .lisa import LisaMI355
+
+
+def parse_args(args):
+    parser = argparse.ArgumentParser(description="LISA chat")
+    parser.add_argument("--version", default="sjauhri/2HAff")
+    parser.add_argument("--vis_save_path", default="./vis_output", type=str)
+    parser.add_argument("--precision", default="bf16", type=str, choices=["fp32", "bf16", "fp16"], help="precision for inference")
+    parser.add_argument("--image_size", default=1024, type=int, help="image size")
+    parser.add_argument("--model_max_length", default=512, type=int)
+    parser.add_argument("--lora_r", default=8, type=int)
+    parser.add_argument("--vision-tower", default="openai/clip-vit-large-patch14", type=str)
+    parser.add_argument("--local-rank", default=0, type=int, help="node rank")
+    parser.add_argument("--load_in_8bit", action="store_true", default=False)
+    parser.add_argument("--load_in_4bit", action="store_true", default=False)
+    parser.add_argument("--use_mm_start_end", action="store_true", default=True)
+    parser.add_argument("--conv_type", default="llava_v1", type=str, choices=["llava_v1", "llava_llama_2"])
+    parser.add_argument("--benchmark-dir", default=None, type=str, help="directory containing subfolders of benchmark examples")
+    # MI355X / offline extras
+    parser.add_argument("--synthetic", default=None, choices=["tiny", "mid", "7b", "13b"], help="random-init model of this geometry")
+    parser.add_argument("--sam-checkpoint", default=None, type=str)
+    parser.add_argument("--max-new-tokens", default=512, type=int)
+    return parser.parse_args(args)
+
+
+def build_model_and_tokenizer(args):
+    if args.load_in_8bit or args.load_in_4bit or args.precision == "fp16":
+        raise SystemExit("bitsandbytes 4/8-bit and the DeepSpeed fp16 kernel-inject mode are outside this build's scope "
+                         "(SURVEY §2.2); use --precision bf16 or fp32")
+    dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    device = f"cuda:{args.local_rank}"
+    if args.synthetic:
+        cfg = {"tiny": hcfg.tiny, "mid": hcfg.mid, "7b": hcfg.haff_7b, "13b": hcfg.haff_13b}[args.synthetic]()
+        sd = checkpoint.synthetic_state_dict(cfg, 1234, device, dtype)
+        tokenizer = checkpoint.ByteTokenizer(cfg)
+    else:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(args.version, cache_dir=None, model_max_length=args.model_max_length,
+                                                  padding_side="right", use_fast=False)
+        tokenizer.pad_token = tokenizer.unk_token
+        cfg = checkpoint.config_from_dir(args.version)
+        cfg.seg_token_idx = tokenizer("[SEG]", add_special_tokens=False).input_ids[0]
+        cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
+        sd = checkpoint.load_state_dict(args.version, args.vision_tower if os.path.isdir(args.vision_tower) else None,
+                                        args.sam_checkpoint)
+    model = LisaMI355(cfg, sd, dtype=dtype, device=device).eval()
+    return model, tokenizer, cfg, dtype
+
+
+def load_rgb(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def prepare_frame(image_np, cfg, dtype, device):
+    """inference.py:229-256: CLIP tensor, resized+normalised+padded SAM tensor, resize_list, original_size_list."""
+    original_size = tuple(image_np.shape[:2])
+    image_clip = preprocess.clip_preprocess(torch.from_numpy(image_np.copy()), cfg.clip.image).unsqueeze(0).to(device, dtype)
+    resized = preprocess.resize_longest_side(torch.from_numpy(image_np.copy()), cfg.sam.img_size)
+    resize = tuple(resized.shape[:2])
+    image = preprocess.sam_preprocess(resized, cfg.sam.img_size).unsqueeze(0).to(device, dtype)
+    return image_clip, image, [resize], [original_size]
+
+
+def save_mask(path, mask_bool):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray((mask_bool.astype(np.uint8) * 255)).save(path)
+    print(f"{path} has been saved.")
+
+
+def main(argv):
+    args = parse_args(argv)
+    model, tokenizer, cfg, dtype = build_model_and_tokenizer(args)
+    device = model.device
+    for dir_name in sorted(os.listdir(args.benchmark_dir)):
+        dir_path = os.path.join(args.benchmark_dir, dir_name)
+        if not os.path.isdir(dir_path):
+            continue
+        for folder_name in sorted(os.listdir(dir_path)):
+            folder_path = os.path.join(dir_path, folder_name)
+            if not os.path.isdir(folder_path):
+                continue
+            image_path = os.path.join(folder_path, "inpainting.png")
+            annotation_path = os.path.join(folder_path, "annotation.json")
+            if not os.path.exists(image_path) or not os.path.exists(annotation_path):
+                print(f"Required files not found in {folder_path}, skipping...")
+                continue
+            with open(annotation_path) as f:
+                narration = json.load(f).get("narration", "")
+            prompt = hprompt.build_inference_prompt(narration, args.use_mm_start_end)
+            image_np = load_rgb(image_path)
+            image_clip, image, resize_list, original_size_list = prepare_frame(image_np, cfg, dtype, device)
+            input_ids = hprompt.tokenizer_image_token(prompt, tokenizer, return_tensors="pt").unsqueeze(0).to(device)
+            output_ids, masks_left, masks_right, taxonomies = model.evaluate(
+                image_clip, image, input_ids, resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
+                tokenizer=tokenizer)
+            taxonomy = taxonomies[0]
+            if taxonomy.numel() == 0:
+                continue
+            t = int(torch.argmax(taxonomy))
+            for side, masks, skip in (("left", masks_left, 1), ("right", masks_right, 0)):
+                if t == skip:
+                    continue
+                for pred_mask in masks:
+                    if pred_mask.shape[0] == 0:
+                        continue
+                    prob = torch.sigmoid(pred_mask[0]).cpu().numpy()
+                    for th in preprocess.THRESHOLDS:
+                        save_mask(os.path.join(args.vis_save_path + str(th), dir_name, folder_name, f"aff_{side}.png"), prob > th)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
