@@ -1,0 +1,556 @@
+"""Differentiable ops of the LoRA fine-tune path: torch.autograd.Function shells whose forward AND backward are
+hand-written HIP kernels (csrc/train.hip + the GEMM / norm kernels). torch.autograd only records the graph and
+routes gradients (plumbing); no torch arithmetic runs in these Functions.
+
+Reference semantics: LISAForCausalLM.model_forward (2Haff/model/LISA.py:175-430), peft LoRA on q_proj/v_proj
+(train_ds.py:217-231), transformers LlamaDecoderLayer / CrossEntropyLoss (llava_llama.py:93-118).
+Contractions in backward reuse the NT GEMM (C = A.W^T): dX = dY.W via W^T, dW = dY^T.X via transposed operands.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .lib import check, load_library
+
+
+def _dt(t):
+    return ops._dt(t)
+
+
+def _s():
+    return ops._stream()
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# raw (non-differentiable) wrappers of csrc/train.hip
+# ------------------------------------------------------------------------------------------------------------------
+def transpose(x, Rp=None, Cp=None):
+    """x [..., R, C] (any batch strides, unit inner stride) -> [Z, Cp, Rp] contiguous, zero padded."""
+    lib = load_library()
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    lead = x.shape[:-2]
+    R, C = x.shape[-2], x.shape[-1]
+    assert x.stride(-1) == 1
+    Rp = R if Rp is None else Rp
+    Cp = C if Cp is None else Cp
+    if len(lead) == 1:
+        nbo, nbi, so, si = lead[0], 1, x.stride(0), 0
+    elif len(lead) == 2:
+        nbo, nbi, so, si = lead[0], lead[1], x.stride(0), x.stride(1)
+    else:
+        raise ValueError("transpose supports at most two batch dims")
+    out = torch.empty((nbo * nbi, Cp, Rp), dtype=x.dtype, device=x.device)
+    check(lib.haff_transpose(x.data_ptr(), x.stride(-2), so, si, out.data_ptr(), R, C, Rp, Cp, nbo, nbi, _dt(x), _s()),
+          "haff_transpose")
+    return out
+
+
+def bgemm(a, w, out=None, out_dtype=None):
+    """Batched NT product: a [Zo,Zi,M,K], w [Zo,Zi,N,K] (strided views, unit inner stride) -> out [Zo,Zi,M,N]
+    (contiguous unless `out` is a strided view with unit inner stride)."""
+    lib = load_library()
+    Zo, Zi, M, K = a.shape
+    N = w.shape[2]
+    assert w.shape[0] == Zo and w.shape[1] == Zi and w.shape[3] == K and a.stride(3) == 1 and w.stride(3) == 1
+    if out_dtype is None:
+        out_dtype = a.dtype
+    if out is None:
+        out = torch.empty((Zo, Zi, M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(3) == 1
+    if a.dtype == torch.bfloat16:
+        rc = lib.haff_gemm_bf16_batched(a.data_ptr(), a.stride(2), a.stride(0), a.stride(1), w.data_ptr(), w.stride(2),
+                                        w.stride(0), w.stride(1), out.data_ptr(), out.stride(2), out.stride(0),
+                                        out.stride(1), Zo, Zi, M, N, K, 1 if out.dtype == torch.float32 else 0, _s())
+    else:
+        assert out.dtype == torch.float32
+        rc = lib.haff_gemm_f32_batched(a.data_ptr(), a.stride(2), a.stride(0), a.stride(1), w.data_ptr(), w.stride(2),
+                                       w.stride(0), w.stride(1), out.data_ptr(), out.stride(2), out.stride(0),
+                                       out.stride(1), Zo, Zi, M, N, K, _s())
+    check(rc, "haff_gemm_batched")
+    return out
+
+
+def colsum(x2d):
+    lib = load_library()
+    x2d = x2d.contiguous()
+    out = torch.zeros((x2d.shape[1],), dtype=torch.float32, device=x2d.device)
+    check(lib.haff_colsum(x2d.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1], _dt(x2d), _s()), "haff_colsum")
+    return out
+
+
+def axpby(a, b, alpha, beta):
+    lib = load_library()
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    bp = 0
+    if b is not None:
+        b = b.contiguous()
+        bp = b.data_ptr()
+    check(lib.haff_axpby(a.data_ptr(), bp, out.data_ptr(), a.numel(), float(alpha), float(beta), _dt(a), _s()), "haff_axpby")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Functions
+# ------------------------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = x @ w.T + bias (+ resid). w_t: optional precomputed w.T (frozen weights keep one resident)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, resid, w_t):
+        x2 = x if x.stride(1) == 1 else x.contiguous()
+        y = ops.linear(x2, w, bias=bias, resid=resid)
+        ctx.save_for_backward(x2, w, w_t if w_t is not None else torch.empty(0, device=x.device))
+        ctx.has_bias = bias is not None
+        ctx.has_resid = resid is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, w_t = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = dres = None
+        M, K = x.shape
+        N = w.shape[0]
+        if ctx.needs_input_grad[0]:
+            if w_t.numel() == 0:
+                w_t = transpose(w, Rp=_pad8(N))[0]  # [K, Np]
+            dyk = dy
+            if w_t.shape[1] != N:  # K-dim of this product is N: pad dy's columns with zeros
+                dyk = torch.zeros((M, w_t.shape[1]), dtype=dy.dtype, device=dy.device)
+                dyk[:, :N] = dy
+            dx = ops.linear(dyk, w_t)
+        if ctx.needs_input_grad[1]:
+            Mp = _pad8(M)
+            dy_t = transpose(dy, Rp=Mp)[0]   # [N, Mp]
+            x_t = transpose(x, Rp=Mp)[0]     # [K, Mp]
+            dw = ops.linear(dy_t, x_t)       # [N, K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
+        if ctx.has_resid and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None
+
+
+def linear(x, w, bias=None, resid=None, w_t=None):
+    return LinearFn.apply(x, w, bias, resid, w_t)
+
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        lib = load_library()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.haff_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, _dt(x), _s()), "haff_act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.haff_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), ctx.act, _dt(x), _s()), "haff_act_bwd")
+        return dx, None
+
+
+def act(x, code):
+    return ActFn.apply(x, code)
+
+
+class SwigluFn(Function):
+    """gu [M, 2F] in the interleaved [gate x16 | up x16] column layout -> silu(gate) * up [M, F]."""
+
+    @staticmethod
+    def forward(ctx, gu):
+        lib = load_library()
+        gu = gu.contiguous()
+        M, F2 = gu.shape
+        y = torch.empty((M, F2 // 2), dtype=gu.dtype, device=gu.device)
+        check(lib.haff_swiglu_fwd(gu.data_ptr(), y.data_ptr(), M, F2 // 2, _dt(gu), _s()), "haff_swiglu_fwd")
+        ctx.save_for_backward(gu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        (gu,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dgu = torch.empty_like(gu)
+        check(lib.haff_swiglu_bwd(gu.data_ptr(), dy.data_ptr(), dgu.data_ptr(), gu.shape[0], gu.shape[1] // 2, _dt(gu), _s()),
+              "haff_swiglu_bwd")
+        return dgu
+
+
+swiglu = SwigluFn.apply
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return axpby(a, b, 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+add = AddFn.apply
+
+
+class ScaleFn(Function):
+    @staticmethod
+    def forward(ctx, a, alpha):
+        ctx.alpha = alpha
+        return axpby(a, None, alpha, 0.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return axpby(dy, None, ctx.alpha, 0.0), None
+
+
+scale = ScaleFn.apply
+
+
+class AddBcastFn(Function):
+    """out[r] = a[r] + b[r % mod] with b constant (positional encodings)."""
+
+    @staticmethod
+    def forward(ctx, a, b, mod):
+        return ops.add_bcast(a.contiguous(), b, mod=mod)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+add_const = AddBcastFn.apply
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return ops.layernorm(x, w, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        need_w = ctx.needs_input_grad[1]
+        dyx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_w else None
+        check(lib.haff_norm_bwd(x.data_ptr(), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), 0 if dyx is None else dyx.data_ptr(),
+                                x.shape[0], x.shape[1], float(ctx.eps), 0, _dt(x), _s()), "haff_norm_bwd")
+        dw = colsum(dyx) if need_w else None
+        db = colsum(dy) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+layernorm = LayerNormFn.apply
+
+
+class RMSNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return ops.rmsnorm(x, w, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.haff_norm_bwd(x.data_ptr(), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, x.shape[0], x.shape[1],
+                                float(ctx.eps), 1, _dt(x), _s()), "haff_norm_bwd")
+        return dx, None, None
+
+
+rmsnorm = RMSNormFn.apply
+
+
+class RopeFn(Function):
+    """x [rows, H*d] (rows = B*T, position = row % T) -> rotated copy."""
+
+    @staticmethod
+    def forward(ctx, x, cos_sin, T, H, d):
+        lib = load_library()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.haff_rope(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), cos_sin.data_ptr(), x.shape[0], T, H, d, 0, 0,
+                            _dt(x), _s()), "haff_rope")
+        ctx.save_for_backward(cos_sin)
+        ctx.dims = (T, H, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        (cos_sin,) = ctx.saved_tensors
+        T, H, d = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.haff_rope(dy.data_ptr(), dy.stride(0), dx.data_ptr(), dx.stride(0), cos_sin.data_ptr(), dy.shape[0], T, H, d, 0, 1,
+                            _dt(dy), _s()), "haff_rope")
+        return dx, None, None, None, None
+
+
+rope = RopeFn.apply
+
+
+class AttentionFn(Function):
+    """softmax(scale * q k^T [+ causal]) v with materialised probabilities (training sequences are a few hundred
+    tokens: P for one layer is tens of MB in 288 GB of HBM). q [B,Nq,H*d], k/v [B,Nk,H*d] token-major -> [B,Nq,H*d]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, scale_, causal):
+        lib = load_library()
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Nq, HD = q.shape
+        Nk = k.shape[1]
+        d = HD // H
+        q4 = q.view(B, Nq, H, d).permute(0, 2, 1, 3)
+        k4 = k.view(B, Nk, H, d).permute(0, 2, 1, 3)
+        v4 = v.view(B, Nk, H, d).permute(0, 2, 1, 3)
+        Nkp = _pad8(Nk)
+        s = bgemm(q4, k4, out_dtype=torch.float32)                       # [B,H,Nq,Nk]
+        p = torch.empty((B, H, Nq, Nkp), dtype=q.dtype, device=q.device)
+        check(lib.haff_softmax_fwd(s.data_ptr(), Nk, p.data_ptr(), Nkp, B * H * Nq, Nq, Nk, float(scale_), 1 if causal else 0,
+                                   Nk - Nq, _dt(q), _s()), "haff_softmax_fwd")
+        vt = transpose(v4, Rp=Nkp).view(B, H, d, Nkp)                    # [B,H,d,Nkp]
+        out = torch.empty((B, Nq, HD), dtype=q.dtype, device=q.device)
+        bgemm(p, vt, out=out.view(B, Nq, H, d).permute(0, 2, 1, 3))
+        ctx.save_for_backward(q, k, v, p)
+        ctx.cfg = (H, float(scale_), Nk)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = load_library()
+        q, k, v, p = ctx.saved_tensors
+        H, scale_, Nk = ctx.cfg
+        do = do.contiguous()
+        B, Nq, HD = q.shape
+        d = HD // H
+        Nkp, Nqp = p.shape[3], _pad8(Nq)
+        q4 = q.view(B, Nq, H, d).permute(0, 2, 1, 3)
+        k4 = k.view(B, Nk, H, d).permute(0, 2, 1, 3)
+        v4 = v.view(B, Nk, H, d).permute(0, 2, 1, 3)
+        do4 = do.view(B, Nq, H, d).permute(0, 2, 1, 3)
+        dp = bgemm(do4, v4, out_dtype=torch.float32)                     # [B,H,Nq,Nk]
+        ds = torch.empty_like(p)
+        check(lib.haff_softmax_bwd(p.data_ptr(), Nkp, dp.data_ptr(), Nk, ds.data_ptr(), B * H * Nq, Nk, scale_, _dt(p), _s()),
+              "haff_softmax_bwd")
+        kt = transpose(k4, Rp=Nkp).view(B, H, d, Nkp)
+        dq = torch.empty_like(q)
+        bgemm(ds, kt, out=dq.view(B, Nq, H, d).permute(0, 2, 1, 3))
+        ds_t = transpose(ds[..., :Nk], Rp=Nqp).view(B, H, Nk, Nqp)
+        p_t = transpose(p[..., :Nk], Rp=Nqp).view(B, H, Nk, Nqp)
+        qt = transpose(q4, Rp=Nqp).view(B, H, d, Nqp)
+        dot = transpose(do4, Rp=Nqp).view(B, H, d, Nqp)
+        dk = torch.empty_like(k)
+        dv = torch.empty_like(v)
+        bgemm(ds_t, qt, out=dk.view(B, Nk, H, d).permute(0, 2, 1, 3))
+        bgemm(p_t, dot, out=dv.view(B, Nk, H, d).permute(0, 2, 1, 3))
+        return dq, dk, dv, None, None, None
+
+
+attention = AttentionFn.apply
+
+
+class BgemmFn(Function):
+    """c[z] = a[z] @ b[z].T for a [Z,M,K], b [Z,N,K]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return bgemm(a.unsqueeze(1), b.unsqueeze(1), out_dtype=a.dtype).squeeze(1)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = dc.contiguous()
+        Z, M, K = a.shape
+        N = b.shape[1]
+        Np, Mp = _pad8(N), _pad8(M)
+        bt = transpose(b, Rp=Np).view(Z, 1, K, Np)
+        dcp = dc
+        if Np != N:
+            dcp = torch.zeros((Z, M, Np), dtype=dc.dtype, device=dc.device)
+            dcp[..., :N] = dc
+        da = bgemm(dcp.unsqueeze(1), bt, out_dtype=a.dtype).squeeze(1)          # [Z,M,K]
+        dct = transpose(dc, Rp=Mp).view(Z, 1, N, Mp)
+        at = transpose(a, Rp=Mp).view(Z, 1, K, Mp)
+        db = bgemm(dct, at, out_dtype=b.dtype).squeeze(1)                       # [Z,N,K]
+        return da, db
+
+
+bmm_nt = BgemmFn.apply
+
+
+class EmbedFn(Function):
+    @staticmethod
+    def forward(ctx, weight, ids):
+        ctx.save_for_backward(ids)
+        ctx.shape = weight.shape
+        ctx.wdtype = weight.dtype
+        safe = ids.clamp(min=0)
+        return weight.index_select(0, safe.reshape(-1)).view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        (ids,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        acc = torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device)
+        flat = ids.reshape(-1).contiguous()
+        check(lib.haff_scatter_add_rows(flat.data_ptr(), dy.data_ptr(), acc.data_ptr(), flat.numel(), ctx.shape[1], _dt(dy), _s()),
+              "haff_scatter_add_rows")
+        return acc.to(ctx.wdtype), None
+
+
+embed = EmbedFn.apply
+
+
+class CrossEntropyFn(Function):
+    """mean over rows with label >= 0 of (logsumexp(logits) - logits[label])  (CrossEntropyLoss, ignore_index=-100)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lib = load_library()
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        R, V = logits.shape
+        n_valid = max(int((labels >= 0).sum().item()), 1)
+        row_loss = torch.empty((R,), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        check(lib.haff_cross_entropy(logits.data_ptr(), logits.stride(0), labels.data_ptr(), row_loss.data_ptr(), dlogits.data_ptr(),
+                                     R, V, 1.0 / n_valid, _dt(logits), _s()), "haff_cross_entropy")
+        ctx.save_for_backward(dlogits)
+        # sum of R floats / n_valid: reduction of a tiny vector (torch sum as plumbing of a scalar)
+        return (row_loss.sum() / n_valid).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return axpby(dlogits, None, float(g.item()), 0.0), None
+
+
+cross_entropy = CrossEntropyFn.apply
+
+
+class MaskLossFn(Function):
+    """Per-sample [bce_i, dice_i] (LISA.py:16-59) of f32 logits x [n, HW] scaled by wgt[i] against targets t."""
+
+    @staticmethod
+    def forward(ctx, x, t, wgts):
+        lib = load_library()
+        x, t = x.contiguous(), t.contiguous()
+        n, hw = x.shape
+        stats = torch.zeros((n, 4), dtype=torch.float32, device=x.device)
+        for i in range(n):  # per-sample weight is a host scalar (taxonomy one-hot sums)
+            check(lib.haff_mask_loss_stats(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), 1, hw, float(wgts[i]), _s()),
+                  "haff_mask_loss_stats")
+        ctx.save_for_backward(x, t, stats)
+        ctx.wgts = [float(w) for w in wgts]
+        st = stats.cpu()
+        bce = st[:, 0] / hw
+        num = 2 * st[:, 1] / 1000 + 1e-6
+        den = st[:, 2] / 1000 + st[:, 3] / 1000 + 1e-6
+        return torch.stack([bce, 1 - num / den], dim=1).to(x.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, t, stats = ctx.saved_tensors
+        n, hw = x.shape
+        gh = g.cpu()
+        dx = torch.empty_like(x)
+        for i in range(n):
+            check(lib.haff_mask_loss_grad(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), dx[i].data_ptr(), 1, hw,
+                                          ctx.wgts[i], float(gh[i, 0]), float(gh[i, 1]), _s()), "haff_mask_loss_grad")
+        return dx, None, None
+
+
+mask_losses = MaskLossFn.apply
+
+
+class BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, crop_hw, out_hw):
+        x = x.contiguous()
+        ctx.geom = (tuple(x.shape), tuple(int(v) for v in crop_hw), tuple(int(v) for v in out_hw))
+        return ops.resize_bilinear(x, crop_hw, out_hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        (N, Hs, Ws), (Hc, Wc), (Ho, Wo) = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.zeros((N, Hs, Ws), dtype=torch.float32, device=dy.device)
+        check(lib.haff_resize_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), N, Hs, Ws, Hc, Wc, Ho, Wo, _s()), "haff_resize_bilinear_bwd")
+        return dx, None, None
+
+
+resize_bilinear = BilinearFn.apply
+
+
+class CastFn(Function):
+    """dtype change (bf16 <-> f32) — a copy, kept as a Function so gradients come back in the source dtype."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return x.to(dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.to(ctx.src), None
+
+
+cast = CastFn.apply
+
+
+class TaxonomyCEFn(Function):
+    """sum over rows of CrossEntropyLoss(softmax(z), soft target) — LISA.py:414-417 (input is already soft-maxed)."""
+
+    @staticmethod
+    def forward(ctx, z, t):
+        lib = load_library()
+        z, t = z.contiguous(), t.contiguous().float()
+        R, C = z.shape
+        loss = torch.empty((R,), dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        probs = torch.empty_like(z)
+        check(lib.haff_taxonomy_ce(z.data_ptr(), t.data_ptr(), probs.data_ptr(), loss.data_ptr(), dz.data_ptr(), R, C, _s()),
+              "haff_taxonomy_ce")
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(probs)
+        return loss, probs
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        (dz,) = ctx.saved_tensors
+        gh = g.cpu()
+        out = torch.empty_like(dz)
+        for i in range(dz.shape[0]):  # per-row upstream scalar (rows = samples of a micro-batch)
+            out[i] = axpby(dz[i], None, float(gh[i]), 0.0)
+        return out, None
+
+
+taxonomy_ce = TaxonomyCEFn.apply

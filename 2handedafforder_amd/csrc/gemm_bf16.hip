@@ -37,6 +37,9 @@ struct GemmArgs {
   const int* row_map;
   int M, N, K;
   int act, out_f32, swiglu;
+  // batched launches (blockIdx.y = z): operand z lives at base + (z / nb_inner) * s?o + (z % nb_inner) * s?i elements
+  int nb_inner;
+  long sAo, sAi, sWo, sWi, sCo, sCi;
 };
 
 // Epilogue activations of the throughput (bf16) path. GELU uses the Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7,
@@ -78,6 +81,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.nb_inner > 0) {
+    const int zo = blockIdx.y / p.nb_inner, zi = blockIdx.y - zo * p.nb_inner;
+    p.A += zo * p.sAo + zi * p.sAi;
+    p.W += zo * p.sWo + zi * p.sWi;
+    const long coff = zo * p.sCo + zi * p.sCi;
+    p.C = OUT_F32 ? static_cast<void*>(reinterpret_cast<float*>(p.C) + coff)
+                  : static_cast<void*>(reinterpret_cast<bf16_t*>(p.C) + coff);
+  }
 
   // ---- XCD-aware + grouped tile mapping (speed only; any mapping is correct) ----
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -317,9 +328,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 
 
 template <int BM, int BN, int WM, int WN>
-static int launch_gemm(const GemmArgs& p, hipStream_t s) {
+static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles), block(64 * WM * WN);
+  dim3 grid(tiles, nbatch), block(64 * WM * WN);
   if (p.swiglu) {
     if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
@@ -339,7 +350,7 @@ extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long l
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || (ldc & 3) || resid)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
-             bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu};
+             bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   bool big = tile_cfg == 2;
   if (tile_cfg == 0) {
@@ -359,4 +370,17 @@ extern "C" int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, 
                               const float* bias, const void* resid, long ldr, const int* row_map,
                               int M, int N, int K, int act, int out_f32, int swiglu, void* stream) {
   return haff_gemm_bf16_cfg(A, lda, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0, stream);
+}
+
+// Batched C_z = A_z . W_z^T (no epilogue): z = zo * nb_inner + zi, operand offsets zo * s?o + zi * s?i (elements).
+// Used by the training path for attention-shaped products over (batch, head) (scores, P.V and their gradients).
+extern "C" int haff_gemm_bf16_batched(const void* A, long lda, long sAo, long sAi, const void* W, long ldw, long sWo,
+                                      long sWi, void* C, long ldc, long sCo, long sCi, int nb_outer, int nb_inner,
+                                      int M, int N, int K, int out_f32, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || nb_outer <= 0 || nb_inner <= 0) return HAFF_ERR_BAD_ARG;
+  if ((K & 7) || (lda & 7) || (ldw & 7) || (sAo & 7) || (sAi & 7) || (sWo & 7) || (sWi & 7)) return HAFF_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
+  GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
+             nullptr, nullptr, 0, nullptr, M, N, K, 0, out_f32, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
+  return launch_gemm<128, 128, 2, 2>(p, reinterpret_cast<hipStream_t>(stream), nb_outer * nb_inner);
 }

@@ -22,11 +22,19 @@ struct GemmF32Args {
   const int* row_map;
   int M, N, K;
   int act, swiglu;
+  int nb_inner;
+  long sAo, sAi, sWo, sWi, sCo, sCi;
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
   __shared__ float sA[TK][TM + 1];
   __shared__ float sW[TK][TN + 1];
+  if (p.nb_inner > 0) {
+    const int zo = blockIdx.y / p.nb_inner, zi = blockIdx.y - zo * p.nb_inner;
+    p.A += zo * p.sAo + zi * p.sAi;
+    p.W += zo * p.sWo + zi * p.sWi;
+    p.C += zo * p.sCo + zi * p.sCi;
+  }
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
   const int tiles_n = (p.N + TN - 1) / TN;
@@ -106,8 +114,19 @@ extern "C" int haff_gemm_f32(const float* A, long lda, const float* W, long ldw,
                              int act, int swiglu, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K & 3) || (lda & 3) || (ldw & 3)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || resid)) return HAFF_ERR_BAD_ARG;
-  GemmF32Args p{A, lda, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, swiglu};
+  GemmF32Args p{A, lda, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, swiglu, 0, 0, 0, 0, 0, 0, 0};
   const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return haff_check_launch();
+}
+
+extern "C" int haff_gemm_f32_batched(const float* A, long lda, long sAo, long sAi, const float* W, long ldw, long sWo,
+                                     long sWi, float* C, long ldc, long sCo, long sCi, int nb_outer, int nb_inner, int M,
+                                     int N, int K, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || nb_outer <= 0 || nb_inner <= 0) return HAFF_ERR_BAD_ARG;
+  if ((K & 3) || (lda & 3) || (ldw & 3) || (sAo & 3) || (sAi & 3) || (sWo & 3) || (sWi & 3)) return HAFF_ERR_BAD_ARG;
+  GemmF32Args p{A, lda, W, ldw, C, ldc, nullptr, nullptr, 0, nullptr, M, N, K, 0, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
+  const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles, nb_outer * nb_inner), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   return haff_check_launch();
 }

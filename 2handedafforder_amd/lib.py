@@ -52,6 +52,31 @@ _PROTOS = {
                           c_float, c_int, c_void_p],
     "haff_resize_bilinear": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_threshold_masks": [c_void_p, c_void_p, c_long, c_float, c_void_p],
+    # ---- training path (csrc/train.hip + batched GEMMs) ----
+    "haff_gemm_bf16_batched": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long,
+                               c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_gemm_f32_batched": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long,
+                              c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_transpose": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_act_fwd": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "haff_act_bwd": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "haff_swiglu_fwd": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "haff_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "haff_axpby": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_int, c_void_p],
+    "haff_norm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
+    "haff_colsum": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "haff_softmax_fwd": [c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p],
+    "haff_softmax_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int, c_void_p],
+    "haff_rope": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_cross_entropy": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_int, c_void_p],
+    "haff_mask_loss_stats": [c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p],
+    "haff_mask_loss_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_float, c_float, c_void_p],
+    "haff_resize_bilinear_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_scatter_add_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "haff_taxonomy_ce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "haff_sumsq": [c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "haff_adamw_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
+                        c_int, c_float, c_int, c_int, c_void_p],
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))

@@ -117,6 +117,64 @@ int haff_resize_bilinear(const float* in, float* out, int N, int Hs, int Ws, int
 /* mask > logit_th -> 0/255 bytes (inference.py:294-301 with logit_th = logit(th); chat.py:226 with 0) */
 int haff_threshold_masks(const float* in, void* out, long total, float logit_th, void* stream);
 
+
+/* ==== training path (LoRA fine-tune: train_ds.py:489-622 driving model_forward, LISA.py:175-430) ==================
+ * Contractions of the backward pass reuse the GEMM kernels: dX = dY.W (NT GEMM on a transposed weight copy),
+ * dW = dY^T.X (NT GEMM on transposed operands), attention-shaped products over (batch, head) through the batched
+ * entry points. z = zo*nb_inner + zi selects operand base + zo*s?o + zi*s?i (elements). */
+int haff_gemm_bf16_batched(const void* A, long lda, long sAo, long sAi, const void* W, long ldw, long sWo, long sWi,
+                           void* C, long ldc, long sCo, long sCi, int nb_outer, int nb_inner, int M, int N, int K,
+                           int out_f32, void* stream);
+int haff_gemm_f32_batched(const float* A, long lda, long sAo, long sAi, const float* W, long ldw, long sWo, long sWi,
+                          float* C, long ldc, long sCo, long sCi, int nb_outer, int nb_inner, int M, int N, int K,
+                          void* stream);
+/* batched transpose: in [z][R][ld_in] (C valid columns) -> out [z][Cp][Rp] contiguous, zero padded */
+int haff_transpose(const void* in, long ld_in, long s_in_o, long s_in_i, void* out, int R, int C, int Rp, int Cp,
+                   int nb_outer, int nb_inner, int dtype, void* stream);
+/* activation forward / adjoint (dx = dy * act'(x)); SwiGLU on the interleaved [gate x16 | up x16] layout */
+int haff_act_fwd(const void* x, void* y, long n, int act, int dtype, void* stream);
+int haff_act_bwd(const void* x, const void* dy, void* dx, long n, int act, int dtype, void* stream);
+int haff_swiglu_fwd(const void* gu, void* y, long M, int F, int dtype, void* stream);
+int haff_swiglu_bwd(const void* gu, const void* dy, void* dgu, long M, int F, int dtype, void* stream);
+/* out = alpha*a + beta*b (b may be null) */
+int haff_axpby(const void* a, const void* b, void* out, long n, float alpha, float beta, int dtype, void* stream);
+/* LayerNorm (rms=0) / RMSNorm (rms=1) adjoint: dx; dyx (f32 [rows][C], may be null) = dy*xhat for the weight grad */
+int haff_norm_bwd(const void* x, const void* dy, const float* w, void* dx, float* dyx, int rows, int C, float eps, int rms,
+                  int dtype, void* stream);
+/* out[c] += sum_r x[r][c] (bias / norm-weight gradients); out f32, zeroed by the caller */
+int haff_colsum(const void* x, float* out, long R, int C, int dtype, void* stream);
+/* row softmax of scale*s (+ causal mask, row r = query r % Nq, key j visible iff j <= q + q_pos0) and its adjoint
+ * dS = scale * P o (dP - rowsum(dP o P)); columns >= Nk are written as zeros (K-padding of the following GEMMs) */
+int haff_softmax_fwd(const float* s, long ld, void* p, long ldp, long rows, int Nq, int Nk, float scale, int causal,
+                     int q_pos0, int dtype, void* stream);
+int haff_softmax_bwd(const void* p, long ldp, const float* dp, long ld, void* ds, long rows, int Nk, float scale, int dtype,
+                     void* stream);
+/* rotate-half RoPE on x [rows][H][d], position pos0 + row % Tlen; adjoint != 0 applies the transpose rotation */
+int haff_rope(const void* x, long ldx, void* y, long ldy, const float* cos_sin, long rows, int Tlen, int H, int d, int pos0,
+              int adjoint, int dtype, void* stream);
+/* fused shift-free cross entropy: row_loss[r] = lse(logits[r]) - logits[r][labels[r]] (0 when labels[r] < 0);
+ * dlogits (may be null) = (softmax - onehot) * gscale on valid rows (llava_llama.py:108-118 after the caller's shift) */
+int haff_cross_entropy(const void* logits, long ld, const long* labels, float* row_loss, void* dlogits, long rows, int V,
+                       float gscale, int dtype, void* stream);
+/* per-sample mask losses (LISA.py:16-59) on f32 logits scaled by wgt: stats[s] = {bce_sum, sum(p*t), sum(p), sum(t)}
+ * (zeroed by caller); grad: dx = wgt*(c_bce*(p-t)/n + c_dice*d dice/dz) */
+int haff_mask_loss_stats(const float* x, const float* t, float* stats, int n_samples, long n, float wgt, void* stream);
+int haff_mask_loss_grad(const float* x, const float* t, const float* stats, float* dx, int n_samples, long n, float wgt,
+                        float c_bce, float c_dice, void* stream);
+/* taxonomy loss (LISA.py:414-417): CrossEntropyLoss on the already soft-maxed probabilities p = softmax(z) with a soft
+ * target t: loss[r] = -sum_c t_c log_softmax(p)_c; probs / dz may be null; C <= 8 */
+int haff_taxonomy_ce(const float* z, const float* t, float* probs, float* loss, float* dz, int rows, int C, void* stream);
+/* adjoint of haff_resize_bilinear (din zeroed by caller) */
+int haff_resize_bilinear_bwd(const float* dout, float* din, int N, int Hs, int Ws, int Hc, int Wc, int Ho, int Wo,
+                             void* stream);
+/* embedding gradient dE[ids[r]] += dx[r] (f32 accumulator; ids < 0 skipped) */
+int haff_scatter_add_rows(const long* ids, const void* dx, float* dE, long rows, int C, int dtype, void* stream);
+/* out += sum(g^2) (gradient-norm clipping, train_ds.py:370) */
+int haff_sumsq(const void* g, float* out, long n, int dtype, void* stream);
+/* fused AdamW on fp32 master weights (+ optional bf16 copy), torch semantics, gradient pre-scaled by gscale */
+int haff_adamw_step(float* master, float* m, float* v, const void* g, void* param_lp, long n, float lr, float beta1,
+                    float beta2, float eps, float wd, int step, float gscale, int g_dtype, int lp_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

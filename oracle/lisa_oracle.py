@@ -429,3 +429,109 @@ def mask_iou(a, b):
     inter = (a & b).sum().item()
     union = (a | b).sum().item()
     return inter / union if union > 0 else 0.0
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Training forward + losses: LISAForCausalLM.model_forward (model/LISA.py:175-430), trainable set of
+# train_ds.py:192-244 (LoRA r/alpha on q_proj,v_proj + embed_tokens, lm_head, text_hidden_fcs, both mask decoders)
+# ----------------------------------------------------------------------------------------------------------
+def dice_loss(inputs, targets, num_masks, scale=1000, eps=1e-6):
+    """LISA.py:16-39."""
+    inputs = inputs.sigmoid().flatten(1, 2)
+    targets = targets.flatten(1, 2)
+    numerator = 2 * (inputs / scale * targets).sum(-1)
+    denominator = (inputs / scale).sum(-1) + (targets / scale).sum(-1)
+    loss = 1 - (numerator + eps) / (denominator + eps)
+    return loss.sum() / (num_masks + 1e-8)
+
+
+def sigmoid_ce_loss(inputs, targets, num_masks):
+    """LISA.py:42-59."""
+    loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    return loss.flatten(1, 2).mean(1).sum() / (num_masks + 1e-8)
+
+
+def with_lora(sd, lora, cfg, alpha=16.0):
+    """Effective q/v weights W + (alpha/r) B A (peft LoRA, train_ds.py:217-231; dropout omitted = eval / p=0)."""
+    if not lora:
+        return sd
+    out = dict(sd)
+    for i in range(cfg.llm.layers):
+        for n in ("q_proj", "v_proj"):
+            k = f"model.layers.{i}.self_attn.{n}"
+            A, B = lora[k + ".lora_A"], lora[k + ".lora_B"]
+            out[k + ".weight"] = sd[k + ".weight"] + (alpha / A.shape[0]) * (B @ A)
+    return out
+
+
+def lisa_model_forward(sd, cfg, batch, lora=None, lora_alpha=16.0, ce_loss_weight=1.0, dice_loss_weight=0.5,
+                       bce_loss_weight=2.0):
+    """model_forward (LISA.py:175-430). `batch` has the keys of collate_fn (utils/dataset.py:152-169)."""
+    sdw = with_lora(sd, lora, cfg, lora_alpha)
+    images, images_clip = batch["images"], batch["images_clip"]
+    input_ids, labels, offset = batch["input_ids"], batch["labels"], batch["offset"]
+    inference = batch.get("inference", False)
+    V = "model.visual_model"
+    with torch.no_grad():
+        emb = torch.cat([sam_image_encoder(sd, V + ".image_encoder", images[i: i + 1], cfg.sam) for i in range(images.shape[0])], 0)
+    bsz = emb.shape[0]
+    assert bsz == len(offset) - 1
+    m = input_ids[:, 1:] == cfg.seg_token_idx
+    m = torch.cat([m, torch.zeros((m.shape[0], 1), dtype=torch.bool)], dim=1)
+    m = torch.cat([torch.zeros((m.shape[0], N_IMG_PAD), dtype=torch.bool), m], dim=1)
+    # images_clip expanded per conversation (LISA.py:235-245)
+    clip_rep = torch.cat([images_clip[i: i + 1].expand(int(offset[i + 1] - offset[i]), -1, -1, -1) for i in range(bsz)], 0)
+    with torch.no_grad():
+        img = encode_images(sd, cfg, clip_rep)  # vision tower + projector are frozen (train_ds.py:183-186)
+    x = splice_embeddings(sdw, input_ids, img)
+    hidden = llama_forward(sdw, x, cfg.llm)
+    logits = F.linear(hidden, sdw["lm_head.weight"])
+    # labels get IGNORE_INDEX over the spliced image span (llava_arch.py:195-205)
+    lab = []
+    for b in range(input_ids.shape[0]):
+        p = int(torch.where(input_ids[b] == IMAGE_TOKEN_INDEX)[0][0])
+        lab.append(torch.cat([labels[b, :p], torch.full((N_IMG_PAD + 1,), -100, dtype=labels.dtype), labels[b, p + 1:]]))
+    lab = torch.stack(lab)
+    ce = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), lab[:, 1:].reshape(-1), ignore_index=-100)
+    last = text_hidden_fcs(sdw, hidden)
+    pred = last[m]
+    counts = m.int().sum(-1)
+    seg_off = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(-1)], 0)[offset]
+    pred_embeddings = [pred[seg_off[i]: seg_off[i + 1]] for i in range(len(seg_off) - 1)]
+    grid = (cfg.sam.grid, cfg.sam.grid)
+    pe = sam_dense_pe(sd, V + ".prompt_encoder", grid)
+    pl, pr, pt = [], [], []
+    for i in range(bsz):
+        sparse, dense = sam_prompt_encoder_text(sdw, V + ".prompt_encoder", pred_embeddings[i].unsqueeze(1), grid)
+        lo_l, _, t = sam_mask_decoder(sdw, V + ".mask_decoder_left", emb[i: i + 1], pe, sparse, dense, True)
+        pt.append(t)
+        pl.append(sam_postprocess_masks(lo_l, cfg.sam.img_size, batch["resize_list"][i], batch["label_list"][i]["left"].shape)[:, 0])
+        lo_r, _ = sam_mask_decoder(sdw, V + ".mask_decoder_right", emb[i: i + 1], pe, sparse, dense, False)
+        pr.append(sam_postprocess_masks(lo_r, cfg.sam.img_size, batch["resize_list"][i], batch["label_list"][i]["right"].shape)[:, 0])
+    gt_l = torch.stack(batch["masks_list_left"], 0)
+    gt_r = torch.stack(batch["masks_list_right"], 0)
+    pl, pr, pt = torch.stack(pl, 0), torch.stack(pr, 0), torch.stack(pt)
+    gt_tax = batch["taxonomies_list"]
+    if inference:
+        return {"pred_masks_left": pl, "pred_masks_right": pr, "pred_taxonomies": pt, "gt_masks_left": gt_l,
+                "gt_masks_right": gt_r, "gt_taxonomies": gt_tax}
+    w_left, w_right, w_both = gt_tax[:, 0], gt_tax[:, 1], gt_tax[:, 2] + gt_tax[:, 3]
+    pl = (w_left.view(-1, 1, 1, 1) + w_both.view(-1, 1, 1, 1)) * pl
+    pr = (w_right.view(-1, 1, 1, 1) + w_both.view(-1, 1, 1, 1)) * pr
+    bce_l = bce_r = dice_l = dice_r = tax_ce = 0
+    num_masks = 0
+    for i in range(len(pl)):
+        n = gt_l[i].shape[0]
+        bce_l = bce_l + sigmoid_ce_loss(pl[i], gt_l[i], n) * n
+        dice_l = dice_l + dice_loss(pl[i], gt_l[i], n) * n
+        bce_r = bce_r + sigmoid_ce_loss(pr[i], gt_r[i], n) * n
+        dice_r = dice_r + dice_loss(pr[i], gt_r[i], n) * n
+        num_masks += n
+        tax_ce = tax_ce + F.cross_entropy(pt[i], gt_tax[i].unsqueeze(0).float())
+    tax_ce = tax_ce / len(pl)
+    mask_bce = bce_loss_weight * bce_l / (num_masks + 1e-8) + bce_loss_weight * bce_r / (num_masks + 1e-8)
+    mask_dice = dice_loss_weight * dice_l / (num_masks + 1e-8) + dice_loss_weight * dice_r / (num_masks + 1e-8)
+    ce = ce * ce_loss_weight
+    mask_loss = mask_bce + mask_dice
+    return {"loss": ce + mask_loss + tax_ce, "ce_loss": ce, "taxonomy_ce_loss": tax_ce, "mask_bce_loss": mask_bce,
+            "mask_dice_loss": mask_dice, "mask_loss": mask_loss}

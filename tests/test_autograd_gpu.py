@@ -1,0 +1,245 @@
+"""Backward kernels of the fine-tune path: each autograd.Function (HIP forward + HIP backward through the C-ABI)
+against torch autograd on a plain fp32 PyTorch reference of the same op. fp32 mode ~1e-5, bf16 mode ~2e-2 of scale."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _ag():
+    import haff  # noqa: F401
+    from haff import autograd as A
+    return A
+
+
+def _rand(shape, dev, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def _tol(dtype):
+    return 3e-5 if dtype == torch.float32 else 3e-2
+
+
+def _close(got, ref, tol, what):
+    got, ref = got.float(), ref.float()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: err {err:.3g} scale {scale:.3g}"
+
+
+def _leaf(t):
+    return t.clone().requires_grad_(True)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (37, 43, 72), (5, 8, 256)])
+def test_linear_fn(dev, dtype, M, N, K):
+    A = _ag()
+    x, w = _leaf(_rand((M, K), dev, dtype, 1)), _leaf(_rand((N, K), dev, dtype, 2, K ** -0.5))
+    b = _leaf(_rand((N,), dev, torch.float32, 3))
+    r = _leaf(_rand((M, N), dev, dtype, 4))
+    gy = _rand((M, N), dev, dtype, 5)
+    y = A.linear(x, w, b, r)
+    y.backward(gy)
+    xr, wr, br, rr = (_leaf(t.detach().float()) for t in (x, w, b, r))
+    yr = F.linear(xr, wr, br) + rr
+    yr.backward(gy.float())
+    tol = _tol(dtype)
+    _close(y, yr, tol, "y")
+    _close(x.grad, xr.grad, tol, "dx")
+    _close(w.grad, wr.grad, tol, "dw")
+    _close(b.grad, br.grad, tol, "db")
+    _close(r.grad, rr.grad, tol, "dres")
+    # frozen weight with a resident transposed copy
+    x2 = _leaf(x.detach())
+    wt = A.transpose(w.detach(), Rp=(N + 7) // 8 * 8)[0]
+    A.linear(x2, w.detach(), None, None, wt).backward(gy)
+    x3 = _leaf(x.detach().float())
+    F.linear(x3, w.detach().float()).backward(gy.float())
+    _close(x2.grad, x3.grad, tol, "dx frozen")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_act_swiglu_norms(dev, dtype):
+    A = _ag()
+    tol = _tol(dtype)
+    x = _rand((70, 96), dev, dtype, 10)
+    gy = _rand((70, 96), dev, dtype, 11)
+    for code, ref in ((1, F.gelu), (3, F.relu), (4, F.silu)):
+        a = _leaf(x)
+        A.act(a, code).backward(gy)
+        b = _leaf(x.float())
+        ref(b).backward(gy.float())
+        _close(a.grad, b.grad, tol, f"act {code}")
+    Fh = 48
+    gu = _leaf(_rand((70, 2 * Fh), dev, dtype, 12))
+    gy2 = _rand((70, Fh), dev, dtype, 13)
+    y = A.swiglu(gu)
+    y.backward(gy2)
+    gr = _leaf(gu.detach().float())
+    g3 = gr.view(70, Fh // 16, 2, 16)
+    yr = (F.silu(g3[:, :, 0]) * g3[:, :, 1]).reshape(70, Fh)
+    yr.backward(gy2.float())
+    _close(y, yr, tol, "swiglu")
+    _close(gu.grad, gr.grad, tol, "swiglu grad")
+    C = 256
+    x = _rand((33, C), dev, dtype, 14, 2.0) + 0.5
+    w, b = _leaf(_rand((C,), dev, torch.float32, 15) + 1.0), _leaf(_rand((C,), dev, torch.float32, 16))
+    gy = _rand((33, C), dev, dtype, 17)
+    a = _leaf(x)
+    A.layernorm(a, w, b, 1e-5).backward(gy)
+    ar, wr, br = _leaf(x.float()), _leaf(w.detach()), _leaf(b.detach())
+    F.layer_norm(ar, (C,), wr, br, 1e-5).backward(gy.float())
+    _close(a.grad, ar.grad, tol, "ln dx")
+    _close(w.grad, wr.grad, tol, "ln dw")
+    _close(b.grad, br.grad, tol, "ln db")
+    a = _leaf(x)
+    A.rmsnorm(a, w.detach(), 1e-5).backward(gy)
+    ar = _leaf(x.float())
+    (ar * torch.rsqrt(ar.pow(2).mean(-1, keepdim=True) + 1e-5) * w.detach()).backward(gy.float())
+    _close(a.grad, ar.grad, tol, "rms dx")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Nq,Nk,d,causal", [(2, 4, 37, 37, 32, True), (2, 8, 6, 200, 16, False), (1, 8, 130, 6, 16, False),
+                                                (2, 2, 50, 50, 128, True)])
+def test_attention_fn(dev, dtype, B, H, Nq, Nk, d, causal):
+    A = _ag()
+    tol = _tol(dtype)
+    q, k, v = (_leaf(_rand((B, n, H * d), dev, dtype, s)) for n, s in ((Nq, 20), (Nk, 21), (Nk, 22)))
+    go = _rand((B, Nq, H * d), dev, dtype, 23)
+    scale = d ** -0.5
+    o = A.attention(q, k, v, H, scale, causal)
+    o.backward(go)
+    qr, kr, vr = (_leaf(t.detach().float()) for t in (q, k, v))
+    q4, k4, v4 = (t.view(B, -1, H, d).permute(0, 2, 1, 3) for t in (qr, kr, vr))
+    s = (q4 @ k4.transpose(-1, -2)) * scale
+    if causal:
+        m = torch.arange(Nk, device=dev)[None, :] > torch.arange(Nq, device=dev)[:, None] + (Nk - Nq)
+        s = s.masked_fill(m, float("-inf"))
+    orf = (torch.softmax(s, -1) @ v4).permute(0, 2, 1, 3).reshape(B, Nq, H * d)
+    orf.backward(go.float())
+    _close(o, orf, tol, "attn out")
+    _close(q.grad, qr.grad, tol, "dq")
+    _close(k.grad, kr.grad, tol, "dk")
+    _close(v.grad, vr.grad, tol, "dv")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_rope_bmm_embed_ce(dev, dtype):
+    A = _ag()
+    tol = _tol(dtype)
+    B, T, H, d = 2, 9, 3, 32
+    x = _leaf(_rand((B * T, H * d), dev, dtype, 30))
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, device=dev).float() / d))
+    ang = torch.arange(T, device=dev).float()[:, None] * inv[None, :]
+    cs = torch.cat([ang.cos(), ang.sin()], 1).contiguous()
+    gy = _rand((B * T, H * d), dev, dtype, 31)
+    y = A.rope(x, cs, T, H, d)
+    y.backward(gy)
+    xr = _leaf(x.detach().float())
+    x4 = xr.view(B, T, H, d)
+    cos = torch.cat([ang.cos(), ang.cos()], 1).view(1, T, 1, d)
+    sin = torch.cat([ang.sin(), ang.sin()], 1).view(1, T, 1, d)
+    yr = (x4 * cos + torch.cat([-x4[..., d // 2:], x4[..., :d // 2]], -1) * sin).reshape(B * T, H * d)
+    yr.backward(gy.float())
+    _close(y, yr, tol, "rope")
+    _close(x.grad, xr.grad, tol, "rope grad")
+    # batched NT product (hypernetwork x upscaled embedding)
+    a, b = _leaf(_rand((3, 1, 32), dev, dtype, 32)), _leaf(_rand((3, 100, 32), dev, dtype, 33))
+    gc = _rand((3, 1, 100), dev, dtype, 34)
+    c = A.bmm_nt(a, b)
+    c.backward(gc)
+    ar, br = _leaf(a.detach().float()), _leaf(b.detach().float())
+    cr = ar @ br.transpose(1, 2)
+    cr.backward(gc.float())
+    _close(c, cr, tol, "bmm")
+    _close(a.grad, ar.grad, tol, "bmm da")
+    _close(b.grad, br.grad, tol, "bmm db")
+    # embedding
+    Wt = _leaf(_rand((50, 64), dev, dtype, 35))
+    ids = torch.tensor([[1, 5, 5, -200, 7], [0, 49, 3, 3, 3]], device=dev)
+    ge = _rand((2, 5, 64), dev, dtype, 36)
+    A.embed(Wt, ids).backward(ge)
+    Wr = _leaf(Wt.detach().float())
+    mask = (ids >= 0)
+    (F.embedding(ids.clamp(min=0), Wr) * mask[..., None]).backward(ge.float())
+    _close(Wt.grad, Wr.grad, tol, "embed grad")
+    # cross entropy with ignore_index
+    lg = _leaf(_rand((40, 323), dev, dtype, 37, 2.0))
+    lab = torch.randint(0, 323, (40,), device=dev)
+    lab[::3] = -100
+    loss = A.cross_entropy(lg, lab)
+    loss.backward()
+    lr = _leaf(lg.detach().float())
+    lossr = F.cross_entropy(lr, lab, ignore_index=-100)
+    lossr.backward()
+    _close(loss, lossr, 1e-5 if dtype == torch.float32 else 1e-2, "ce")
+    _close(lg.grad, lr.grad, tol, "ce grad")
+
+
+def test_losses_and_bilinear(dev):
+    A = _ag()
+    n, hw = 2, 3000
+    x = _leaf(_rand((n, hw), dev, torch.float32, 40, 2.0))
+    t = (torch.rand((n, hw), device=dev) > 0.6).float()
+    w = [1.0, 0.0]
+    out = A.mask_losses(x, t, w)
+    coef = torch.tensor([[2.0, 0.5], [2.0, 0.5]], device=dev)
+    (out * coef).sum().backward()
+    xr = _leaf(x.detach())
+    tot = 0
+    for i in range(n):
+        z = (w[i] * xr[i]).view(1, 1, hw)
+        bce = F.binary_cross_entropy_with_logits(z, t[i].view(1, 1, hw), reduction="none").flatten(1, 2).mean(1).sum()
+        p = z.sigmoid().flatten(1, 2)
+        tt = t[i].view(1, hw)
+        dice = (1 - (2 * (p / 1000 * tt).sum(-1) + 1e-6) / ((p / 1000).sum(-1) + (tt / 1000).sum(-1) + 1e-6)).sum()
+        _close(out[i, 0], bce, 1e-5, "bce")
+        _close(out[i, 1], dice, 1e-5, "dice")
+        tot = tot + 2.0 * bce + 0.5 * dice
+    tot.backward()
+    _close(x.grad, xr.grad, 1e-4, "mask loss grad")
+    # taxonomy CE on already soft-maxed probabilities
+    z = _leaf(_rand((3, 4), dev, torch.float32, 41))
+    tgt = torch.tensor([[1., 0, 0, 0], [0, 0, 1., 0], [0, 1., 0, 0]], device=dev)
+    loss, probs = A.taxonomy_ce(z, tgt)
+    loss.sum().backward()
+    zr = _leaf(z.detach())
+    pr = torch.softmax(zr, -1)
+    lr = torch.stack([F.cross_entropy(pr[i:i + 1], tgt[i:i + 1]) for i in range(3)])
+    lr.sum().backward()
+    _close(loss, lr, 1e-5, "tax ce")
+    _close(probs, pr, 1e-6, "tax probs")
+    _close(z.grad, zr.grad, 1e-5, "tax grad")
+    # bilinear adjoint
+    m = _leaf(_rand((2, 56, 56), dev, torch.float32, 42))
+    g = _rand((2, 120, 90), dev, torch.float32, 43)
+    up = A.resize_bilinear(m, (56, 56), (224, 224))
+    A.resize_bilinear(up, (224, 168), (120, 90)).backward(g)
+    mr = _leaf(m.detach())
+    u = F.interpolate(mr[:, None], (224, 224), mode="bilinear", align_corners=False)
+    F.interpolate(u[..., :224, :168], (120, 90), mode="bilinear", align_corners=False)[:, 0].backward(g)
+    _close(m.grad, mr.grad, 1e-5, "bilinear grad")
+
+
+def test_adamw_matches_torch(dev):
+    import haff  # noqa: F401
+    from haff import train_ops as T
+    p = _rand((1000,), dev, torch.float32, 50)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
+    state = T.AdamWState(p.clone())
+    for step in range(1, 4):
+        g = _rand((1000,), dev, torch.float32, 60 + step)
+        ref.grad = g.clone()
+        opt.step()
+        T.adamw_step(state, g, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, wd=0.0, gscale=1.0)
+    _close(state.master, ref.detach(), 1e-6, "adamw")
+    assert abs(T.grad_norm([g, g]).item() - math.sqrt(2) * g.norm().item()) < 1e-2
