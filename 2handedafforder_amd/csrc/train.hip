@@ -89,6 +89,12 @@ __global__ void axpby_kernel(const T* a, const T* b, T* out, long n, float alpha
     elem<T>::st(out + i, alpha * elem<T>::ld(a + i) + (b ? beta * elem<T>::ld(b + i) : 0.f));
 }
 
+template <typename T>
+__global__ void mul_kernel(const T* a, const T* b, T* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    elem<T>::st(out + i, elem<T>::ld(a + i) * elem<T>::ld(b + i));
+}
+
 // ---- norm adjoints: one wave per row ---------------------------------------------------------------------------
 // LayerNorm: xhat = (x-mean)*rstd, g = dy*w ; dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dyx = dy*xhat (f32, for dw)
 // RMSNorm  : xhat = x*rstd ;            dx = rstd*(g - xhat*mean(g*xhat))
@@ -403,6 +409,14 @@ extern "C" int haff_axpby(const void* a, const void* b, void* out, long n, float
   dim3 g(grid_for(n, 256)), blk(256);
   DISPATCH_T(dtype, hipLaunchKernelGGL((axpby_kernel<bf16_t>), g, blk, 0, HS(stream), (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, alpha, beta),
              hipLaunchKernelGGL((axpby_kernel<float>), g, blk, 0, HS(stream), (const float*)a, (const float*)b, (float*)out, n, alpha, beta));
+  return haff_check_launch();
+}
+// out = a * b elementwise (LoRA dropout mask, peft lora_dropout, train_ds.py:224)
+extern "C" int haff_mul(const void* a, const void* b, void* out, long n, int dtype, void* stream) {
+  if (n <= 0) return HAFF_ERR_BAD_ARG;
+  dim3 g(grid_for(n, 256)), blk(256);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((mul_kernel<bf16_t>), g, blk, 0, HS(stream), (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n),
+             hipLaunchKernelGGL((mul_kernel<float>), g, blk, 0, HS(stream), (const float*)a, (const float*)b, (float*)out, n));
   return haff_check_launch();
 }
 // rms != 0: RMSNorm adjoint (dx only). dyx (f32 [rows][C], may be null) receives dy*xhat for the weight gradient.

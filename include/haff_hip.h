@@ -138,6 +138,8 @@ int haff_swiglu_fwd(const void* gu, void* y, long M, int F, int dtype, void* str
 int haff_swiglu_bwd(const void* gu, const void* dy, void* dgu, long M, int F, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be null) */
 int haff_axpby(const void* a, const void* b, void* out, long n, float alpha, float beta, int dtype, void* stream);
+/* out = a * b elementwise (LoRA dropout mask) */
+int haff_mul(const void* a, const void* b, void* out, long n, int dtype, void* stream);
 /* LayerNorm (rms=0) / RMSNorm (rms=1) adjoint: dx; dyx (f32 [rows][C], may be null) = dy*xhat for the weight grad */
 int haff_norm_bwd(const void* x, const void* dy, const float* w, void* dx, float* dyx, int rows, int C, float eps, int rms,
                   int dtype, void* stream);

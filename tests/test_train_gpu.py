@@ -1,0 +1,122 @@
+"""Fine-tune path parity: LisaTrainable.forward(**batch) (HIP forward + HIP backward) against the CPU oracle's
+model_forward restatement under torch autograd — same seeded weights, LoRA adapters and collate_fn-shaped batch.
+fp32 mode: losses within 1e-4, gradients of every trainable tensor within 2e-3 of their max; bf16: looser."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_batch(cfg, b=2, L=14, seed=0, hw=(100, 90)):
+    rng = np.random.default_rng(seed)
+    S = cfg.sam.img_size
+    ids = torch.from_numpy(rng.integers(3, 300, size=(b, L))).long()
+    ids[:, 0], ids[:, 1], ids[:, 2], ids[:, 3] = cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx
+    ids[:, 10], ids[:, 12] = cfg.seg_token_idx, cfg.eos_token_id
+    labels = ids.clone()
+    labels[:, :8] = -100
+    g = torch.Generator().manual_seed(seed)
+    return dict(
+        images=torch.randn((b, 3, S, S), generator=g), images_clip=torch.randn((b, 3, 224, 224), generator=g),
+        input_ids=ids, labels=labels, attention_masks=torch.ones_like(ids, dtype=torch.bool), offset=torch.arange(b + 1),
+        masks_list_left=[(torch.rand((1,) + hw, generator=g) > 0.5).float() for _ in range(b)],
+        masks_list_right=[(torch.rand((1,) + hw, generator=g) > 0.5).float() for _ in range(b)],
+        label_list=[{"left": torch.zeros(hw), "right": torch.zeros(hw)} for _ in range(b)],
+        resize_list=[(S, S - 24)] * b, taxonomies_list=torch.tensor([[1., 0, 0, 0], [0, 0, 1., 0]])[:b], inference=False)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_model_forward_loss_and_grads_match_oracle(dev, mode):
+    import haff  # noqa: F401
+    from haff import config as hcfg, weights as hw
+    from haff.train_model import LisaTrainable
+    from oracle import lisa_oracle as O
+    cfg = hcfg.tiny()
+    sd = hw.make_state_dict(cfg, 21)
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    batch = make_batch(cfg)
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)
+        batch["images"] = batch["images"].to(torch.bfloat16).float()
+        batch["images_clip"] = batch["images_clip"].to(torch.bfloat16).float()
+    model = LisaTrainable(cfg, sd, dtype=dtype, device=dev, lora_dropout=0.0, lora_init_b_zero=False, seed=3)
+    # oracle side: same trainable tensors as fp32 leaves
+    osd = {k: v.clone() for k, v in sd.items()}
+    lora = {}
+    for k, p in model.named_parameters():
+        t = p.detach().float().cpu().clone().requires_grad_(True)
+        if "lora_" in k:
+            lora[k] = t
+        else:
+            osd[k] = t
+    ref = O.lisa_model_forward(osd, cfg, batch, lora=lora)
+    ref["loss"].backward()
+    dev_batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = model(**dev_batch)
+    out["loss"].backward()
+    ltol = 1e-4 if mode == "f32" else 3e-2
+    for k in ref:
+        a, b = float(out[k]), float(ref[k])
+        print(f"{mode} {k}: hip {a:.6f} oracle {b:.6f}")
+        assert abs(a - b) <= ltol * max(1.0, abs(b)), k
+    gtol = 2e-3 if mode == "f32" else 0.25  # bf16: per-tensor relative L2; plus a global cosine check below
+    flat_g, flat_r = [], []
+    worst = ("", 0.0)
+    n_checked = 0
+    for k, p in model.named_parameters():
+        r = (lora[k] if "lora_" in k else osd[k]).grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k  # iou_prediction_head: unused by the loss
+            continue
+        scale = r.abs().max().item()
+        if p.grad is None:  # hypernetworks 1-3: computed by the reference, multiplied out by masks[:, 0:1] (zero grad)
+            assert scale == 0.0, k
+            continue
+        err = (p.grad.float().cpu() - r).abs().max().item()
+        if scale < 1e-6:  # analytically zero gradients (k_proj.bias: softmax is shift-invariant) are float noise
+            assert err < (1e-6 if mode == "f32" else 1e-3), k
+            continue
+        rel = err / (scale + 1e-12)
+        if mode == "bf16":  # bf16 gradients: judge the tensor as a whole (relative L2), not its worst element
+            rel = ((p.grad.float().cpu() - r).norm() / (r.norm() + 1e-12)).item()
+        if rel > worst[1]:
+            worst = (k, rel)
+        n_checked += 1
+        flat_g.append(p.grad.float().cpu().reshape(-1))
+        flat_r.append(r.reshape(-1))
+        assert scale == 0 or rel <= gtol, f"{k}: grad rel err {rel:.3g} (scale {scale:.3g})"
+    print(f"{mode}: {n_checked} gradient tensors checked, worst {worst}")
+    assert n_checked > 150
+    cos = torch.nn.functional.cosine_similarity(torch.cat(flat_g), torch.cat(flat_r), dim=0).item()
+    print(f"{mode}: global gradient cosine {cos:.6f}")
+    assert cos >= (0.99999 if mode == "f32" else 0.995)
+
+
+def test_validation_forward_and_train_step_reduces_loss(dev):
+    import haff  # noqa: F401
+    from haff import config as hcfg, weights as hw
+    from haff import train_ops as T
+    from haff.train_model import LisaTrainable
+    cfg = hcfg.tiny()
+    sd = hw.make_state_dict(cfg, 22)
+    model = LisaTrainable(cfg, sd, dtype=torch.bfloat16, device=dev, lora_dropout=0.05)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(cfg, seed=1).items()}
+    val = model.eval()(**{**batch, "inference": True})
+    assert val["pred_masks_left"].shape == (2, 1, 100, 90) and val["pred_taxonomies"].shape == (2, 1, 4)
+    model.train()
+    states = {k: T.AdamWState(p) for k, p in model.named_parameters()}
+    losses = []
+    for step in range(6):
+        model.zero_grad()
+        out = model(**batch)
+        out["loss"].backward()
+        losses.append(float(out["loss"]))
+        grads = [p.grad for _, p in model.named_parameters() if p.grad is not None]
+        norm = float(T.grad_norm(grads))
+        clip = min(1.0, 1.0 / (norm + 1e-6))
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                T.adamw_step(states[k], p.grad, lr=3e-4, gscale=clip, param_lp=p.data)
+    print("losses", [round(v, 4) for v in losses])
+    assert losses[-1] < losses[0]
