@@ -120,3 +120,20 @@ def test_validation_forward_and_train_step_reduces_loss(dev):
                 T.adamw_step(states[k], p.grad, lr=3e-4, gscale=clip, param_lp=p.data)
     print("losses", [round(v, 4) for v in losses])
     assert losses[-1] < losses[0]
+
+
+def test_train_ds_cli_runs_logs_checkpoints_and_resumes(dev, tmp_path, capsys):
+    import haff  # noqa: F401
+    from haff import train_ds
+    argv = ["--synthetic", "tiny", "--epochs", "1", "--steps_per_epoch", "2", "--grad_accumulation_steps", "2",
+            "--batch_size", "2", "--log_base_dir", str(tmp_path), "--exp_name", "t", "--mask_hw", "64", "48",
+            "--val_samples", "2", "--lr", "0.0003"]
+    train_ds.main(argv)
+    out = capsys.readouterr().out
+    assert "Epoch: [0][1/2]" in out and "Loss" in out and "MaskDICELoss" in out and "IoU:" in out
+    assert "saved checkpoint" in out
+    import os
+    assert os.path.exists(tmp_path / "t" / "ckpt_model" / "latest.pt")
+    train_ds.main(argv[:3] + ["2"] + argv[4:])  # epochs=2 -> resumes at epoch 1
+    out = capsys.readouterr().out
+    assert "resume training from" in out and "start from epoch 1" in out and "Epoch: [1][1/2]" in out
