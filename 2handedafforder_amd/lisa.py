@@ -31,6 +31,8 @@ class LisaMI355:
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.seg_token_idx = cfg.seg_token_idx
         self.sam_chunk = sam_chunk
+        self._sam_stream = torch.cuda.Stream(device=self.device)
+        self.overlap_streams = True  # False serialises everything on the caller's stream (per-kernel measurements)
         sd, dev = state_dict, self.device
         assert cfg.clip.n_patches == N_IMG_PAD + 1, "the reference hard-codes 256 image tokens (LISA.py:461)"
         self.sam_encoder = SamEncoderHip(sd, cfg.sam, dtype, dev)
@@ -116,13 +118,22 @@ class LisaMI355:
     @torch.no_grad()
     def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, max_new_tokens=32,
                  tokenizer=None, forced_answer=None, frames_u8=None):
+        # The SAM encoder (MFMA-bound, ~60 % of the FLOPs) does not depend on the language model: it runs on its own
+        # HIP stream so its big GEMMs fill the CUs while the HBM/latency-bound greedy decode steps of the LLM trickle
+        # through on the caller's stream. Joined before the mask decoders.
+        cur = torch.cuda.current_stream(self.device)
+        side = self._sam_stream if self.overlap_streams else cur
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if frames_u8 is not None:
+                from .preprocess import SAM_MEAN, SAM_STD
+                emb = self.get_visual_embs_u8(frames_u8.to(self.device), SAM_MEAN, SAM_STD)
+            else:
+                emb = self.get_visual_embs(images)
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer)
         pred, frame_idx, counts = self.seg_embeddings(output_ids, hidden)
-        if frames_u8 is not None:
-            from .preprocess import SAM_MEAN, SAM_STD
-            emb = self.get_visual_embs_u8(frames_u8.to(self.device), SAM_MEAN, SAM_STD)
-        else:
-            emb = self.get_visual_embs(images)
+        cur.wait_stream(side)
+        emb.record_stream(cur)
         B = output_ids.shape[0]
         pred_masks_left, pred_masks_right, taxonomies = [], [], []
         if pred.shape[0] > 0:

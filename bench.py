@@ -209,8 +209,10 @@ def main():
 
     if rank == 0:
         flops_frame = SURVEY_FLOPS.get(cfg.name) or hflops.frame_flops(cfg, args.text_tokens, args.n_gen)["total"]
+        model.overlap_streams = False  # per-launch event timing needs the two HIP streams serialised
         with GemmMeter() as meter:
             step()
+        model.overlap_streams = True
         n_launch, gemm_ms, gemm_fl = meter.summary()
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         roofline = {
