@@ -19,6 +19,8 @@
 // (bf16) / 16-byte (f32) vectors and SwiGLU pairs (gate, up) land in the same lane.
 // Workgroup ids are remapped XCD-aware (ids that share an XCD get neighbouring tiles) and grouped 8 M-tiles
 // deep so the 4 MiB per-XCD L2 holds the A and W panels the concurrently running tiles share.
+#include <type_traits>
+
 #include "haff_common.h"
 
 namespace {
@@ -45,21 +47,31 @@ struct GemmArgs {
 // Epilogue activations of the throughput (bf16) path. GELU uses the Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7,
 // far below the bf16 output rounding) instead of ocml erff: ~10 VALU ops + v_exp + v_rcp per element, which matters
 // for the K=1280 SAM MLP GEMM whose epilogue touches 5120 columns per row. The fp32 parity kernel keeps erff.
-__device__ __forceinline__ float gemm_act(float x, int act) {
-  switch (act) {
-    case HAFF_ACT_GELU: {
-      const float z = fabsf(x) * 0.70710678118654752440f;
-      const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-      const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-      const float erf_abs = 1.0f - poly * __expf(-z * z);
-      return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-    }
-    case HAFF_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
-    case HAFF_ACT_RELU: return fmaxf(x, 0.0f);
-    case HAFF_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-    default: return x;
+template <int ACT>
+__device__ __forceinline__ float gemm_act(float x) {
+  if constexpr (ACT == HAFF_ACT_GELU) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+  } else if constexpr (ACT == HAFF_ACT_QUICK_GELU) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+  } else if constexpr (ACT == HAFF_ACT_RELU) {
+    return fmaxf(x, 0.0f);
+  } else if constexpr (ACT == HAFF_ACT_SILU) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+  } else {
+    return x;
   }
 }
+
+#ifdef HAFF_GEMM_TRACE  // phase timestamps (100 MHz wall clock) of each workgroup's first tile, for tools/gemm_trace.py
+__device__ unsigned long long haff_gemm_trace_buf[8192 * 8];
+#define HAFF_TRACE(i) do { if (tid == 0 && blockIdx.x < 8192 && blockIdx.y == 0) haff_gemm_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define HAFF_TRACE(i) do {} while (0)
+#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -90,48 +102,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
                   : static_cast<void*>(reinterpret_cast<bf16_t*>(p.C) + coff);
   }
 
-  // ---- XCD-aware + grouped tile mapping (speed only; any mapping is correct) ----
+  // ---- workgroup -> output tile ----
+  // Ids are remapped XCD-aware (ids equal mod 8 share an XCD/L2) and grouped GROUP_M row-tiles deep so concurrently
+  // running tiles share A and W panels in the 4 MiB per-XCD L2.
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  int lin;
+  int m0, n0;
   {
-    const int orig = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  int tm, tn;
-  {
+    const int nwg = tiles_m * tiles_n;
+    const int t = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
     const int per_group = GROUP_M * tiles_n;
     const int g = lin / per_group;
     const int first_m = g * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
     const int in_g = lin - g * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
+    m0 = (first_m + in_g % gsz) * BM;
+    n0 = (in_g / gsz) * BN;
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+  HAFF_TRACE(0);
 
-  // ---- per-thread staging coordinates: 4 chunks of 16 B per operand per K-tile ----
-  // LDS position pos = i*256 + tid (lane-linear); row = pos>>3; logical chunk = (pos&7) ^ (row&7)
+  // ---- per-thread staging coordinates: 16-B chunks of the K-tile ----
+  // LDS position pos = i*NTHREADS + tid (lane-linear); row = pos>>3; logical chunk = (pos&7) ^ (row&7)
   const bf16_t* a_src[NA];
   const bf16_t* w_src[NW];
   int a_kcol[NA], w_kcol[NW];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int pos = i * NTHREADS + tid;
-    const int row = pos >> 3;
-    const int c = (pos & 7) ^ (row & 7);
-    a_kcol[i] = c * 8;
-    a_src[i] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + c * 8;
+    const int pos = i * NTHREADS + tid, row = pos >> 3;
+    a_kcol[i] = ((pos & 7) ^ (row & 7)) * 8;
+    a_src[i] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + a_kcol[i];
   }
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
-    const int pos = i * NTHREADS + tid;
-    const int row = pos >> 3;
-    const int c = (pos & 7) ^ (row & 7);
-    w_kcol[i] = c * 8;
-    w_src[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + c * 8;
+    const int pos = i * NTHREADS + tid, row = pos >> 3;
+    w_kcol[i] = ((pos & 7) ^ (row & 7)) * 8;
+    w_src[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + w_kcol[i];
   }
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(haff_zero_page);
 
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fh = lane >> 4;
+  const int nk = (p.K + BK - 1) / BK;
 
   f32x4 acc[TN][TM];  // [ni][mi]
 #pragma unroll
@@ -161,7 +169,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -173,11 +180,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) HAFF_TRACE(1);
 
     const bf16_t* sA = smem + cur * STAGE_ELEMS;
     const bf16_t* sW = sA + A_ELEMS;
-    // issue every fragment read of the K-tile up front (both 32-deep k-steps), consume in issue order: only the
-    // first read's latency is exposed, the compiler places counted lgkmcnt waits in front of each MFMA group
+    // issue every fragment read of the K-tile up front (both 32-deep k-steps), consume in issue order
     bf16x8 wf[2][TN], af[2][TM];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -212,125 +219,179 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);
     __builtin_amdgcn_s_barrier();
   }
+  HAFF_TRACE(2);
 
   // ---- epilogue, staged through LDS so global traffic is whole 128-B row segments ----
-  // lane holds D[n = 4*fh + reg][m = fr] of each 16x16 tile -> (+bias, act) -> fp32 LDS image [32 rows][WCOLS]
-  // per wave -> read back 8 consecutive columns per lane -> (+residual) -> 16-B stores.
+  // lane holds D[n = 4*fh + reg][m = fr] of each 16x16 tile -> (+bias, act) -> fp32 LDS image [16 rows][WCOLS],
+  // wave-private (LDS ops of one wave execute in order: no workgroup barrier inside the epilogue) -> read back
+  // 8 consecutive columns per lane -> (+residual) -> 16-B stores.
+  // Every global LOAD of the epilogue (bias, row map, residual) is issued before the stores it would otherwise
+  // queue behind: vmcnt retires in order, so a load issued after a store waits for that store's round trip.
   constexpr int WCOLS = SWIGLU ? 32 : 64;   // output columns owned by a wave
   constexpr int RS = WCOLS + 4;             // LDS row stride in floats (pad keeps b128 accesses conflict-free)
   constexpr int LPR = WCOLS / 8;            // lanes per output row on the read-back side
   constexpr int RPS = 64 / LPR;             // rows per read-back step
-  float* sEp = reinterpret_cast<float*>(smem) + wave * (32 * RS);
+  constexpr int STEPS = 16 / RPS;
+  constexpr int WROWS = BM / WM;            // output rows owned by a wave (64 or 128)
+  static_assert(WM * WN * 16 * RS * 4 <= STAGE_ELEMS * 2, "epilogue staging must fit in one LDS stage");
+  float* sEp = reinterpret_cast<float*>(smem) + wave * (16 * RS);
+  const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
   const int n_wave_in = n0 + wn * 64;                           // first (interleaved) input column of the wave
   const int n_wave_out = SWIGLU ? (n_wave_in >> 1) : n_wave_in;
-  const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
+  const int m_wave = m0 + wm * WROWS;
   const bool c_vec = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((p.ldc & 7) == 0);
   const bool r_vec = p.resid && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) && ((p.ldr & 7) == 0);
+  const bool fast = c_vec && (!p.resid || r_vec) && (n_wave_out + WCOLS <= n_total_out);
 
   float bias_r[TN][4];
+  if (p.bias && n_wave_in + 64 <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
+    for (int ni = 0; ni < TN; ++ni) load4(p.bias + n_wave_in + ni * 16 + fh * 4, bias_r[ni]);
+  } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n_wave_in + ni * 16 + fh * 4 + r;
-      bias_r[ni][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_wave_in + ni * 16 + fh * 4 + r;
+        bias_r[ni][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+      }
+  }
+  // output row of wave-row (lane) and (lane + 64): -1 = dropped. Distributed to the read-back lanes by ds_bpermute.
+  int orow_l[WROWS / 64];
+#pragma unroll
+  for (int h = 0; h < WROWS / 64; ++h) {
+    const int m = m_wave + h * 64 + lane;
+    orow_l[h] = m < p.M ? (p.row_map ? p.row_map[m] : m) : -1;
+  }
+  const int rb_r = lane / LPR, rb_c = (lane % LPR) * 8;   // read-back row within a step / first column
+  const long n_out = n_wave_out + rb_c;
+
+  // residual of pass mi, prefetched one pass ahead (bf16 output only; the rare f32-out residual loads in place)
+  constexpr bool PREFETCH_R = !OUT_F32;
+  uint4 rres[STEPS];
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) rres[st] = uint4{0u, 0u, 0u, 0u};
+  auto fetch_resid = [&](int mi) {
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int wr = mi * 16 + st * RPS + rb_r;
+      const int orow = __shfl(orow_l[(mi * 16) >> 6], wr & 63);
+      rres[st] = uint4{0u, 0u, 0u, 0u};
+      if (orow >= 0)
+        rres[st] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)orow * p.ldr + n_out);
     }
+  };
+  const bool pre_r = PREFETCH_R && fast && p.resid;
+  if (pre_r) fetch_resid(0);
 
 #pragma unroll
-  for (int pi = 0; pi < TM / 2; ++pi) {
-    __syncthreads();  // previous pass fully read back (pass 0: every wave is past its last operand read)
-#pragma unroll
-    for (int ml = 0; ml < 2; ++ml) {
-      const int mi = pi * 2 + ml;
-      float* row = sEp + (ml * 16 + fr) * RS + fh * 4;
-      if (!SWIGLU) {
+  for (int mi = 0; mi < TM; ++mi) {
+    float* row = sEp + fr * RS + fh * 4;
+    if (!SWIGLU) {
+      // the activation is resolved ONCE per pass (wave-uniform switch) so the per-element code is straight-line
+      auto write_side = [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gemm_act(acc[ni][mi][r] + bias_r[ni][r], p.act);
+          for (int r = 0; r < 4; ++r) v[r] = gemm_act<ACT>(acc[ni][mi][r] + bias_r[ni][r]);
           store4(row + ni * 16, v);
         }
-      } else {
+      };
+      switch (p.act) {
+        case HAFF_ACT_GELU: write_side(std::integral_constant<int, HAFF_ACT_GELU>{}); break;
+        case HAFF_ACT_QUICK_GELU: write_side(std::integral_constant<int, HAFF_ACT_QUICK_GELU>{}); break;
+        case HAFF_ACT_RELU: write_side(std::integral_constant<int, HAFF_ACT_RELU>{}); break;
+        case HAFF_ACT_SILU: write_side(std::integral_constant<int, HAFF_ACT_SILU>{}); break;
+        default: write_side(std::integral_constant<int, HAFF_ACT_NONE>{}); break;
+      }
+    } else {
 #pragma unroll
-        for (int nj = 0; nj < TN / 2; ++nj) {
-          float v[4];
+      for (int nj = 0; nj < TN / 2; ++nj) {
+        float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float g = acc[2 * nj][mi][r] + bias_r[2 * nj][r];
-            const float u = acc[2 * nj + 1][mi][r] + bias_r[2 * nj + 1][r];
-            v[r] = (g / (1.0f + __expf(-g))) * u;
-          }
-          store4(row + nj * 16, v);
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[2 * nj][mi][r] + bias_r[2 * nj][r];
+          const float u = acc[2 * nj + 1][mi][r] + bias_r[2 * nj + 1][r];
+          v[r] = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u;
         }
+        store4(row + nj * 16, v);
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    if (fast) {
+      // interior tile, 16-B aligned rows: straight-line read-back, 16-B (bf16) / 2x16-B (f32) stores per lane
+      uint4 rcur[STEPS];
 #pragma unroll
-    for (int st = 0; st < 32 / RPS; ++st) {
-      const int r = st * RPS + lane / LPR;
-      const int c = (lane % LPR) * 8;
-      const int m = m0 + wm * (BM / WM) + pi * 32 + r;
-      const int n = n_wave_out + c;
-      if (m >= p.M || n >= n_total_out) continue;
-      long orow = m;
-      if (p.row_map) {
-        const int mapped = p.row_map[m];
-        if (mapped < 0) continue;
-        orow = mapped;
-      }
-      float v[8];
-      load8(sEp + r * RS + c, v);
-      const bool full = n + 8 <= n_total_out;
-      if (OUT_F32) {
-        float* crow = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
-        if (p.resid) {
-          const float* rrow = reinterpret_cast<const float*>(p.resid) + orow * p.ldr + n;
+      for (int st = 0; st < STEPS; ++st) rcur[st] = rres[st];
+      if (pre_r && mi + 1 < TM) fetch_resid(mi + 1);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (full || n + j < n_total_out) v[j] += rrow[j];
-        }
-        if (full && c_vec) {
-          store8(crow, v);
-        } else {
+      for (int st = 0; st < STEPS; ++st) {
+        const int wr = mi * 16 + st * RPS + rb_r;
+        const int orow = __shfl(orow_l[(mi * 16) >> 6], wr & 63);
+        float v[8];
+        load8(sEp + (st * RPS + rb_r) * RS + rb_c, v);
+        if (orow >= 0) {
+          if (OUT_F32) {
+            if (p.resid) {
+              float rr[8];
+              load8(reinterpret_cast<const float*>(p.resid) + (long)orow * p.ldr + n_out, rr);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (n + j < n_total_out) crow[j] = v[j];
-        }
-      } else {
-        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + orow * p.ldc + n;
-        if (p.resid) {
-          const bf16_t* rrow = reinterpret_cast<const bf16_t*>(p.resid) + orow * p.ldr + n;
-          if (full && r_vec) {
-            float rr[8];
-            load8(rrow, rr);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+              for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            }
+            store8(reinterpret_cast<float*>(p.C) + (long)orow * p.ldc + n_out, v);
           } else {
+            if (p.resid) {
+              const unsigned int w[4] = {rcur[st].x, rcur[st].y, rcur[st].z, rcur[st].w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (n + j < n_total_out) v[j] += bf16_to_f32(rrow[j]);
+              for (int j = 0; j < 4; ++j) {
+                v[2 * j] += __builtin_bit_cast(float, w[j] << 16);
+                v[2 * j + 1] += __builtin_bit_cast(float, w[j] & 0xffff0000u);
+              }
+            }
+            store8(reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n_out, v);
           }
         }
-        if (full && c_vec) {
-          store8(crow, v);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (n + j < n_total_out) crow[j] = f32_to_bf16(v[j]);
+      }
+    } else {
+      // ragged N edge or unaligned rows: element-wise, kept rolled (cold)
+#pragma unroll 1
+      for (int st = 0; st < STEPS; ++st) {
+        const int wr = mi * 16 + st * RPS + rb_r;
+        const int orow = __shfl(orow_l[(mi * 16) >> 6], wr & 63);
+        if (orow < 0) continue;
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+          const long n = n_out + j;
+          if (n >= n_total_out) break;
+          float x = sEp[(st * RPS + rb_r) * RS + rb_c + j];
+          if (OUT_F32) {
+            if (p.resid) x += reinterpret_cast<const float*>(p.resid)[(long)orow * p.ldr + n];
+            reinterpret_cast<float*>(p.C)[(long)orow * p.ldc + n] = x;
+          } else {
+            if (p.resid) x += bf16_to_f32(reinterpret_cast<const bf16_t*>(p.resid)[(long)orow * p.ldr + n]);
+            reinterpret_cast<bf16_t*>(p.C)[(long)orow * p.ldc + n] = f32_to_bf16(x);
+          }
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
+  HAFF_TRACE(3);
+#ifdef HAFF_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HAFF_TRACE(4);
+#endif
 }
 
 }  // namespace
 
-
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles, nbatch), block(64 * WM * WN);
+  const int gx = tiles;
+  dim3 grid(gx, nbatch), block(64 * WM * WN);
   if (p.swiglu) {
     if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
@@ -340,6 +401,12 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   }
   return haff_check_launch();
 }
+
+#ifdef HAFF_GEMM_TRACE
+extern "C" int haff_gemm_trace_read(unsigned long long* host, int n_words) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(haff_gemm_trace_buf), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (for A/B measurements)
 extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
