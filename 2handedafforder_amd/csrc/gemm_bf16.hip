@@ -8,15 +8,20 @@
 //   Llama q/k/v/o/gate/up/down/lm_head (transformers LlamaDecoderLayer, called at llava_llama.py:93-105)
 //   mm_projector (llava_arch.py:35), text_hidden_fcs (LISA.py:95-101), SAM decoder linears (transformer.py:206-209)
 //
-// Design (gfx950): 128x128x64 tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16). Both operands are staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round
-// trip); the LDS image is lane-linear and the XOR swizzle (chunk ^= row&7) is applied on the per-lane SOURCE
-// address and again on the ds_read_b128 address, which makes the fragment reads bank-conflict free.
-// Double-buffered with a counted s_waitcnt vmcnt(8) + raw s_barrier so the next K-tile's loads stay in
-// flight across the barrier while the current tile is multiplied.
-// The MFMA is issued "swapped" (W rows as the A operand, activation rows as the B operand): each lane then
-// holds 4 CONSECUTIVE output columns of one output row, so bias/residual loads and the C stores are 8-byte
-// (bf16) / 16-byte (f32) vectors and SwiGLU pairs (gate, up) land in the same lane.
+// Design (gfx950): two tiles of one kernel template — 256x256x64 with 8 waves (2x4, 128x64 per wave; one
+// workgroup per CU, 128 KiB LDS) for anything that fills the chip with it, 128x128x64 with 4 waves (2x2, 64x64
+// per wave; two workgroups per CU) for small / ragged problems, K tails and the batched entry point. MFMA is
+// v_mfma_f32_16x16x32_bf16. Both operands are staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round trip);
+// the LDS image is lane-linear and the XOR swizzle (chunk ^= row&7) is applied on the per-lane SOURCE address and
+// again on the ds_read_b128 address, which makes the fragment reads bank-conflict free.
+// Double-buffered, ONE workgroup barrier per K-tile, and the MFMA stream is software-pipelined across that
+// barrier (see the K loop). The MFMA is issued "swapped" (W rows as the A operand, activation rows as the B
+// operand): each lane then holds 4 CONSECUTIVE output columns of one output row, so SwiGLU pairs (gate, up) land
+// in the same lane and the epilogue's LDS image is written with 16-B stores.
+// Epilogue: per 16-row pass the wave writes (+bias, activation) to a wave-private fp32 LDS image and reads it
+// back as whole 128-B row segments (+residual, row map) -> 16-B global stores. The activation is resolved once
+// per pass (wave-uniform switch, straight-line per-element code) and every global load of the epilogue is issued
+// ahead of the stores it would otherwise queue behind.
 // Workgroup ids are remapped XCD-aware (ids that share an XCD get neighbouring tiles) and grouped 8 M-tiles
 // deep so the 4 MiB per-XCD L2 holds the A and W panels the concurrently running tiles share.
 #include <type_traits>
@@ -125,35 +130,69 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 
   // ---- per-thread staging coordinates: 16-B chunks of the K-tile ----
   // LDS position pos = i*NTHREADS + tid (lane-linear); row = pos>>3; logical chunk = (pos&7) ^ (row&7)
-  const bf16_t* a_src[NA];
-  const bf16_t* w_src[NW];
-  int a_kcol[NA], w_kcol[NW];
+  // The 8-wave tile is only launched for K % 64 == 0 and operands under 4 GiB, so it keeps 32-bit offsets from a
+  // uniform base (saves 16 VGPRs for the ping-pong loop); the 4-wave tile keeps pointers and the zero-page K tail.
+  constexpr bool OFF32 = (WM * WN == 8);
+  const bf16_t* a_src[OFF32 ? 1 : NA];
+  const bf16_t* w_src[OFF32 ? 1 : NW];
+  int a_kcol[OFF32 ? 1 : NA], w_kcol[OFF32 ? 1 : NW];
+  unsigned a_off[OFF32 ? NA : 1], w_off[OFF32 ? NW : 1];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int pos = i * NTHREADS + tid, row = pos >> 3;
-    a_kcol[i] = ((pos & 7) ^ (row & 7)) * 8;
-    a_src[i] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + a_kcol[i];
+    const int kcol = ((pos & 7) ^ (row & 7)) * 8;
+    if constexpr (OFF32) {
+      a_off[i] = ((unsigned)(min(m0 + row, p.M - 1)) * (unsigned)p.lda + kcol) * 2u;  // bytes
+    } else {
+      a_kcol[i] = kcol;
+      a_src[i] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + kcol;
+    }
   }
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
     const int pos = i * NTHREADS + tid, row = pos >> 3;
-    w_kcol[i] = ((pos & 7) ^ (row & 7)) * 8;
-    w_src[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + w_kcol[i];
+    const int kcol = ((pos & 7) ^ (row & 7)) * 8;
+    if constexpr (OFF32) {
+      w_off[i] = ((unsigned)(min(n0 + row, p.N - 1)) * (unsigned)p.ldw + kcol) * 2u;
+    } else {
+      w_kcol[i] = kcol;
+      w_src[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + kcol;
+    }
   }
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(haff_zero_page);
 
   auto stage = [&](int buf, int k0) {
     bf16_t* sA = smem + buf * STAGE_ELEMS;
     bf16_t* sW = sA + A_ELEMS;
+    const bf16_t* a_base = p.A + k0;
+    const bf16_t* w_base = p.W + k0;
+    if constexpr (OFF32) {  // keep SGPR-base + 32-bit-VGPR-offset addressing (no hoisted 64-bit pointer per chunk)
+      asm volatile("" : "+s"(a_base));
+      asm volatile("" : "+s"(w_base));
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const bf16_t* ga = (k0 + a_kcol[i]) < p.K ? a_src[i] + k0 : zero_src;
+      const bf16_t* ga;
+      if constexpr (OFF32) {
+        unsigned o = a_off[i];
+        asm volatile("" : "+v"(o));  // keeps the zero-extension next to the load so it selects the saddr form
+        ga = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(a_base) + o);
+      } else {
+        ga = (k0 + a_kcol[i]) < p.K ? a_src[i] + k0 : zero_src;
+      }
       bf16_t* la = sA + (i * NTHREADS + wave * 64) * 8;  // wave-uniform LDS base; hardware adds lane*16
       __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)la, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      const bf16_t* gw = (k0 + w_kcol[i]) < p.K ? w_src[i] + k0 : zero_src;
+      const bf16_t* gw;
+      if constexpr (OFF32) {
+        unsigned o = w_off[i];
+        asm volatile("" : "+v"(o));
+        gw = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(w_base) + o);
+      } else {
+        gw = (k0 + w_kcol[i]) < p.K ? w_src[i] + k0 : zero_src;
+      }
       bf16_t* lw = sW + (i * NTHREADS + wave * 64) * 8;
       __builtin_amdgcn_global_load_lds((gptr_t)gw, (lptr_t)lw, 16, 0, 0);
     }
@@ -169,56 +208,96 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      stage(cur ^ 1, (kt + 1) * BK);
-      if constexpr (NA + NW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (kt == 0) HAFF_TRACE(1);
-
-    const bf16_t* sA = smem + cur * STAGE_ELEMS;
+  bf16x8 wf[2][TN], af[2][TM];  // fragments of one K-tile: [32-deep k-step][16-row tile]
+  auto read_frags = [&](int buf, int ks) {
+    const bf16_t* sA = smem + buf * STAGE_ELEMS;
     const bf16_t* sW = sA + A_ELEMS;
-    // issue every fragment read of the K-tile up front (both 32-deep k-steps), consume in issue order
-    bf16x8 wf[2][TN], af[2][TM];
+    const int c = ks * 4 + fh;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int c = ks * 4 + fh;
-#pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const int rw = wn * (BN / WN) + t * 16 + fr;
-        wf[ks][t] = *reinterpret_cast<const bf16x8*>(sW + rw * BK + ((c ^ (rw & 7)) << 3));
-      }
-#pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        const int ra = wm * (BM / WM) + t * 16 + fr;
-        af[ks][t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
-      }
+    for (int t = 0; t < TN; ++t) {
+      const int rw = wn * (BN / WN) + t * 16 + fr;
+      wf[ks][t] = *reinterpret_cast<const bf16x8*>(sW + rw * BK + ((c ^ (rw & 7)) << 3));
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[ks][mi], acc[ni][mi], 0, 0, 0);
-    // Schedule: k-step-0 reads first, then the k-step-1 reads trickle in between the k-step-0 MFMA groups, so at
-    // most 15 LDS reads are outstanding (lgkmcnt is 4 bits: more forces a full drain) and the compiler can place
-    // counted waits; only the first group's read latency is exposed per K-tile.
-    __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);
-#pragma unroll
-    for (int g = 0; g < TM; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, (TN + TM + TM - 1) / TM, 0);
+    for (int t = 0; t < TM; ++t) {
+      const int ra = wm * (BM / WM) + t * 16 + fr;
+      af[ks][t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);
+  };
+  auto mfma_rows = [&](int ks, int mi_lo, int mi_hi) {
+#pragma unroll
+    for (int mi = mi_lo; mi < mi_hi; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[ks][mi], acc[ni][mi], 0, 0, 0);
+  };
+
+  // K loop, software-pipelined ACROSS the workgroup barrier. One barrier per K-tile: after it every wave's share of
+  // tile kt+1 has landed and every wave is done reading tile kt-1's buffer, so the DMA of tile kt+2 may overwrite it
+  // and has a whole K-tile of MFMAs to land. The second half of k-step 1's MFMAs (operands already in registers) is
+  // held back and issued AFTER the barrier, where it keeps the MFMA pipe busy while the first fragments of the
+  // next K-tile come back from LDS. (Measured alternatives, tools/gemm_variant.py: two barriers per K-tile -7 %,
+  // no hold-back -4 %, an LDS-counter split barrier and a ping-pong wave schedule no better than this.)
+  if constexpr (WM * WN == 8) {
+    constexpr int HEAD = TM / 2;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    HAFF_TRACE(1);
+    if (nk > 1) stage(1, BK);
+    read_frags(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      read_frags(cur, 1);
+      mfma_rows(0, 0, TM);
+      mfma_rows(1, 0, HEAD);
+      // k-step-1 reads trickle in between the k-step-0 MFMA groups (lgkmcnt is 4 bits: keep <= 15 reads outstanding)
+#pragma unroll
+      for (int g = 0; g < TM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (TN + TM + TM - 1) / TM, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, TN * HEAD, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt+1 landed; my reads of tile kt are done
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
+        read_frags(cur ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_rows(1, HEAD, TM);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // 4-wave tile: two workgroups per CU cover for each other, and the plain double-buffered loop (next tile's DMA
+    // in flight across a counted wait, two barriers per K-tile) measured faster than the pipelined one here.
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        stage(cur ^ 1, (kt + 1) * BK);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kt == 0) HAFF_TRACE(1);
+      read_frags(cur, 0);
+      read_frags(cur, 1);
+      mfma_rows(0, 0, TM);
+      mfma_rows(1, 0, TM);
+      __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);
+#pragma unroll
+      for (int g = 0; g < TM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (TN + TM + TM - 1) / TM, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);
+      __builtin_amdgcn_s_barrier();
+    }
   }
+  __builtin_amdgcn_s_barrier();  // the epilogue reuses stage memory: every wave is done reading fragments
   HAFF_TRACE(2);
 
   // ---- epilogue, staged through LDS so global traffic is whole 128-B row segments ----
@@ -419,15 +498,17 @@ extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long l
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
              bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  bool big = tile_cfg == 2;
-  if (tile_cfg == 0) {
+  // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
+  const bool big_ok = (K % BK == 0) && ((long)M * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
+  bool big = tile_cfg == 2 && big_ok;
+  if (tile_cfg == 0 && big_ok) {
     // Pick the tile by wave-quantisation efficiency (tiles / slots rounded up) times the measured per-tile
-    // advantage of the 256^2 kernel (tools/gemm_bench.py: ~6 % at K=1280, ~10 % at K>=2048): 128^2 runs 2
+    // advantage of the 256^2 kernel (tools/gemm_bench.py: ~1.2x at equal quantisation): 128^2 runs 2
     // workgroups per CU (512 slots), 256^2 one (256 slots).
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-    const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256) * (K >= 2048 ? 1.10 : 1.06);
+    const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256) * 1.22;
     big = (M >= 256 && N >= 256 && e256 > e128);
   }
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Time haff_gemm_bf16_cfg from an explicitly named build of gemm_bf16.hip (experiment variants compiled with -D flags
+into 2handedafforder_amd/lib/libhaff_gemm_<name>.so). usage: gemm_variant.py name [name ...]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = [(78400, 3840, 1280), (65536, 1280, 5120), (18624, 12288, 4096), (8192, 8192, 8192)]
+
+
+def load(name):
+    lib = ctypes.CDLL(os.path.join(HERE, "2handedafforder_amd", "lib", f"libhaff_gemm_{name}.so"))
+    vp, cl, ci = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+    lib.haff_gemm_bf16_cfg.argtypes = [vp, cl, vp, cl, vp, cl, vp, vp, cl, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.haff_gemm_bf16_cfg.restype = ci
+    return lib
+
+
+def main():
+    names = sys.argv[1:]
+    libs = {n: load(n) for n in names}
+    dev = torch.device("cuda:0")
+    for M, N, K in SHAPES:
+        x = torch.randn((M, K), device=dev).to(torch.bfloat16)
+        w = (torch.randn((N, K), device=dev) * K ** -0.5).to(torch.bfloat16)
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        res = {n: [] for n in names}
+        for r in range(4):
+            for n in names:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    rc = libs[n].haff_gemm_bf16_cfg(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, None, None, 0,
+                                                    None, M, N, K, 0, 0, 0, 2, None)
+                    assert rc == 0
+                e1.record()
+                torch.cuda.synchronize()
+                if r:
+                    res[n].append(e0.elapsed_time(e1) / 3 * 1e3)
+        fl = 2.0 * M * N * K
+        print(f"{M:6d} {N:6d} {K:6d} | " + " | ".join(f"{n}: {sorted(v)[1]:8.1f} us {fl / sorted(v)[1] / 1e6:5.0f}" for n, v in res.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
