@@ -239,7 +239,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   // next K-tile come back from LDS. (Measured alternatives, tools/gemm_variant.py: two barriers per K-tile -7 %,
   // no hold-back -4 %, an LDS-counter split barrier and a ping-pong wave schedule no better than this.)
   if constexpr (WM * WN == 8) {
-    constexpr int HEAD = TM / 2;
+#ifndef HAFF_GEMM_HEAD
+#define HAFF_GEMM_HEAD (TM / 2)
+#endif
+    constexpr int HEAD = HAFF_GEMM_HEAD;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

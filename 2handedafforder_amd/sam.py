@@ -111,9 +111,13 @@ class SamEncoderHip:
             q = q5[:, :, 0].permute(0, 2, 1, 3)
             k = q5[:, :, 1].permute(0, 2, 1, 3)
             v = q5[:, :, 2].permute(0, 2, 1, 3)
-            relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
-            a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
-            del relh, relw, qkv
+            if not blk["global"] and ops.window_attention_supported(q, S):
+                a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
+            else:
+                relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
+                a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
+                del relh, relw
+            del qkv
             ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
             h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6)
             h = ops.linear(h, blk["w1"], bias=blk["b1"], act=ops.ACT_GELU)

@@ -67,6 +67,16 @@ int haff_relpos_tables(const void* q, long q_sb, long q_sh, long q_st, const flo
 int haff_relpos_tables_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* tab_h, const void* tab_w,
                             float* relh, float* relw, int B, int H, int S, int d, void* stream);
 
+/* fused SAM WINDOW attention with the decomposed rel-pos bias computed in the kernel (one pass over HBM; replaces
+ * haff_relpos_tables_bf16 + haff_attention_bf16 for the 28 windowed ViT-H blocks): Attention.forward
+ * (image_encoder.py:235-260) + add_decomposed_rel_pos (:354-392) + get_rel_pos with q_size == k_size (:322-351).
+ * q/k/v/o: bf16 [n_windows][H][S*S][d] views given by (window, head, token) strides; tab_*: bf16 [2S-1][d].
+ * Supported geometry: S == 14, d == 80; otherwise HAFF_ERR_UNSUPPORTED (-2) and the caller takes the generic pair. */
+int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* k, long k_sb, long k_sh,
+                               long k_st, const void* v, long v_sb, long v_sh, long v_st, void* o, long o_sb,
+                               long o_sh, long o_st, int n_windows, int H, int S, int d, float scale,
+                               const void* tab_h, const void* tab_w, void* stream);
+
 /* ---- row norms ----------------------------------------------------------------------------------------------
  * haff_layernorm: nn.LayerNorm / LayerNorm2d on channels-last rows (common.py:31-43; image_encoder.py:179,191;
  * transformer.py:134-144; CLIP layer norms). in_map (int32[rows], may be null): out row i normalises in row

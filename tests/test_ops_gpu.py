@@ -205,6 +205,34 @@ def test_relpos_tables(dev, dtype, S, d):
     _close(relw, ref_w, 1e-5, "relw")
 
 
+@pytest.mark.parametrize("n_win", [8, 5, 48])
+def test_window_attention_fused(dev, n_win):
+    """haff_window_attention_bf16 (rel-pos computed in the kernel) vs the reference formula
+    (image_encoder.py:235-260,354-392) on the ViT-H window geometry; both grid->workgroup mappings (n_win % 8)."""
+    ops = _ops()
+    S, d, H = 14, 80, 3
+    N = S * S
+    qkv = _rand((n_win, N, 3, H, d), dev, torch.bfloat16, 45, 1.5)
+    q = qkv[:, :, 0].permute(0, 2, 1, 3)
+    k = qkv[:, :, 1].permute(0, 2, 1, 3)
+    v = qkv[:, :, 2].permute(0, 2, 1, 3)
+    th = _rand((2 * S - 1, d), dev, torch.float32, 46, 0.5).to(torch.bfloat16).float()
+    tw = _rand((2 * S - 1, d), dev, torch.float32, 47, 0.5).to(torch.bfloat16).float()
+    assert ops.window_attention_supported(q, S)
+    scale = d ** -0.5
+    got = ops.window_attention(q, k, v, scale, th, tw, S)
+    idx = torch.arange(S, device=dev)[:, None] - torch.arange(S, device=dev)[None, :] + (S - 1)
+    rq = q.float().reshape(n_win * H, S, S, d)
+    relh = torch.einsum("bhwc,hkc->bhwk", rq, th[idx]).reshape(n_win * H, N, S)
+    relw = torch.einsum("bhwc,wkc->bhwk", rq, tw[idx]).reshape(n_win * H, N, S)
+    ref = _attn_ref(q, k, v, scale, False, 0, relh, relw, S)
+    _close(got, ref, 2e-2, f"fused window attention n_win={n_win}")
+    # and against the generic pair it replaces
+    rh, rw = ops.relpos_tables(q, th, tw, S)
+    old = ops.attention(q, k, v, scale, relh=rh, relw=rw, S=S)
+    _close(got, old.float(), 2e-2, "fused vs generic window attention")
+
+
 @pytest.mark.parametrize("C", [64, 256, 1024, 1280, 4096, 5120])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_norms(dev, C, dtype):
