@@ -419,6 +419,95 @@ int launch_attn(const AttnArgs& p, hipStream_t s) {
   return haff_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// KV-cached decode step (Nq == 1, d == 128, every key visible): HBM-bound, no matrix shape to it — one wave per
+// (batch, head) streams the K and V rows of that head once and does the two GEMVs on the VALU.
+// Lane = (g = lane>>4, c = lane&15): per iteration the wave reads 4 consecutive keys (one per 16-lane row g), lane
+// (g, c) holding the 16-B chunk c of K[key] and of V[key]: a whole 256-B row per 16 lanes, 1 KB per instruction.
+// score(key) = sum over the row's 16 lanes (DPP row reduction leaves it in all 16), so the lanes that need p(key) for
+// the P.V update already have it: no LDS, no barrier. Online softmax per row group (keys = g mod 4), the four groups
+// are merged once at the end. (The generic 128-query flash kernel spent 190 us per layer on this at B=64.)
+constexpr int DEC_D = 128;
+constexpr int DEC_UNROLL = 4;   // 16-B loads in flight per lane per operand
+
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + wave;
+  if (bh >= p.B * p.H) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int g = lane >> 4, c = lane & 15;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
+  const bf16_t* kb = p.k + (long)b * p.k_sb + (long)h * p.k_sh + c * 8;
+  const bf16_t* vb = p.v + (long)b * p.v_sb + (long)h * p.v_sh + c * 8;
+
+  float qv[8];
+  load8(qb + c * 8, qv);
+  const float sl2 = p.scale * LOG2E;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qv[j] *= sl2;
+
+  float m_run = -1e30f, l_run = 0.f;
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int n_it = (p.Nk + 3) / 4;
+  for (int it0 = 0; it0 < n_it; it0 += DEC_UNROLL) {
+    uint4 kr[DEC_UNROLL], vr[DEC_UNROLL];
+#pragma unroll
+    for (int u = 0; u < DEC_UNROLL; ++u) {
+      const int key = min((it0 + u) * 4 + g, p.Nk - 1);
+      kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st);
+      vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st);
+    }
+#pragma unroll
+    for (int u = 0; u < DEC_UNROLL; ++u) {
+      const int key = (it0 + u) * 4 + g;
+      const unsigned kw[4] = {kr[u].x, kr[u].y, kr[u].z, kr[u].w};
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s += qv[2 * j] * __builtin_bit_cast(float, kw[j] << 16);
+        s += qv[2 * j + 1] * __builtin_bit_cast(float, kw[j] & 0xffff0000u);
+      }
+      s = row16_sum(s);
+      s = key < p.Nk ? s : -INFINITY;
+      const float m_new = fmaxf(m_run, s);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float pr = __builtin_amdgcn_exp2f(s - m_new);
+      m_run = m_new;
+      l_run = l_run * alpha + pr;
+      const unsigned vw[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[2 * j] = o[2 * j] * alpha + pr * __builtin_bit_cast(float, vw[j] << 16);
+        o[2 * j + 1] = o[2 * j + 1] * alpha + pr * __builtin_bit_cast(float, vw[j] & 0xffff0000u);
+      }
+    }
+  }
+  // merge the four row groups (lanes c, c+16, c+32, c+48 hold partial results for the same 8 output columns)
+  float m_all = fmaxf(m_run, __shfl_xor(m_run, 16, 64));
+  m_all = fmaxf(m_all, __shfl_xor(m_all, 32, 64));
+  const float w = __builtin_amdgcn_exp2f(m_run - m_all);
+  float l = l_run * w;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float x = o[j] * w;
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    o[j] = x / l;
+  }
+  if (g == 0) store8(p.o + (long)b * p.o_sb + (long)h * p.o_sh + c * 8, o);
+}
+
 }  // namespace
 
 // q/k/v/o: bf16; strides in elements (batch, head, token). d % 8 == 0, d <= 128.
@@ -441,6 +530,11 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
              reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
              B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
+      (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+    hipLaunchKernelGGL(attn_decode_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, p);
+    return haff_check_launch();
+  }
   const int dp = d <= 64 ? 64 : (d <= 96 ? 96 : 128);
   if (rel) {
     const int mode = (S == 64) ? 2 : (S <= 16 && Nk == S * S ? 3 : 1);

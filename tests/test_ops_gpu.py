@@ -135,6 +135,9 @@ ATTN_CASES = [
     (2, 4, 257, 257, 64, False, 0),
     (2, 4, 291, 291, 128, True, 0),
     (3, 4, 1, 295, 128, False, 0),
+    (2, 3, 1, 1, 128, False, 0),     # decode kernel: single key
+    (2, 3, 1, 7, 128, False, 0),     # decode kernel: ragged last group of 4 keys
+    (5, 7, 1, 300, 128, True, 0),    # decode through the causal flag (q_pos0 = Nk-1: every key visible)
     (2, 8, 6, 4096, 16, False, 0),
     (2, 8, 4096, 6, 16, False, 0),
     (2, 8, 6, 6, 32, False, 0),
