@@ -68,7 +68,12 @@ class GemmMeter:
             e0.record()
             out = meter._orig(x, w, *a, **kw)
             e1.record()
-            meter.records.append((e0, e1, 2.0 * x.shape[0] * x.shape[1] * w.shape[0]))
+            M, K, N = x.shape[0], x.shape[1], w.shape[0]
+            n_out = N // 2 if kw.get("swiglu") else N
+            byts = 2.0 * (M * K + N * K + M * n_out + (M * n_out if kw.get("resid") is not None else 0))
+            if out.dtype == torch.float32:
+                byts += 2.0 * M * n_out
+            meter.records.append((e0, e1, 2.0 * M * K * N, byts))
             return out
         ops.linear = timed
         return self
@@ -78,9 +83,10 @@ class GemmMeter:
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
-        return len(self.records), ms, fl
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
+        by = sum(r[3] for r in self.records)
+        return len(self.records), ms, fl, by
 
 
 def cpu_baseline(cfg, text_tokens, n_gen, threads):
@@ -213,12 +219,24 @@ def main():
         with GemmMeter() as meter:
             step()
         model.overlap_streams = True
-        n_launch, gemm_ms, gemm_fl = meter.summary()
+        n_launch, gemm_ms, gemm_fl, gemm_bytes = meter.summary()
+        # HBM traffic of the dominant kernel cannot be sampled from inside this process: it comes from the two
+        # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of THIS command, summarised by tools/pmc_traffic.py into
+        # profiles/ (FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes). null when no summary matches.
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_gemm_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            if pmc.get("config") == cfg.name and pmc.get("batch") == B:
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_src = "profiles/pmc_gemm_traffic.json (%s)" % pmc.get("collected", "")
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         roofline = {
             "bound": "mfma", "kernel": "gemm_bf16_kernel (haff_gemm_bf16, all epilogue variants)",
             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch_avg": gemm_bytes / n_launch,
             "launches_per_step": n_launch, "avg_launch_us": 1e3 * gemm_ms / n_launch,
             "flops_per_launch_avg": gemm_fl / n_launch, "gemm_share_of_step": gemm_ms / ms_per_step,
             "whole_path": {"flops_per_frame": flops_frame, "achieved": fps / world * flops_frame / 1e12,

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise the two rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE — they do not fit one pass) into the
+per-launch HBM traffic of the dominant kernel family, written to profiles/pmc_gemm_traffic.json for bench.py's
+`roofline.traffic`. Units and correction per MI355X_MICROARCH.md: both counters are KiB; on gfx950 FETCH_SIZE counts
+128-B requests as 64 B, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <config> <batch> [out.json]"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def per_kernel(path, counter):
+    tot = collections.defaultdict(lambda: [0, 0.0])
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            key = "gemm_bf16_kernel" if "gemm_bf16_kernel" in name else name.replace("(anonymous namespace)::", "")[:60]
+            tot[key][0] += 1
+            tot[key][1] += float(r["Counter_Value"])
+    return tot
+
+
+def main():
+    fpath, wpath, config, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                            "profiles", "pmc_gemm_traffic.json")
+    f, w = per_kernel(fpath, "FETCH_SIZE"), per_kernel(wpath, "WRITE_SIZE")
+    table = {}
+    for k in f:
+        n = f[k][0]
+        fetch = 2.0 * 1024.0 * f[k][1] / n
+        write = 1024.0 * w[k][1] / w[k][0] if k in w else 0.0
+        table[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write}
+    g = table["gemm_bf16_kernel"]
+    res = {"config": config, "batch": batch, "kernel": "gemm_bf16_kernel",
+           "launches_profiled": g["launches"],
+           "hbm_bytes_per_launch": g["fetch_bytes_per_launch"] + g["write_bytes_per_launch"],
+           "fetch_bytes_per_launch": g["fetch_bytes_per_launch"], "write_bytes_per_launch": g["write_bytes_per_launch"],
+           "collected": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --batch %d --steps 1 "
+                        "--warmup 1 --no-cpu-baseline --no-b1; FETCH_SIZE x2 (gfx950)" % batch,
+           "other_kernels": {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["fetch_bytes_per_launch"] * kv[1]["launches"])[:10]
+                             if k != "gemm_bf16_kernel"}}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: res[k] for k in ("launches_profiled", "hbm_bytes_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch")}))
+
+
+if __name__ == "__main__":
+    main()
