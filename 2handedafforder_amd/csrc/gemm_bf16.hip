@@ -42,6 +42,7 @@ struct GemmArgs {
   const float* bias;
   const void* resid; long ldr;
   const int* row_map;
+  const int* a_map;   // optional gather: logical A row m is stored at A row a_map[m]
   int M, N, K;
   int act, out_f32, swiglu;
   // batched launches (blockIdx.y = z): operand z lives at base + (z / nb_inner) * s?o + (z % nb_inner) * s?i elements
@@ -141,11 +142,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   for (int i = 0; i < NA; ++i) {
     const int pos = i * NTHREADS + tid, row = pos >> 3;
     const int kcol = ((pos & 7) ^ (row & 7)) * 8;
+    int arow = min(m0 + row, p.M - 1);
+    if (p.a_map) arow = p.a_map[arow];
     if constexpr (OFF32) {
-      a_off[i] = ((unsigned)(min(m0 + row, p.M - 1)) * (unsigned)p.lda + kcol) * 2u;  // bytes
+      a_off[i] = ((unsigned)arow * (unsigned)p.lda + kcol) * 2u;  // bytes
     } else {
       a_kcol[i] = kcol;
-      a_src[i] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + kcol;
+      a_src[i] = p.A + (long)arow * p.lda + kcol;
     }
   }
 #pragma unroll
@@ -490,19 +493,18 @@ extern "C" int haff_gemm_trace_read(unsigned long long* host, int n_words) {
 }
 #endif
 
-// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (for A/B measurements)
-extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
-                                  const float* bias, const void* resid, long ldr, const int* row_map,
-                                  int M, int N, int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {
+static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, void* C,
+                          long ldc, const float* bias, const void* resid, long ldr, const int* row_map, int M, int N,
+                          int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return HAFF_ERR_BAD_ARG;
   if ((K & 7) || (lda & 7) || (ldw & 7)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || (ldc & 3) || resid)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
-             bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
+             bias, resid, ldr, row_map, a_map, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
-  const bool big_ok = (K % BK == 0) && ((long)M * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
+  const bool big_ok = (K % BK == 0) && ((long)(a_map ? a_rows : M) * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
   bool big = tile_cfg == 2 && big_ok;
   if (tile_cfg == 0 && big_ok) {
     // Pick the tile by wave-quantisation efficiency (tiles / slots rounded up) times the measured per-tile
@@ -517,10 +519,31 @@ extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long l
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
 
+// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (for A/B measurements)
+extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                                  const float* bias, const void* resid, long ldr, const int* row_map,
+                                  int M, int N, int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {
+  return gemm_bf16_impl(A, lda, nullptr, 0, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu,
+                        tile_cfg, stream);
+}
+
 extern "C" int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                               const float* bias, const void* resid, long ldr, const int* row_map,
                               int M, int N, int K, int act, int out_f32, int swiglu, void* stream) {
-  return haff_gemm_bf16_cfg(A, lda, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0, stream);
+  return gemm_bf16_impl(A, lda, nullptr, 0, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0,
+                        stream);
+}
+
+// Same with a gather on the A side: logical row m of the product reads A row a_map[m] (0 <= a_map[m] < a_rows).
+// Used to run the window-unpartition projection only over real tokens (image_encoder.py:186-188,291-318: the padded
+// window rows are dropped right after the projection, so they are never multiplied).
+extern "C" int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw,
+                                     void* C, long ldc, const float* bias, const void* resid, long ldr,
+                                     const int* row_map, int M, int N, int K, int act, int out_f32, int swiglu,
+                                     void* stream) {
+  if (!a_map || a_rows <= 0) return HAFF_ERR_BAD_ARG;
+  return gemm_bf16_impl(A, lda, a_map, a_rows, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu,
+                        0, stream);
 }
 
 // Batched C_z = A_z . W_z^T (no epilogue): z = zo * nb_inner + zi, operand offsets zo * s?o + zi * s?i (elements).
@@ -532,6 +555,6 @@ extern "C" int haff_gemm_bf16_batched(const void* A, long lda, long sAo, long sA
   if ((K & 7) || (lda & 7) || (ldw & 7) || (sAo & 7) || (sAi & 7) || (sWo & 7) || (sWi & 7)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
-             nullptr, nullptr, 0, nullptr, M, N, K, 0, out_f32, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
+             nullptr, nullptr, 0, nullptr, nullptr, M, N, K, 0, out_f32, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
   return launch_gemm<128, 128, 2, 2>(p, reinterpret_cast<hipStream_t>(stream), nb_outer * nb_inner);
 }

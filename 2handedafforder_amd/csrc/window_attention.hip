@@ -35,6 +35,11 @@ struct WinArgs {
   int B, H;  // B = number of windows
   float scale;
   const bf16_t *tab_h, *tab_w;  // [2S-1][D] bf16, contiguous
+  // window padding (image_encoder.py:263-288): windows tile a grid_h x grid_w token grid, wps per side; window
+  // tokens beyond the grid are pads whose q/k/v are those of token row `pad_token` (relative to the base pointers).
+  // grid_h == 0: every token is real.
+  int grid_h, grid_w, wps;
+  long pad_token;
 };
 
 #ifdef HAFF_WIN_TRACE  // phase timestamps (100 MHz wall clock) of workgroup 0 / wave 0, for tools/window_attn_trace.py
@@ -113,22 +118,27 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
   // caller passes; checked on the host). Pad / tail slots re-read chunk 0 of a K row: they only have to be finite
   // (the matching Q columns are zero).
   unsigned slot_off[NDMA];
+  unsigned slot_pad[NDMA];   // [31:28] token row in window, [27:24] token column, [23:0] byte offset inside the pad row
   const long v_minus_k = (p.v - p.k);   // elements; same for every (window, head) because strides match
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
     const int sl = tid + i * C::NTHREADS;
     long off;
+    unsigned pad = 0;
     if (sl >= TOTAL_SLOTS) {
       off = 0;
     } else if (sl < C::KSLOTS) {
       const int row = sl / (C::CPR + 1), c = sl - row * (C::CPR + 1);
       off = (long)row * p.k_st + (c < C::CPR ? c * 8 : 0);
+      pad = ((unsigned)(row / S) << 28) | ((unsigned)(row % S) << 24) | (unsigned)((c < C::CPR ? c : 0) * 16);
     } else {
       const int sv = sl - C::KSLOTS;
       const int row = sv / C::CPR, c = sv - row * C::CPR;
       off = v_minus_k + (long)row * p.v_st + c * 8;
+      pad = ((unsigned)(row / S) << 28) | ((unsigned)(row % S) << 24) | (unsigned)(v_minus_k * 2 + c * 16);
     }
     slot_off[i] = (unsigned)(off * 2);
+    slot_pad[i] = pad;
   }
   uint4 qnext[C::QPW][C::NKD];
   const int qcol = min(fr, S - 1);       // the lane's query column inside a grid row (masked lanes duplicate S-1)
@@ -137,14 +147,24 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
     decode(id, win, h);
     const bf16_t* qb = p.q + (long)win * p.q_sb + (long)h * p.q_sh;
     const bf16_t* kb = p.k + (long)win * p.k_sb + (long)h * p.k_sh;
+    // first padded token row / column of this window (>= S: none)
+    int pad_h0 = S, pad_w0 = S;
+    if (p.grid_h > 0) {
+      const int wi = win % (p.wps * p.wps);
+      pad_h0 = p.grid_h - (wi / p.wps) * S;
+      pad_w0 = p.grid_w - (wi % p.wps) * S;
+    }
+    const unsigned pad_base = (unsigned)((p.pad_token * p.k_st - (long)win * p.k_sb) * 2);   // bytes from kb
+    const bf16_t* qpad = p.q + p.pad_token * p.q_st + (long)h * p.q_sh;
 #pragma unroll
     for (int t = 0; t < C::QPW; ++t) {
-      const long qrow = (long)(min(wave + t * C::NWAVES, S - 1) * S + qcol);
+      const int qh_t = min(wave + t * C::NWAVES, S - 1);
+      const bf16_t* qsrc = (qh_t >= pad_h0 || qcol >= pad_w0) ? qpad : qb + (long)(qh_t * S + qcol) * p.q_st;
 #pragma unroll
       for (int kd = 0; kd < C::NKD; ++kd) {
         const int col = kd * 32 + fh * 8;
         qnext[t][kd] = make_uint4(0, 0, 0, 0);
-        if (col < D) qnext[t][kd] = *reinterpret_cast<const uint4*>(qb + qrow * p.q_st + col);
+        if (col < D) qnext[t][kd] = *reinterpret_cast<const uint4*>(qsrc + col);
       }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(wlptr_t)(wsm + buf * C::BUF_BYTES) + wave * 1024;  // hardware adds lane*16
@@ -154,8 +174,10 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const unsigned m0v = lds0 + i * C::NTHREADS * 16;
+      const bool is_pad = (int)(slot_pad[i] >> 28) >= pad_h0 || (int)((slot_pad[i] >> 24) & 15u) >= pad_w0;
+      const unsigned off = is_pad ? pad_base + (slot_pad[i] & 0xffffffu) : slot_off[i];
       if ((i + 1) * C::NTHREADS <= C::PAD_SLOTS || (i * C::NTHREADS + wave * 64) < C::PAD_SLOTS)   // wave-uniform
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(slot_off[i]), "s"(kb), "s"(m0v)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(kb), "s"(m0v)
                      : "memory");
     }
   };
@@ -395,7 +417,11 @@ extern "C" int haff_win_trace_read(unsigned long long* host, int n_words) {
 #endif
 
 // Fused window attention with in-kernel decomposed rel-pos (bf16). q/k/v/o: strides in elements (window, head,
-// token); n_tokens = S*S per window. tab_h/tab_w: bf16 [2S-1][d] contiguous (image_encoder.py:322-351 with
+// token); n_tokens = S*S per window. grid_h/grid_w > 0: the windows tile images of grid_h x grid_w tokens
+// (ceil(grid/S)^2 windows per image, window-major as window_partition orders them) and tokens beyond the grid are
+// PADS that were never written: their q/k/v are read from token row `pad_token` (relative to the base pointers),
+// which the caller fills with the projection of a zero token, i.e. the qkv bias (pad after norm1,
+// image_encoder.py:179-183). grid_h == 0: every row of every window is real. tab_h/tab_w: bf16 [2S-1][d] contiguous (image_encoder.py:322-351 with
 // q_size == k_size: no interpolation). Supported geometry: S == 14, d == 80 (SAM ViT-H windowed blocks);
 // anything else returns HAFF_ERR_UNSUPPORTED and the caller uses haff_relpos_tables + haff_attention_bf16.
 extern "C" int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, long q_st,
@@ -403,7 +429,8 @@ extern "C" int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, l
                                           const void* v, long v_sb, long v_sh, long v_st,
                                           void* o, long o_sb, long o_sh, long o_st,
                                           int n_windows, int H, int S, int d, float scale,
-                                          const void* tab_h, const void* tab_w, void* stream) {
+                                          const void* tab_h, const void* tab_w, int grid_h, int grid_w,
+                                          long pad_token, void* stream) {
   if (n_windows <= 0 || H <= 0 || S <= 0 || d <= 0 || !tab_h || !tab_w) return HAFF_ERR_BAD_ARG;
   if ((q_st & 7) || (k_st & 7) || (v_st & 7) || (o_st & 3) || (q_sh & 7) || (k_sh & 7) || (v_sh & 7) || (o_sh & 3) ||
       (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (o_sb & 3))
@@ -423,7 +450,14 @@ extern "C" int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, l
   }
   WinArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
             reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
-            n_windows, H, scale, reinterpret_cast<const bf16_t*>(tab_h), reinterpret_cast<const bf16_t*>(tab_w)};
+            n_windows, H, scale, reinterpret_cast<const bf16_t*>(tab_h), reinterpret_cast<const bf16_t*>(tab_w),
+            grid_h, grid_w, grid_h > 0 ? (grid_h + S - 1) / S : 0, pad_token};
+  if (grid_h > 0) {
+    // padded windows: square window grid, whole images, pad row addressable with the 32-bit staging offsets
+    if (grid_w != grid_h || (n_windows % (p.wps * p.wps)) != 0 || pad_token < 0 || q_st != k_st ||
+        (pad_token + 1) * k_st * 2 >= (1L << 32))
+      return HAFF_ERR_BAD_ARG;
+  }
   using C = WinCfg<80, 14>;
   static bool attr_set = false;
   if (!attr_set) {

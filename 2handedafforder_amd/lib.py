@@ -19,6 +19,8 @@ _PROTOS = {
                        c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_bf16_cfg": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_gemm_bf16_gather": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
+                              c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_f32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                       c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
@@ -35,7 +37,8 @@ _PROTOS = {
                                 c_int, c_int, c_int, c_int, c_void_p],
     "haff_window_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                    c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
-                                   c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+                                   c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_long,
+                                   c_void_p],
     "haff_layernorm": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                        c_int, c_void_p],
     "haff_rmsnorm": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_int, c_void_p],

@@ -33,7 +33,7 @@ def _req(t, name):
 
 
 def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, out_rows=None, out_dtype=None,
-           swiglu=False, tile_cfg=0):
+           swiglu=False, tile_cfg=0, a_map=None):
     """y = epi(x @ w.T): x [M,K] (row stride free, unit inner stride), w [N,K], bias fp32 [N] or None.
 
     epilogue order: +bias -> act -> +resid (resid indexed like out). row_map (int32 [M]) redirects output
@@ -43,6 +43,9 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
     _req(x, "x")
     assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
     M, K = x.shape
+    if a_map is not None:  # gather: logical row m reads x[a_map[m]] (bf16 only)
+        assert a_map.dtype == torch.int32 and x.dtype == torch.bfloat16
+        M = a_map.numel()
     N = w.shape[0]
     assert w.shape[1] == K, (x.shape, w.shape)
     n_out = N // 2 if swiglu else N
@@ -57,7 +60,13 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
         assert bias.dtype == torch.float32 and bias.numel() == N
     if row_map is not None:
         assert row_map.dtype == torch.int32 and row_map.numel() == M
-    if x.dtype == torch.bfloat16:
+    if a_map is not None:
+        assert w.dtype == torch.bfloat16
+        rc = lib.haff_gemm_bf16_gather(x.data_ptr(), x.stride(0), a_map.data_ptr(), x.shape[0], w.data_ptr(),
+                                       w.stride(0), out.data_ptr(), out.stride(0), _p(bias), _p(resid),
+                                       0 if resid is None else resid.stride(0), _p(row_map), M, N, K, act,
+                                       1 if out.dtype == torch.float32 else 0, 1 if swiglu else 0, _stream())
+    elif x.dtype == torch.bfloat16:
         assert w.dtype == torch.bfloat16
         rc = lib.haff_gemm_bf16_cfg(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
                                     out.stride(0), _p(bias), _p(resid), 0 if resid is None else resid.stride(0),
@@ -133,9 +142,11 @@ def window_attention_supported(q, S):
     return q.dtype == torch.bfloat16 and S == 14 and q.shape[3] == 80 and q.shape[2] == S * S
 
 
-def window_attention(q, k, v, scale, tab_h, tab_w, S, out=None):
+def window_attention(q, k, v, scale, tab_h, tab_w, S, out=None, grid=0, pad_token=0):
     """Fused SAM window attention + decomposed rel-pos. q/k/v [n_windows,H,S*S,d] strided views, tab_* fp32 [2S-1,d]
-    (rounded to bf16 once and cached, as the reference's bf16 checkpoint stores them). Returns [n_windows,S*S,H*d]."""
+    (rounded to bf16 once and cached, as the reference's bf16 checkpoint stores them). Returns [n_windows,S*S,H*d].
+    grid > 0: windows tile grid x grid token images and the padded window tokens were never written; their q/k/v
+    are taken from token row `pad_token` of the views (the caller stores the qkv bias there)."""
     lib = load_library()
     _req(q, "q")
     B, H, N, d = q.shape
@@ -148,7 +159,8 @@ def window_attention(q, k, v, scale, tab_h, tab_w, S, out=None):
                                         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
                                         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
                                         out.data_ptr(), o4.stride(0), o4.stride(1), o4.stride(2),
-                                        B, H, S, d, float(scale), th.data_ptr(), tw.data_ptr(), _stream())
+                                        B, H, S, d, float(scale), th.data_ptr(), tw.data_ptr(), int(grid), int(grid),
+                                        int(pad_token), _stream())
     check(rc, "haff_window_attention_bf16")
     return out
 

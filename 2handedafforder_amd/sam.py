@@ -57,6 +57,7 @@ class SamEncoderHip:
         self.w_neck2 = sd[E + ".neck.2.weight"].permute(0, 2, 3, 1).reshape(s.out_chans, -1).to(dev, dtype).contiguous()
         self.neck3 = (_f32(sd[E + ".neck.3.weight"], dev), _f32(sd[E + ".neck.3.bias"], dev))
         self._maps = {}
+        self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
 
     @staticmethod
     def _fit_rel_pos(table, S):
@@ -83,6 +84,17 @@ class SamEncoderHip:
         self._maps[B] = (win, nw * nw)
         return self._maps[B]
 
+    def _compact_window_map(self, B):
+        """Inverse of _window_maps: image token row -> its row in the window-major padded layout (int32 [B*g*g])."""
+        key = ("inv", B)
+        if key not in self._maps:
+            win, _ = self._window_maps(B)
+            valid = win >= 0
+            inv = torch.empty((B * self.cfg.grid * self.cfg.grid,), dtype=torch.int32, device=self.device)
+            inv[win[valid].long()] = torch.arange(win.numel(), dtype=torch.int32, device=self.device)[valid]
+            self._maps[key] = inv
+        return self._maps[key]
+
     def patch_rows_from_nchw(self, images):
         s = self.cfg
         return ops.patchify_nchw(images, s.patch, s.grid, s.grid, 3 * s.patch * s.patch, self.dtype)
@@ -99,26 +111,49 @@ class SamEncoderHip:
         x = ops.add_bcast(x, self.pos, mod=N, out=x)
         scale = hd ** -0.5
         for i, blk in enumerate(self.blocks):
-            if blk["global"]:
+            compact = (self.compact_windows and not blk["global"] and self.dtype == torch.bfloat16 and s.window == 14
+                       and hd == 80)
+            if compact:
+                # Windowed block, real tokens only: the padded window rows (16 % of the rows at 64x64 / 14) are never
+                # normalised, projected or written. qkv rows are scattered straight into the window-major layout;
+                # the fused window kernel substitutes the one "pad token" row (qkv of a zero token = the bias, since
+                # window_partition pads AFTER norm1, image_encoder.py:179-183) for them; proj gathers the real rows
+                # back (window_unpartition drops the pads right after, :186-188).
+                _, nw2 = self._window_maps(B)
+                inv = self._compact_window_map(B)
+                nb, ntok, S = B * nw2, s.window * s.window, s.window
                 xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6)
-                nb, ntok, S, row_map = B, N, g, None
+                qkv = torch.empty((nb * ntok + 1, 3 * C), dtype=self.dtype, device=x.device)
+                ops.linear(xn, blk["wqkv"], bias=blk["bqkv"], row_map=inv, out=qkv[:-1])
+                qkv[-1].copy_(blk["bqkv"])
+                q5 = qkv[:-1].view(nb, ntok, 3, H, hd)
+                q = q5[:, :, 0].permute(0, 2, 1, 3)
+                k = q5[:, :, 1].permute(0, 2, 1, 3)
+                v = q5[:, :, 2].permute(0, 2, 1, 3)
+                a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=nb * ntok)
+                del qkv
+                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, a_map=inv, out=x)
             else:
-                win, nw2 = self._window_maps(B)
-                xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, in_map=win)
-                nb, ntok, S, row_map = B * nw2, s.window * s.window, s.window, win
-            qkv = ops.linear(xn, blk["wqkv"], bias=blk["bqkv"])
-            q5 = qkv.view(nb, ntok, 3, H, hd)
-            q = q5[:, :, 0].permute(0, 2, 1, 3)
-            k = q5[:, :, 1].permute(0, 2, 1, 3)
-            v = q5[:, :, 2].permute(0, 2, 1, 3)
-            if not blk["global"] and ops.window_attention_supported(q, S):
-                a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
-            else:
-                relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
-                a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
-                del relh, relw
-            del qkv
-            ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
+                if blk["global"]:
+                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6)
+                    nb, ntok, S, row_map = B, N, g, None
+                else:
+                    win, nw2 = self._window_maps(B)
+                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, in_map=win)
+                    nb, ntok, S, row_map = B * nw2, s.window * s.window, s.window, win
+                qkv = ops.linear(xn, blk["wqkv"], bias=blk["bqkv"])
+                q5 = qkv.view(nb, ntok, 3, H, hd)
+                q = q5[:, :, 0].permute(0, 2, 1, 3)
+                k = q5[:, :, 1].permute(0, 2, 1, 3)
+                v = q5[:, :, 2].permute(0, 2, 1, 3)
+                if not blk["global"] and ops.window_attention_supported(q, S):
+                    a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
+                else:
+                    relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
+                    a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
+                    del relh, relw
+                del qkv
+                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
             h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6)
             h = ops.linear(h, blk["w1"], bias=blk["b1"], act=ops.ACT_GELU)
             ops.linear(h, blk["w2"], bias=blk["b2"], resid=x, out=x)

@@ -38,6 +38,12 @@ int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, lo
 int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                        const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
                        int swiglu, int tile_cfg, void* stream);
+/* haff_gemm_bf16 with a gather on the A side: logical row m reads A row a_map[m] (0 <= a_map[m] < a_rows). Runs the
+ * window-unpartition projection over real tokens only (image_encoder.py:186-188,291-318 drop the padded rows right
+ * after proj). */
+int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, void* C,
+                          long ldc, const float* bias, const void* resid, long ldr, const int* row_map, int M, int N,
+                          int K, int act, int out_f32, int swiglu, void* stream);
 /* parity-mode twin: everything f32. K % 4 == 0, lda/ldw % 4 == 0. */
 int haff_gemm_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, const float* bias,
                   const float* resid, long ldr, const int* row_map, int M, int N, int K, int act, int swiglu,
@@ -71,11 +77,15 @@ int haff_relpos_tables_bf16(const void* q, long q_sb, long q_sh, long q_st, cons
  * haff_relpos_tables_bf16 + haff_attention_bf16 for the 28 windowed ViT-H blocks): Attention.forward
  * (image_encoder.py:235-260) + add_decomposed_rel_pos (:354-392) + get_rel_pos with q_size == k_size (:322-351).
  * q/k/v/o: bf16 [n_windows][H][S*S][d] views given by (window, head, token) strides; tab_*: bf16 [2S-1][d].
+ * grid_h/grid_w > 0: windows tile images of grid_h x grid_w tokens; window tokens beyond the grid are pads that the
+ * caller never wrote — their q/k/v are read from token row pad_token (= projection of a zero token = the qkv bias;
+ * window_partition pads AFTER norm1, image_encoder.py:179-183,263-288). grid_h == 0: every token is real.
  * Supported geometry: S == 14, d == 80; otherwise HAFF_ERR_UNSUPPORTED (-2) and the caller takes the generic pair. */
 int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* k, long k_sb, long k_sh,
                                long k_st, const void* v, long v_sb, long v_sh, long v_st, void* o, long o_sb,
                                long o_sh, long o_st, int n_windows, int H, int S, int d, float scale,
-                               const void* tab_h, const void* tab_w, void* stream);
+                               const void* tab_h, const void* tab_w, int grid_h, int grid_w, long pad_token,
+                               void* stream);
 
 /* ---- row norms ----------------------------------------------------------------------------------------------
  * haff_layernorm: nn.LayerNorm / LayerNorm2d on channels-last rows (common.py:31-43; image_encoder.py:179,191;

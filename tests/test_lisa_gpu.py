@@ -176,3 +176,43 @@ def test_batch_invariance_and_determinism(dev):
     _, l1, r1, t1 = model.evaluate(*args(slice(1, 2)), max_new_tokens=4, forced_answer=forced[1:2])
     assert all(torch.equal(a, b) for a, b in zip(l3, l3b))
     assert torch.equal(l3[1], l1[0]) and torch.equal(r3[1], r1[0]) and torch.equal(t3[1], t1[0])
+
+
+def test_sam_vith_width_windowed_blocks(dev):
+    """ViT-H block geometry (dim 1280, 16 heads of 80, 14x14 windows on a 64x64 grid -> 5x5 windows with padding),
+    depth cut to 3 (windowed, global, windowed): exercises the fused window-attention kernel, the pad-token
+    substitution and the gather/scatter GEMMs, which the tiny/mid geometries cannot reach.
+    (1) compact path (real tokens only) == padded path (every window row computed) up to bf16 rounding noise;
+    (2) both within the bf16 tolerance of the fp32 CPU oracle on the same bf16-rounded weights."""
+    import copy
+    import haff  # noqa: F401
+    from haff import config as hcfg
+    from haff import weights as hw
+    from haff.sam import SamEncoderHip
+    from oracle import lisa_oracle as O
+    cfg = copy.deepcopy(hcfg.haff_7b())
+    cfg.sam.depth, cfg.sam.global_idx = 3, (1,)
+    shapes = {k: v for k, v in hw.all_shapes(cfg).items() if k.startswith(V + ".image_encoder")}
+    sd = hw.make_state_dict(cfg, 11, shapes)
+    hw.round_to_bf16_(sd)
+    rng = np.random.default_rng(12)
+    images = torch.from_numpy(rng.standard_normal((2, 3, 1024, 1024), dtype=np.float32)).to(torch.bfloat16).float()
+    enc = SamEncoderHip(sd, cfg.sam, torch.bfloat16, dev)
+    with torch.no_grad():
+        taps_c, taps_p, taps_ref = {}, {}, {}
+        enc.compact_windows = True
+        out_c = enc(images.to(dev), taps_c).float().cpu()
+        enc.compact_windows = False
+        out_p = enc(images.to(dev), taps_p).float().cpu()
+        ref = O.sam_image_encoder(sd, V + ".image_encoder", images, cfg.sam, taps_ref)
+    g = cfg.sam.grid
+    ref_cl = ref.permute(0, 2, 3, 1).reshape(2, g * g, -1)
+    scale = ref_cl.abs().max().item()
+    d_cp = (out_c - out_p).abs().max().item() / scale
+    d_ref = (out_c - ref_cl).abs().max().item() / scale
+    for i in range(3):
+        r = (taps_c[f"block{i}"] - taps_ref[f"block{i}"]).abs().max().item() / taps_ref[f"block{i}"].abs().max().item()
+        print(f"vit-h width block{i} rel {r:.3e}")
+        assert r <= 5e-2
+    print(f"compact vs padded {d_cp:.3e}, compact vs oracle {d_ref:.3e}")
+    assert d_cp <= 2e-2 and d_ref <= 1e-1

@@ -208,6 +208,59 @@ def test_relpos_tables(dev, dtype, S, d):
     _close(relw, ref_w, 1e-5, "relw")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 1280, 1280), (70, 96, 64)])
+def test_linear_gather_rows(dev, M, N, K):
+    """haff_gemm_bf16_gather: logical row m reads x[a_map[m]]; combined with bias, residual and an output row map."""
+    ops = _ops()
+    R = M + 57
+    x = _rand((R, K), dev, torch.bfloat16, 70)
+    w = _rand((N, K), dev, torch.bfloat16, 71, K ** -0.5)
+    b = _rand((N,), dev, torch.float32, 72)
+    g = torch.Generator(device="cpu").manual_seed(73)
+    a_map = torch.randint(0, R, (M,), generator=g).to(torch.int32).to(dev)
+    resid = _rand((M, N), dev, torch.bfloat16, 74)
+    got = ops.linear(x, w, bias=b, resid=resid, a_map=a_map)
+    ref = x.float()[a_map.long()] @ w.float().t() + b + resid.float()
+    _close(got, ref, 2e-2, "gather linear")
+    # in-place residual, as the SAM proj uses it
+    xr = resid.clone()
+    ops.linear(x, w, bias=b, resid=xr, a_map=a_map, out=xr)
+    _close(xr, ref, 2e-2, "gather linear in place")
+
+
+def test_window_attention_pad_token(dev):
+    """Padded windows: rows of padded tokens are never written (filled with NaN here); the kernel must take the pad
+    token row instead. 2 images of 20x20 tokens -> 2x2 windows of 14x14, windows on the right/bottom edge padded."""
+    ops = _ops()
+    S, d, H, grid, nimg = 14, 80, 2, 20, 2
+    N, wps = S * S, 2
+    n_win = nimg * wps * wps
+    qkv = _rand((n_win * N + 1, 3, H, d), dev, torch.bfloat16, 48, 1.5)
+    pad_tok = qkv[-1].clone()
+    is_pad = torch.zeros((n_win, S, S), dtype=torch.bool, device=dev)
+    for w in range(n_win):
+        wy, wx = (w % 4) // 2, (w % 4) % 2
+        is_pad[w, max(0, grid - wy * S):, :] = True
+        is_pad[w, :, max(0, grid - wx * S):] = True
+    full = qkv[:-1].view(n_win, N, 3, H, d).clone()
+    full[is_pad.view(n_win, N)] = pad_tok          # what window_partition's zero pad + qkv bias would hold
+    holes = qkv.clone()
+    holes[:-1].view(n_win, N, 3, H, d)[is_pad.view(n_win, N)] = float("nan")
+    th = _rand((2 * S - 1, d), dev, torch.float32, 46, 0.5).to(torch.bfloat16).float()
+    tw = _rand((2 * S - 1, d), dev, torch.float32, 47, 0.5).to(torch.bfloat16).float()
+
+    def views(buf):
+        q5 = buf.view(n_win, N, 3, H, d)
+        return (q5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    q, k, v = views(holes[:-1])
+    got = ops.window_attention(q, k, v, d ** -0.5, th, tw, S, grid=grid, pad_token=n_win * N)
+    qf, kf, vf = views(full)
+    ref = ops.window_attention(qf, kf, vf, d ** -0.5, th, tw, S)
+    real = ~is_pad.view(n_win, N)
+    assert torch.isfinite(got[real]).all()
+    assert torch.equal(got[real], ref[real])
+
+
 @pytest.mark.parametrize("n_win", [8, 5, 48])
 def test_window_attention_fused(dev, n_win):
     """haff_window_attention_bf16 (rel-pos computed in the kernel) vs the reference formula

@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = ctypes.CDLL(os.path.join(HERE, "2handedafforder_amd", "lib", "libhaff_win_trace.so"))
 vp, cl, ci, cf = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
-lib.haff_window_attention_bf16.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, cf, vp, vp, vp]
+lib.haff_window_attention_bf16.argtypes = [vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci, cf, vp, vp, ci, ci, cl, vp]
 lib.haff_window_attention_bf16.restype = ci
 lib.haff_win_trace_read.argtypes = [vp, ci]
 
@@ -25,7 +25,7 @@ row = 3 * H * d
 base = qkv.data_ptr()
 for _ in range(3):
     rc = lib.haff_window_attention_bf16(base, N * row, d, row, base + H * d * 2, N * row, d, row, base + 2 * H * d * 2, N * row, d, row,
-                                        out.data_ptr(), N * H * d, d, H * d, n_win, H, S, d, d ** -0.5, th.data_ptr(), tw.data_ptr(), None)
+                                        out.data_ptr(), N * H * d, d, H * d, n_win, H, S, d, d ** -0.5, th.data_ptr(), tw.data_ptr(), 0, 0, 0, None)
     assert rc == 0
 torch.cuda.synchronize()
 buf = np.zeros(64 * 16, dtype=np.uint64)
