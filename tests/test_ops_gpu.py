@@ -312,6 +312,27 @@ def test_norms(dev, C, dtype):
     assert (got[m < 0] == 0).all()
 
 
+@pytest.mark.parametrize("C", [256, 1024, 1280])
+def test_norms_many_rows(dev, C):
+    """>= 8192 rows take the 4-rows-per-wave kernel: ragged row count, gather map with dropped rows."""
+    ops = _ops()
+    R = 8203
+    x = _rand((R, C), dev, torch.bfloat16, 53, 2.0) + 0.3
+    w = _rand((C,), dev, torch.float32, 54) + 1.0
+    b = _rand((C,), dev, torch.float32, 55)
+    xf = x.float()
+    _close(ops.layernorm(x, w, b, 1e-6), F.layer_norm(xf, (C,), w, b, 1e-6), 1e-2, "layernorm many rows")
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * w
+    _close(ops.rmsnorm(x, w, 1e-5), ref, 1e-2, "rmsnorm many rows")
+    m = torch.randint(0, R, (9001,), device=dev).to(torch.int32)
+    m[::7] = -1
+    got = ops.layernorm(x, w, b, 1e-6, in_map=m)
+    ref = F.layer_norm(xf, (C,), w, b, 1e-6)[m.clamp(min=0).long()]
+    ref[m < 0] = 0
+    _close(got, ref, 1e-2, "layernorm gather many rows")
+    assert (got[m < 0] == 0).all()
+
+
 def test_patchify_and_im2col(dev):
     ops = _ops()
     B, P, g = 2, 16, 5
