@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;
   constexpr int NA = BM * 8 / NTHREADS, NW = BN * 8 / NTHREADS;  // 16-B chunks per thread per K-tile
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;             // 16x16 MFMA tiles per wave
-  static_assert(BN / WN == 64, "epilogue assumes a 64-column wave tile");
+  constexpr int WNC = BN / WN;                                    // columns per wave: 64, or 128 for the 4-wave 256^2 tile
+  static_assert(WNC == 64 || WNC == 128, "wave tile width");
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS];  // [buf][A | W]
 
   const int tid = threadIdx.x;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   // LDS position pos = i*NTHREADS + tid (lane-linear); row = pos>>3; logical chunk = (pos&7) ^ (row&7)
   // The 8-wave tile is only launched for K % 64 == 0 and operands under 4 GiB, so it keeps 32-bit offsets from a
   // uniform base (saves 16 VGPRs for the ping-pong loop); the 4-wave tile keeps pointers and the zero-page K tail.
-  constexpr bool OFF32 = (WM * WN == 8);
+  constexpr bool OFF32 = (BM == 256);
   const bf16_t* a_src[OFF32 ? 1 : NA];
   const bf16_t* w_src[OFF32 ? 1 : NW];
   int a_kcol[OFF32 ? 1 : NA], w_kcol[OFF32 ? 1 : NW];
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   // 8 consecutive columns per lane -> (+residual) -> 16-B stores.
   // Every global LOAD of the epilogue (bias, row map, residual) is issued before the stores it would otherwise
   // queue behind: vmcnt retires in order, so a load issued after a store waits for that store's round trip.
-  constexpr int WCOLS = SWIGLU ? 32 : 64;   // output columns owned by a wave
+  constexpr int WCOLS = SWIGLU ? WNC / 2 : WNC;   // output columns owned by a wave
   constexpr int RS = WCOLS + 4;             // LDS row stride in floats (pad keeps b128 accesses conflict-free)
   constexpr int LPR = WCOLS / 8;            // lanes per output row on the read-back side
   constexpr int RPS = 64 / LPR;             // rows per read-back step
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   static_assert(WM * WN * 16 * RS * 4 <= STAGE_ELEMS * 2, "epilogue staging must fit in one LDS stage");
   float* sEp = reinterpret_cast<float*>(smem) + wave * (16 * RS);
   const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
-  const int n_wave_in = n0 + wn * 64;                           // first (interleaved) input column of the wave
+  const int n_wave_in = n0 + wn * WNC;                          // first (interleaved) input column of the wave
   const int n_wave_out = SWIGLU ? (n_wave_in >> 1) : n_wave_in;
   const int m_wave = m0 + wm * WROWS;
   const bool c_vec = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((p.ldc & 7) == 0);
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const bool fast = c_vec && (!p.resid || r_vec) && (n_wave_out + WCOLS <= n_total_out);
 
   float bias_r[TN][4];
-  if (p.bias && n_wave_in + 64 <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
+  if (p.bias && n_wave_in + WNC <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) load4(p.bias + n_wave_in + ni * 16 + fh * 4, bias_r[ni]);
   } else {
@@ -505,6 +506,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
   const bool big_ok = (K % BK == 0) && ((long)(a_map ? a_rows : M) * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
+  if (tile_cfg == 3 && big_ok) return launch_gemm<256, 256, 2, 2>(p, s);
   bool big = tile_cfg == 2 && big_ok;
   if (tile_cfg == 0 && big_ok) {
     // Pick the tile by wave-quantisation efficiency (tiles / slots rounded up) times the measured per-tile
@@ -519,7 +521,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
 
-// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (for A/B measurements)
+// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (8 waves), 3 = force 256x256 (4 waves) (for A/B measurements)
 extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                                   const float* bias, const void* resid, long ldr, const int* row_map,
                                   int M, int N, int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {

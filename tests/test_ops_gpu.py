@@ -57,6 +57,37 @@ def test_gemm_bf16_epilogues(dev, M, N, K, act):
     _close(got32, ACT_REF[act](x.float() @ w.float().T + bias), 2e-3, "gemm_bf16 f32-out")
 
 
+@pytest.mark.parametrize("tile_cfg", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 1003, 256), (300, 520, 64), (1111, 256, 1280)])
+def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
+    """Every tile of the template (128^2 / 4 waves, 256^2 / 8 waves, 256^2 / 4 waves with 128-column wave tiles) through
+    every epilogue feature, ragged edges included; the auto heuristic only picks the big tiles on large problems."""
+    ops = _ops()
+    x = _rand((M, K), dev, torch.bfloat16, 11)
+    w = _rand((N, K), dev, torch.bfloat16, 12, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 13)
+    resid = _rand((M, N), dev, torch.bfloat16, 14)
+    y = x.float() @ w.float().T + bias
+    got = ops.linear(x, w, bias=bias, act=1, resid=resid, tile_cfg=tile_cfg)
+    _close(got, F.gelu(y) + resid.float(), 1.2e-2, f"cfg{tile_cfg} gelu+resid")
+    got32 = ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=tile_cfg)
+    _close(got32, y, 2e-3, f"cfg{tile_cfg} f32 out")
+    perm = torch.randperm(M, device=dev).to(torch.int32)
+    perm[::5] = -1
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+    ops.linear(x, w, bias=bias, resid=resid, row_map=perm, out=out, tile_cfg=tile_cfg)
+    ref = torch.zeros((M, N), dtype=torch.float32, device=dev)
+    keep = perm >= 0
+    ref[perm[keep].long()] = y[keep] + resid.float()[perm[keep].long()]
+    _close(out, ref, 1.2e-2, f"cfg{tile_cfg} row_map")
+    if N % 32 == 0:
+        F_ = N // 2
+        wg, wu = w[:F_], w[F_:]
+        wi = torch.stack([wg.reshape(F_ // 16, 16, K), wu.reshape(F_ // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+        got = ops.linear(x, wi, swiglu=True, tile_cfg=tile_cfg)
+        _close(got, F.silu(x.float() @ wg.float().T) * (x.float() @ wu.float().T), 1.2e-2, f"cfg{tile_cfg} swiglu")
+
+
 def test_gemm_bf16_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a swapped C layout (cdna guide §3)."""
     ops = _ops()

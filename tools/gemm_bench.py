@@ -34,7 +34,7 @@ SHAPES = [  # name, M, N, K, kind
 def main():
     dev = torch.device("cuda:0")
     rounds = int(os.environ.get("ROUNDS", "5"))
-    cfgs = [1, 2, 0]
+    cfgs = [int(c) for c in os.environ.get("CFGS", "1,2,0").split(",")]
     print(f"{'shape':22s} {'M':>7s} {'N':>6s} {'K':>6s} | " + " | ".join(f"cfg{c}: us   TF/s" for c in cfgs))
     for name, M, N, K, kind in SHAPES:
         x = torch.randn((M, K), device=dev).to(torch.bfloat16)
