@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--text-tokens", type=int, default=32)
     ap.add_argument("--n-gen", type=int, default=8)
-    ap.add_argument("--sam-chunk", type=int, default=16)
+    ap.add_argument("--sam-chunk", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
     args = ap.parse_args()
