@@ -45,13 +45,18 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((address_space(3))) bf16x4* lds_v4_ptr;
 
-template <int DP, int BIAS, bool CAUSAL>
+// NDT: output d-tiles actually computed (d <= 16*NDT <= DP): SAM's d = 80 lives in DP = 96 for the QK k-steps but
+// needs only 5 of the 6 P.V output tiles.
+// LSUM (needs d % 16 == 0 and d < DP): column d of the staged V tile is a constant 1, so the softmax denominator falls
+// out of the P.V MFMA as output row d (one extra d-tile of MFMAs instead of 16 VALU adds per q-tile per KV tile, and it
+// sums exactly the bf16-rounded probabilities the numerator uses).
+template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int KSTRIDE = DP * 2 + 16;  // bytes
   constexpr int VSTRIDE = DP * 2 + 32;
   constexpr int NCH = DP / 32;          // 16-B chunks per thread per operand per tile
   constexpr int CPR = DP / 8;           // chunks per row
-  constexpr int ND = DP / 16;           // output d-tiles
+  constexpr int ND = NDT;               // output d-tiles
   constexpr int NKD = DP / 32;          // k-steps over head dim
   constexpr int SMAX = 32;
   constexpr int RSTRIDE = 2 * SMAX + 1;  // odd stride: the 16 query lanes of a tile hit 16 different banks
@@ -182,6 +187,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     st_c[i] = id - st_row[i] * CPR;
   }
   uint4 kreg[NCH], vreg[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
   const bf16_t* kptr[NCH];
   const bf16_t* vptr[NCH];
   bool col_ok[NCH];
@@ -196,9 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const bool plain = (BIAS != 3) && (kt * KT + KT <= p.Nk);  // wave-uniform: whole tile in range, no remap
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      kreg[i] = make_uint4(0, 0, 0, 0);
-      vreg[i] = make_uint4(0, 0, 0, 0);
-      if (col_ok[i]) {
+      if (col_ok[i]) {   // chunks past d are never loaded nor written: their LDS slots are set once (below)
         if (plain) {
           kreg[i] = *reinterpret_cast<const uint4*>(kptr[i] + kt * k_step);
           vreg[i] = *reinterpret_cast<const uint4*>(vptr[i] + kt * v_step);
@@ -217,10 +222,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     unsigned char* wV = wK + KT * KSTRIDE;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      *reinterpret_cast<uint4*>(wK + st_row[i] * KSTRIDE + st_c[i] * 16) = kreg[i];
-      *reinterpret_cast<uint4*>(wV + st_row[i] * VSTRIDE + st_c[i] * 16) = vreg[i];
+      if (col_ok[i]) {
+        *reinterpret_cast<uint4*>(wK + st_row[i] * KSTRIDE + st_c[i] * 16) = kreg[i];
+        *reinterpret_cast<uint4*>(wV + st_row[i] * VSTRIDE + st_c[i] * 16) = vreg[i];
+      }
     }
   };
+  // head-dim padding (d < DP), both stages, once: K columns zero (Q is zero there too), V columns zero except the
+  // ones-column at d when the row sums are taken from the MFMA
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (!col_ok[i]) {
+      uint4 vpad = make_uint4(0, 0, 0, 0);
+      if (LSUM && st_c[i] * 8 == p.d) vpad.x = 0x3f80u;   // bf16 1.0 in column d
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        unsigned char* wK = sKV + b2 * STAGE_BYTES;
+        unsigned char* wV = wK + KT * KSTRIDE;
+        *reinterpret_cast<uint4*>(wK + st_row[i] * KSTRIDE + st_c[i] * 16) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(wV + st_row[i] * VSTRIDE + st_c[i] * 16) = vpad;
+      }
+    }
+  }
 
   f32x4 oacc[ND][2];
 #pragma unroll
@@ -228,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     oacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     oacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float m_run[2] = {-1e30f, -1e30f};
+  float m_run[2] = {0.f, 0.f};   // reference max the accumulators are expressed against (set by the first tile)
   float l_run[2] = {0.f, 0.f};
 
   int nkt = (p.Nk + KT - 1) / KT;
@@ -253,19 +276,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     for (int qt = 0; qt < 2; ++qt) {
       float rh3[4] = {0.f, 0.f, 0.f, 0.f};
       if (BIAS == 3) {
-        switch (kt) {
-          case 0: rh3[0] = relh3[qt][0]; rh3[1] = relh3[qt][1]; rh3[2] = relh3[qt][2]; rh3[3] = relh3[qt][3]; break;
-          case 1: rh3[0] = relh3[qt][4]; rh3[1] = relh3[qt][5]; rh3[2] = relh3[qt][6]; rh3[3] = relh3[qt][7]; break;
-          case 2: rh3[0] = relh3[qt][8]; rh3[1] = relh3[qt][9]; rh3[2] = relh3[qt][10]; rh3[3] = relh3[qt][11]; break;
-          default: rh3[0] = relh3[qt][12]; rh3[1] = relh3[qt][13]; rh3[2] = relh3[qt][14]; rh3[3] = relh3[qt][15]; break;
-        }
+        // (select chain, not a switch on kt: hipcc 7.2 miscompiled the switch's default arm in this loop — wrong
+        // rel_h terms for the fourth KV tile; tests/test_ops_gpu.py::test_attention case S=14 catches it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          rh3[j] = kt == 0 ? relh3[qt][j] : (kt == 1 ? relh3[qt][4 + j] : (kt == 2 ? relh3[qt][8 + j] : relh3[qt][12 + j]));
       }
-      const float rhv = relh_next[qt] * LOG2E;
+      // The running max is folded into the accumulator's initial value too: the MFMA then delivers s - m_run and
+      // the exponentials need no subtraction unless this tile raises the max (first tile: no max yet, plain s).
+      const float msub = m_run[qt];
+      const float rhv = relh_next[qt] * LOG2E - msub;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (BIAS == 2) sacc[t][qt] = f32x4{relw_r[qt][t][0] + rhv, relw_r[qt][t][1] + rhv, relw_r[qt][t][2] + rhv, relw_r[qt][t][3] + rhv};
-        else if (BIAS == 3) sacc[t][qt] = f32x4{relw3[qt][0] + rh3[t], relw3[qt][1] + rh3[t], relw3[qt][2] + rh3[t], relw3[qt][3] + rh3[t]};
-        else sacc[t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (BIAS == 3) {
+          const float rb = rh3[t] - msub;
+          sacc[t][qt] = f32x4{relw3[qt][0] + rb, relw3[qt][1] + rb, relw3[qt][2] + rb, relw3[qt][3] + rb};
+        }
+        else sacc[t][qt] = f32x4{-msub, -msub, -msub, -msub};
       }
       if (BIAS == 2 && kt + 1 < nkt) relh_next[qt] = relh_row[qt][kt + 1];  // one tile ahead: latency hidden
     }
@@ -298,16 +326,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float s[4][4];
       const float* rel_q = sRel + (wave * 32 + qt * 16 + fr) * RSTRIDE;
       float mx = -1e30f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = sacc[t][qt][r];
-          if (BIAS == 1) v += rel_q[off_h[t][r]] + rel_q[off_w[t][r]];
-          s[t][r] = v;
+          if (BIAS == 1) sacc[t][qt][r] += rel_q[off_h[t][r]] + rel_q[off_w[t][r]];
         }
       }
       if (BIAS == 3) {
@@ -315,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int t = 0; t < 4; ++t) {
           const bool row_ok = (4 * kt + t) < p.S;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[t][r] = (row_ok && kw_ok[r]) ? s[t][r] : -INFINITY;
+          for (int r = 0; r < 4; ++r) sacc[t][qt][r] = (row_ok && kw_ok[r]) ? sacc[t][qt][r] : -INFINITY;
         }
       } else if (need_mask) {
 #pragma unroll
@@ -325,44 +350,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             const int key = kt * KT + 16 * t + 4 * fh + r;
             bool ok = key < p.Nk;
             if (CAUSAL) ok = ok && (key <= qrow[qt] + p.q_pos0);
-            s[t][r] = ok ? s[t][r] : -INFINITY;
+            sacc[t][qt][r] = ok ? sacc[t][qt][r] : -INFINITY;
           }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        mx = fmaxf(mx, fmaxf(fmaxf(sacc[t][qt][0], sacc[t][qt][1]), fmaxf(sacc[t][qt][2], sacc[t][qt][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      if (__any(mx > m_run[qt])) {  // exact lazy rescale: most tiles do not raise the running max
-        const float m_new = fmaxf(m_run[qt], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-        m_run[qt] = m_new;
+      // s holds scores relative to m_run (or absolute before the first max is known). Exact lazy rescale: only a tile
+      // that raises the max pays for a subtraction and for rescaling the accumulators.
+      // (first tile: m_run is 0 and the tile max is taken unconditionally; a row with no visible key in the first
+      // tile keeps a finite -1e30 reference, which cannot happen for the masks this path uses: key 0 is visible to
+      // every causal query with q_pos0 >= 0)
+      if (kt == 0 || __any(mx > 0.f)) {
+        const float delta = kt == 0 ? fmaxf(mx, -1e30f) : fmaxf(mx, 0.f);
+        const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);   // first tile: accumulators are still zero
+        m_run[qt] += delta;
+        const float shift = delta;
         l_run[qt] *= alpha;
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
           oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
           oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[t][qt][r] -= shift;
       }
       float psum = 0.f;
-      const float mb = m_run[qt];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[t][r] - mb);  // raw v_exp_f32: arguments are <= 0, tiny results may flush
-          s[t][r] = e;
-          psum += e;
+          const float e = __builtin_amdgcn_exp2f(sacc[t][qt][r]);  // raw v_exp_f32: arguments are <= 0, tiny results may flush
+          sacc[t][qt][r] = e;
+          if (!LSUM) psum += e;
         }
-      l_run[qt] += psum;
+      if (!LSUM) l_run[qt] += psum;
       // P^T fragment for k-step ks: slots j<4 <- tile 2ks (keys 4fh+j), j>=4 <- tile 2ks+1
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         uint4 u;
-        u.x = pack_bf16x2(s[2 * ks][0], s[2 * ks][1]);
-        u.y = pack_bf16x2(s[2 * ks][2], s[2 * ks][3]);
-        u.z = pack_bf16x2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
-        u.w = pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+        u.x = pack_bf16x2(sacc[2 * ks][qt][0], sacc[2 * ks][qt][1]);
+        u.y = pack_bf16x2(sacc[2 * ks][qt][2], sacc[2 * ks][qt][3]);
+        u.z = pack_bf16x2(sacc[2 * ks + 1][qt][0], sacc[2 * ks + 1][qt][1]);
+        u.w = pack_bf16x2(sacc[2 * ks + 1][qt][2], sacc[2 * ks + 1][qt][3]);
         pf[qt][ks] = __builtin_bit_cast(bf16x8, u);
       }
     }
@@ -392,9 +426,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   bf16_t* ob = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (LSUM) {
+      l = __shfl(oacc[ND - 1][qt][0], fr, 64);   // O^T row d lives in tile d/16, register 0 of the fh == 0 lanes
+    } else {
+      l = l_run[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / l;
     if (qrow[qt] < p.Nq) {
 #pragma unroll
@@ -409,13 +448,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
-template <int DP, int BIAS, bool CAUSAL>
+template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false>
 int launch_attn(const AttnArgs& p, hipStream_t s) {
   constexpr int KSTRIDE = DP * 2 + 16, VSTRIDE = DP * 2 + 32;
   size_t lds = 2 * ((size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE);
   if (BIAS == 1) lds += (size_t)QB * (2 * 32 + 1) * sizeof(float);
   dim3 grid(((p.Nq + QB - 1) / QB) * p.H * p.B), block(256);
-  hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL>), grid, block, lds, s, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL, NDT, LSUM>), grid, block, lds, s, p);
   return haff_check_launch();
 }
 
@@ -545,6 +584,7 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
       return launch_attn<128, 3, false>(p, s);
     }
     if (dp == 64) return mode == 2 ? launch_attn<64, 2, false>(p, s) : launch_attn<64, 1, false>(p, s);
+    if (dp == 96 && mode == 2 && d == 80) return launch_attn<96, 2, false, 6, true>(p, s);   // SAM global blocks
     if (dp == 96) return mode == 2 ? launch_attn<96, 2, false>(p, s) : launch_attn<96, 1, false>(p, s);
     return mode == 2 ? launch_attn<128, 2, false>(p, s) : launch_attn<128, 1, false>(p, s);
   }

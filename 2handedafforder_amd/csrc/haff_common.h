@@ -33,8 +33,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(bf16_t, h);
 }
+// two floats -> one dword of two bf16 with ONE v_cvt_pk_bf16_f32 (converting them separately and or-ing the halves
+// costs 3-4 VALU ops per pair: measured as a third of the attention kernels' VALU work)
+typedef float haff_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 haff_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  const haff_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, haff_bf16x2));
 }
 
 template <typename T> struct elem;
