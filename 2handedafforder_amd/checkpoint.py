@@ -69,6 +69,90 @@ def synthetic_state_dict(cfg, seed, device=None, dtype=torch.bfloat16):
     return hw.make_state_dict(cfg, seed)
 
 
+class SentencePieceTokenizer:
+    """The reference's tokenizer: `AutoTokenizer.from_pretrained(version, use_fast=False)` (inference.py:115-127,
+    train_ds.py:131-149) = transformers' slow LlamaTokenizer over `tokenizer.model`, plus the added tokens `[SEG]`,
+    `<im_start>`, `<im_end>` appended after the sentencepiece vocabulary in that order (ids 32000..32002 for Llama-2).
+
+    Restated from the published behaviour of the 4.31 slow tokenizer in its default (legacy) mode: the text is split on
+    the added tokens, every remaining chunk is encoded by sentencepiece on its own (so each chunk gets the model's
+    dummy-prefix space), BOS is prepended once, no EOS. Parity with transformers 4.31 is UNPINNED here: that version is
+    not installed and the 5.x LlamaTokenizer is a different (fast) implementation; the tests pin the wrapper against
+    sentencepiece itself and the id layout the config expects."""
+
+    def __init__(self, model_file, cfg=None, added_tokens=("[SEG]", "<im_start>", "<im_end>")):
+        import sentencepiece as spm
+        self.sp = spm.SentencePieceProcessor(model_file=model_file)
+        n = self.sp.get_piece_size()
+        self.bos_token_id, self.eos_token_id, self.unk_token_id = self.sp.bos_id(), self.sp.eos_id(), self.sp.unk_id()
+        self.pad_token_id = self.unk_token_id            # tokenizer.pad_token = tokenizer.unk_token (inference.py:121)
+        self.special = {tok: n + i for i, tok in enumerate(added_tokens)}
+        self.vocab_size = n + len(added_tokens)
+        if cfg is not None:  # the ids the model was built for (train_ds.py:143-149) must match this vocabulary
+            want = {"[SEG]": cfg.seg_token_idx, "<im_start>": cfg.im_start_idx, "<im_end>": cfg.im_end_idx}
+            for tok, tid in want.items():
+                if tok in self.special and self.special[tok] != tid:
+                    raise ValueError(f"{tok}: tokenizer id {self.special[tok]} != model config id {tid}")
+
+    def __len__(self):
+        return self.vocab_size
+
+    def _split(self, text):
+        """[(is_added_token, piece)] in order, splitting on the added tokens (longest match first)."""
+        toks = sorted(self.special, key=len, reverse=True)
+        out, buf, i = [], [], 0
+        while i < len(text):
+            for t in toks:
+                if text.startswith(t, i):
+                    if buf:
+                        out.append((False, "".join(buf)))
+                        buf = []
+                    out.append((True, t))
+                    i += len(t)
+                    break
+            else:
+                buf.append(text[i])
+                i += 1
+        if buf:
+            out.append((False, "".join(buf)))
+        return out
+
+    def __call__(self, text, add_special_tokens=True):
+        ids = [self.bos_token_id] if add_special_tokens else []
+        for is_tok, piece in self._split(text):
+            if is_tok:
+                ids.append(self.special[piece])
+            else:
+                ids.extend(self.sp.encode(piece))
+
+        class _R:
+            pass
+        r = _R()
+        r.input_ids = ids
+        return r
+
+    def decode(self, ids, skip_special_tokens=False):
+        inv = {v: k for k, v in self.special.items()}
+        out, run = [], []
+
+        def flush():
+            if run:
+                out.append(self.sp.decode(run))
+                run.clear()
+        for t in [int(x) for x in ids]:
+            if t in inv:
+                flush()
+                out.append(inv[t])
+            elif t in (self.bos_token_id, self.eos_token_id) or t < 0:
+                flush()
+                if not skip_special_tokens and t >= 0:
+                    out.append("<s>" if t == self.bos_token_id else "</s>")
+            elif t < self.sp.get_piece_size():
+                run.append(t)
+        flush()
+        return "".join(out)
+
+
 class ByteTokenizer:
     """Offline stand-in for the sentencepiece tokenizer (no tokenizer.model exists in this setting): UTF-8 bytes
     shifted past the special ids, BOS prepended; the three added tokens of train_ds.py:142-149 map to the ids the

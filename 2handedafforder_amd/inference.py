@@ -58,11 +58,17 @@ def build_model_and_tokenizer(args):
         sd = checkpoint.synthetic_state_dict(cfg, 1234, device, dtype)
         tokenizer = checkpoint.ByteTokenizer(cfg)
     else:
-        from transformers import AutoTokenizer
-        tokenizer = AutoTokenizer.from_pretrained(args.version, cache_dir=None, model_max_length=args.model_max_length,
-                                                  padding_side="right", use_fast=False)
-        tokenizer.pad_token = tokenizer.unk_token
         cfg = checkpoint.config_from_dir(args.version)
+        sp_file = os.path.join(args.version, "tokenizer.model")
+        try:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(args.version, cache_dir=None, model_max_length=args.model_max_length,
+                                                      padding_side="right", use_fast=False)
+            tokenizer.pad_token = tokenizer.unk_token
+        except Exception:  # transformers without the slow (sentencepiece) Llama tokenizer: use the model file directly
+            if not os.path.isfile(sp_file):
+                raise
+            tokenizer = checkpoint.SentencePieceTokenizer(sp_file)
         cfg.seg_token_idx = tokenizer("[SEG]", add_special_tokens=False).input_ids[0]
         cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
         sd = checkpoint.load_state_dict(args.version, args.vision_tower if os.path.isdir(args.vision_tower) else None,

@@ -86,3 +86,35 @@ def test_preprocess_contracts():
     assert t == 1 and not l.any() and r.tolist() == [[False, True]]
     l, r, t = preprocess.gate_and_threshold(ml, mr, torch.tensor([[0.7, 0.1, 0.1, 0.1]]), mode="inference", threshold=0.5)
     assert t == 0 and l.tolist() == [[True, False]] and not r.any()
+
+
+def test_sentencepiece_tokenizer_wrapper(tmp_path):
+    """checkpoint.SentencePieceTokenizer (the reference's slow Llama tokenizer + 3 added tokens, inference.py:115-127)
+    on a tiny sentencepiece model trained here: id layout, BOS handling, added-token splitting, the image-token
+    splice of llava/mm_utils.py:19-44 and a decode round trip."""
+    import sentencepiece as spm
+    from haff import prompt as hprompt
+    from haff.checkpoint import SentencePieceTokenizer
+    corpus = tmp_path / "c.txt"
+    corpus.write_text("\n".join(["where would someone grasp the cup to pour water", "cut the bread with the knife",
+                                  "A chat between a curious human and an artificial intelligence assistant.",
+                                  "USER: can you segment the affordance ASSISTANT: Sure, it is ."] * 20))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "tok"), vocab_size=320,
+                                   model_type="bpe", bos_id=1, eos_id=2, unk_id=0, pad_id=-1, byte_fallback=True,
+                                   character_coverage=1.0, minloglevel=2)
+    tok = SentencePieceTokenizer(str(tmp_path / "tok.model"))
+    sp = spm.SentencePieceProcessor(model_file=str(tmp_path / "tok.model"))
+    n = sp.get_piece_size()
+    assert (tok.special["[SEG]"], tok.special["<im_start>"], tok.special["<im_end>"]) == (n, n + 1, n + 2)
+    assert len(tok) == n + 3 and tok.bos_token_id == 1 and tok.pad_token_id == tok.unk_token_id == 0
+    ids = tok("cut the bread [SEG] with<im_end>").input_ids
+    assert ids[0] == 1 and ids.count(n) == 1 and ids[-1] == n + 2
+    assert ids == [1] + sp.encode("cut the bread ") + [n] + sp.encode(" with") + [n + 2]
+    assert tok("cut", add_special_tokens=False).input_ids == sp.encode("cut")
+    text = "USER: <im_start><image><im_end>\ncut the bread ASSISTANT: Sure, it is [SEG]."
+    got = hprompt.tokenizer_image_token(text, tok)
+    assert got.count(-200) == 1 and got[0] == 1 and got.count(1) == 1   # one BOS, one image sentinel
+    i = got.index(-200)
+    assert got[i - 1] == n + 1 and got[i + 1] == n + 2
+    assert tok.decode(tok("cut the bread").input_ids, skip_special_tokens=True).strip() == "cut the bread"
+    assert "[SEG]" in tok.decode(ids)
