@@ -118,3 +118,35 @@ def test_sentencepiece_tokenizer_wrapper(tmp_path):
     assert got[i - 1] == n + 1 and got[i + 1] == n + 2
     assert tok.decode(tok("cut the bread").input_ids, skip_special_tokens=True).strip() == "cut the bread"
     assert "[SEG]" in tok.decode(ids)
+
+
+def test_evaluation_harness(tmp_path):
+    """haff.evaluation on a hand-made benchmark/prediction tree: closed-form IoU / IoCM / Hausdorff values, the
+    missing-hand rule, the threshold sweep (calculate_iou.py:26-41,97-114,243-261,321-343)."""
+    from PIL import Image
+    from haff import evaluation as ev
+    a = np.zeros((10, 10), bool); a[2:6, 2:6] = True          # 16 px
+    b = np.zeros((10, 10), bool); b[4:8, 4:8] = True          # 16 px, 4 px overlap
+    assert ev.calculate_iou(a, b) == 4 / 28 and ev.calculate_iocm(a, b) == 4 / 16
+    assert ev.calculate_iou(a, np.zeros((0, 0))) is None and ev.calculate_iou(np.zeros_like(a), np.zeros_like(a)) == 0.0
+    dhd, hd = ev.calculate_hausdorff(a, b)
+    assert abs(dhd - np.sqrt(8)) < 1e-9 and abs(hd - np.sqrt(8)) < 1e-9      # corner (7,7) to nearest point (5,5)
+    assert ev.calculate_hausdorff(a, np.zeros_like(a)) == (np.sqrt(200), np.sqrt(200))
+    assert ev.calculate_hausdorff(np.zeros_like(a), a) == (0.0, 0.0)
+
+    def png(path, m):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        Image.fromarray(m.astype(np.uint8) * 255).save(path)
+    bench, comp = tmp_path / "bench", tmp_path / "pred"
+    png(str(bench / "vid" / "0001" / "inpainting.png"), np.zeros((10, 10), bool))
+    png(str(bench / "vid" / "0001" / "aff_left.png"), a)
+    png(str(bench / "vid" / "0001" / "aff_right.png"), b)
+    for th, shrink in (("0.3", 0), ("0.7", 1)):
+        pl = np.zeros((10, 10), bool); pl[2 + shrink:6, 2 + shrink:6] = True
+        png(str(comp / th / "vid" / "0001" / "aff_left.png"), pl)          # right hand missing -> counted as empty
+    res = ev.evaluate_folders(str(bench), str(comp), calc_map=True, is_cropped=True, verbose=False)
+    r3, r7 = res["per_threshold"]
+    union = a | b
+    assert r3["count"] == 1 and abs(r3["iou"] - 16 / union.sum()) < 1e-9 and r3["iocm"] == 1.0
+    assert abs(r7["iou"] - 9 / union.sum()) < 1e-9 and r7["iocm"] == 1.0
+    assert res["best"]["threshold"] == "0.3" and res["mean_average_precision"] == 1.0
