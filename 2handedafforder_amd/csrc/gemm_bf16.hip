@@ -471,6 +471,97 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Skinny GEMM for M <= 16 (KV-cached decode at small batch, the [SEG] MLP, decoder token projections): the product is
+// a stream over W — HBM-bound, 2*N*K bytes — so the grid is laid out for bandwidth, not for MFMA reuse:
+// one workgroup per 16 weight rows (32 for SwiGLU pairs), its 4 waves split K into quarters, each wave streams its
+// 16 x K/4 slab straight from HBM into MFMA A-fragments (16 B per lane, 8 loads in flight), the activation rows (<= 16,
+// L2-resident) are the B operand, and the four partial 16x16 tiles meet in LDS. N = 4096 still gives 256 workgroups x
+// 4 waves; the 128x128 tile launched 32 workgroups there (1.3 TB/s).
+template <bool SWIGLU>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+  constexpr int NT = SWIGLU ? 2 : 1;   // 16-row weight tiles per workgroup
+  __shared__ float red[4][NT][64][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fh = lane >> 4;
+  const int n0 = blockIdx.x * 16 * NT;
+  const int kq = p.K >> 2;                     // K % 128 == 0: every wave gets whole 32-deep k-steps
+  const int k_lo = wave * kq;
+  const bf16_t* xrow = p.A + (long)(p.a_map ? p.a_map[min(fr, p.M - 1)] : min(fr, p.M - 1)) * p.lda + k_lo + fh * 8;
+  const bf16_t* wrow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wrow[t] = p.W + (long)min(n0 + t * 16 + fr, p.N - 1) * p.ldw + k_lo + fh * 8;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;                         // k-steps per batch of loads
+  for (int k = 0; k < kq; k += 32 * U) {
+    uint4 wv[NT][U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = min(k + 32 * u, kq - 32);   // tail batches re-read the last step; masked below
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wv[t][u] = *reinterpret_cast<const uint4*>(wrow[t] + kk);
+      xv[u] = *reinterpret_cast<const uint4*>(xrow + kk);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + 32 * u < kq) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[t][u]),
+                                                           __builtin_bit_cast(bf16x8, xv[u]), acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+    store4(&red[wave][t][lane][0], v);
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // lane holds D[n = 4*fh + r][m = fr] of each tile
+  float o[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[t][r] = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r];
+  const int m = fr;
+  if (m >= p.M) return;
+  long orow = m;
+  if (p.row_map) {
+    orow = p.row_map[m];
+    if (orow < 0) return;
+  }
+  const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float val;
+    int n_out;
+    if (SWIGLU) {
+      const int ng = n0 + 4 * fh + r, nu = ng + 16;
+      const float g = o[0][r] + (p.bias ? p.bias[min(ng, p.N - 1)] : 0.f);
+      const float u = o[1][r] + (p.bias ? p.bias[min(nu, p.N - 1)] : 0.f);
+      val = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u;
+      n_out = (n0 >> 1) + 4 * fh + r;
+    } else {
+      n_out = n0 + 4 * fh + r;
+      val = apply_act(o[0][r] + (p.bias ? p.bias[min(n_out, p.N - 1)] : 0.f), p.act);
+    }
+    if (n_out >= n_total_out) continue;
+    if (p.out_f32) {
+      if (p.resid) val += reinterpret_cast<const float*>(p.resid)[orow * p.ldr + n_out];
+      reinterpret_cast<float*>(p.C)[orow * p.ldc + n_out] = val;
+    } else {
+      if (p.resid) val += bf16_to_f32(reinterpret_cast<const bf16_t*>(p.resid)[orow * p.ldr + n_out]);
+      reinterpret_cast<bf16_t*>(p.C)[orow * p.ldc + n_out] = f32_to_bf16(val);
+    }
+  }
+}
+
 }  // namespace
 
 template <int BM, int BN, int WM, int WN>
@@ -504,6 +595,11 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
              bias, resid, ldr, row_map, a_map, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (M <= 16 && (K % 128) == 0 && tile_cfg == 0) {   // weight-streaming kernel for decode-sized M
+    if (swiglu) hipLaunchKernelGGL((gemm_skinny_kernel<true>), dim3((N + 31) / 32), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<false>), dim3((N + 15) / 16), dim3(256), 0, s, p);
+    return haff_check_launch();
+  }
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
   const bool big_ok = (K % BK == 0) && ((long)(a_map ? a_rows : M) * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
   if (tile_cfg == 3 && big_ok) return launch_gemm<256, 256, 2, 2>(p, s);

@@ -33,6 +33,12 @@ class LisaMI355:
         self.sam_chunk = sam_chunk
         self._sam_stream = torch.cuda.Stream(device=self.device)
         self.overlap_streams = True  # False serialises everything on the caller's stream (per-kernel measurements)
+        # KV-cached decode steps are launch-bound at small batch (32 layers x 9 launches per token): each step is
+        # captured once per (batch, position) into a hipGraph and replayed. The KV cache is persistent per
+        # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
+        self.decode_graphs = True
+        self._graphs = {}
+        self._caches = {}
         sd, dev = state_dict, self.device
         assert cfg.clip.n_patches == N_IMG_PAD + 1, "the reference hard-codes 256 image tokens (LISA.py:461)"
         self.sam_encoder = SamEncoderHip(sd, cfg.sam, dtype, dev)
@@ -64,15 +70,15 @@ class LisaMI355:
         # the sentinel slot itself is never dereferenced by the splice kernel
         x = ops.embed_splice(input_ids.contiguous(), img_pos, self.llm.embed, img.contiguous())
         T = L + n_img - 1
-        cache = self.llm.new_cache(B, T + max_new_tokens)
+        cache = self._persistent_cache(B, T + max_new_tokens)
         hidden = [self.llm.forward(x, cache)]
         out_ids = input_ids
         finished = torch.zeros(B, dtype=torch.bool, device=self.device)
         if forced_answer is not None:
             forced_answer = forced_answer.to(self.device)
+        logits = self.llm.next_token_logits(hidden[-1][:, -1])
+        nxt = ops.argmax_rows(logits)
         for step in range(max_new_tokens):
-            logits = self.llm.next_token_logits(hidden[-1][:, -1])
-            nxt = ops.argmax_rows(logits)
             if forced_answer is not None:
                 nxt = forced_answer[:, step].clone()
             nxt = torch.where(finished, torch.full_like(nxt, cfg.pad_token_id), nxt)
@@ -80,9 +86,56 @@ class LisaMI355:
             finished = finished | (nxt == cfg.eos_token_id)
             if step == max_new_tokens - 1 or bool(finished.all()):
                 break
-            x1 = self.llm.embed.index_select(0, nxt).view(B, 1, -1)
-            hidden.append(self.llm.forward(x1, cache))
+            h1, nxt = self._decode_step(nxt, cache)
+            hidden.append(h1)
         return out_ids, torch.cat(hidden, dim=1) if len(hidden) > 1 else hidden[0]
+
+    def _persistent_cache(self, B, tmax):
+        key = (B, tmax)
+        c = self._caches.get(key)
+        if c is None:
+            if len(self._caches) >= 4:   # a few shapes at most stay resident (7B, B=64, 299 positions: 10 GB)
+                old = next(iter(self._caches))
+                del self._caches[old]
+                self._graphs = {k: v for k, v in self._graphs.items() if k[:2] != old}
+            c = self._caches[key] = self.llm.new_cache(B, tmax)
+        c["len"] = 0
+        return c
+
+    def _decode_step_eager(self, nxt, cache):
+        B = nxt.shape[0]
+        x1 = self.llm.embed.index_select(0, nxt).view(B, 1, -1)
+        h1 = self.llm.forward(x1, cache)
+        logits = self.llm.next_token_logits(h1[:, -1])
+        return h1, ops.argmax_rows(logits)
+
+    def _decode_step(self, nxt, cache):
+        """One greedy step: embed(nxt) -> 32 layers against the KV cache -> logits -> argmax. Returns (hidden [B,1,H],
+        next ids [B]). Replays a hipGraph captured for this (batch, cache capacity, position) when enabled."""
+        if not self.decode_graphs:
+            return self._decode_step_eager(nxt, cache)
+        B, pos = nxt.shape[0], cache["len"]
+        key = (B, cache["tmax"], pos)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 1024:
+                self._graphs.clear()
+            static_in = nxt.clone()
+            # warm-up outside the capture (lazy one-time work inside the ops), then rewind the cache length
+            self._decode_step_eager(static_in, cache)
+            cache["len"] = pos
+            torch.cuda.current_stream(self.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                h1, out = self._decode_step_eager(static_in, cache)
+            ent = self._graphs[key] = (g, static_in, h1, out)
+            cache["len"] = pos
+        g, static_in, h1, out = ent
+        static_in.copy_(nxt)
+        g.replay()
+        cache["len"] = pos + 1
+        # outputs are the graph's static tensors: hand out copies so the next replay cannot overwrite them
+        return h1.clone(), out.clone()
 
     # ---- a10: SAM image encoder --------------------------------------------------------------------------
     @torch.no_grad()

@@ -266,6 +266,26 @@ def main():
                 step(1)
             torch.cuda.synchronize()
             line["latency_batch1_ms"] = 1e3 * (time.perf_counter() - t1) / 5
+            # one KV-cached decode step at batch 1: HBM-bound on the weight stream — report its rate
+            T0 = ids.shape[1] + 255
+            cache = model._persistent_cache(1, T0 + args.n_gen)
+            tok = torch.zeros((1,), dtype=torch.long, device=device)
+
+            def one_step():
+                cache["len"] = T0
+                return model._decode_step(tok, cache)
+            for _ in range(3):
+                one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                one_step()
+            torch.cuda.synchronize()
+            step_ms = 1e3 * (time.perf_counter() - t1) / 10
+            l = cfg.llm
+            w_bytes = 2.0 * (l.layers * (4 * l.hidden * l.hidden + 3 * l.hidden * l.ffn) + l.vocab * l.hidden)
+            line["decode_step_batch1"] = {"ms": step_ms, "weight_bytes": w_bytes, "bound": "hbm",
+                                          "achieved_TBps": w_bytes / (step_ms * 1e-3) / 1e12, "peak_TBps": 8.0}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(len(os.sched_getaffinity(0)), 32)
             line["cpu_baseline"] = cpu_baseline(cfg, args.text_tokens, args.n_gen, threads)

@@ -165,7 +165,9 @@ def test_no_seg_token_gives_empty_masks(dev):
 
 
 def test_batch_invariance_and_determinism(dev):
-    """Frame i's masks do not depend on its batch neighbours, and repeated runs are bitwise identical."""
+    """Repeated runs are bitwise identical; frame i's masks do not depend on its batch neighbours beyond bf16
+    accumulation-order noise (decode-sized products, M <= 16, take the weight-streaming GEMM, whose K split differs from
+    the tiled kernel's: like the reference's cuBLAS path, results are not bitwise batch-invariant)."""
     from haff.lisa import LisaMI355
     cfg, sd, images, images_clip, ids, forced = _setup("tiny", "bf16", B=3)
     S = cfg.sam.img_size
@@ -175,7 +177,10 @@ def test_batch_invariance_and_determinism(dev):
     _, l3b, _, _ = model.evaluate(*args(slice(0, 3)), max_new_tokens=4, forced_answer=forced)
     _, l1, r1, t1 = model.evaluate(*args(slice(1, 2)), max_new_tokens=4, forced_answer=forced[1:2])
     assert all(torch.equal(a, b) for a, b in zip(l3, l3b))
-    assert torch.equal(l3[1], l1[0]) and torch.equal(r3[1], r1[0]) and torch.equal(t3[1], t1[0])
+    for a, b in ((l3[1], l1[0]), (r3[1], r1[0])):
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+        assert _iou(a > 0, b > 0) >= 0.97   # random-weight logits are dense around 0 (module docstring)
+    assert (t3[1] - t1[0]).abs().max().item() <= 2e-2
 
 
 def test_sam_vith_width_windowed_blocks(dev):
@@ -216,3 +221,29 @@ def test_sam_vith_width_windowed_blocks(dev):
         assert r <= 5e-2
     print(f"compact vs padded {d_cp:.3e}, compact vs oracle {d_ref:.3e}")
     assert d_cp <= 2e-2 and d_ref <= 1e-1
+
+
+def test_decode_graphs_match_eager(dev):
+    """hipGraph-captured decode steps (capture on the first call, replay on the second) reproduce the eager greedy
+    loop bit for bit: ids, hidden states, masks."""
+    from haff.lisa import LisaMI355
+    cfg, sd, images, images_clip, ids, forced = _setup("tiny", "bf16", B=3, n_gen=5)
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev)
+    sizes = [(cfg.sam.img_size, cfg.sam.img_size)] * 3
+
+    def run(free_running):
+        kw = dict(max_new_tokens=5, forced_answer=None if free_running else forced)
+        with torch.no_grad():
+            o, h = model.generate(images_clip.to(dev), ids.to(dev), kw["max_new_tokens"], kw["forced_answer"])
+            ev = model.evaluate(images_clip.to(dev), images.to(dev), ids.to(dev), sizes, sizes, **kw)
+        return o.cpu(), h.float().cpu(), [m.float().cpu() for m in ev[1]]
+    for free_running in (False, True):
+        model.decode_graphs = False
+        ref = run(free_running)
+        model.decode_graphs = True
+        cap = run(free_running)      # captures
+        rep = run(free_running)      # replays
+        assert len(model._graphs) > 0
+        for got in (cap, rep):
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+            assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))

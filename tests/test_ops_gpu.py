@@ -88,6 +88,38 @@ def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
         _close(got, F.silu(x.float() @ wg.float().T) * (x.float() @ wu.float().T), 1.2e-2, f"cfg{tile_cfg} swiglu")
 
 
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1003, 256), (320, 11008), (64, 128)])
+def test_gemm_skinny(dev, M, N, K):
+    """M <= 16 takes the weight-streaming kernel (one workgroup per 16 weight rows, K split over 4 waves): every
+    epilogue feature, ragged N, gather and scatter maps."""
+    ops = _ops()
+    x = _rand((M + 5, K), dev, torch.bfloat16, 15)
+    w = _rand((N, K), dev, torch.bfloat16, 16, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 17)
+    resid = _rand((M, N), dev, torch.bfloat16, 18)
+    y = x[:M].float() @ w.float().T + bias
+    _close(ops.linear(x[:M], w, bias=bias, act=1, resid=resid), F.gelu(y) + resid.float(), 1.2e-2, "skinny gelu+resid")
+    _close(ops.linear(x[:M], w, out_dtype=torch.float32), x[:M].float() @ w.float().T, 2e-3, "skinny f32 out")
+    a_map = torch.randint(0, M + 5, (M,), device=dev).to(torch.int32)
+    _close(ops.linear(x, w, bias=bias, a_map=a_map), x.float()[a_map.long()] @ w.float().T + bias, 1.2e-2, "skinny gather")
+    perm = torch.randperm(M + 3, device=dev)[:M].to(torch.int32)
+    if M > 1:
+        perm[0] = -1
+    out = torch.zeros((M + 3, N), dtype=torch.bfloat16, device=dev)
+    ops.linear(x[:M], w, bias=bias, row_map=perm, out=out)
+    ref = torch.zeros((M + 3, N), dtype=torch.float32, device=dev)
+    keep = perm >= 0
+    ref[perm[keep].long()] = y[keep]
+    _close(out, ref, 1.2e-2, "skinny row_map")
+    if N % 32 == 0:
+        F_ = N // 2
+        wg, wu = w[:F_], w[F_:]
+        wi = torch.stack([wg.reshape(F_ // 16, 16, K), wu.reshape(F_ // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+        got = ops.linear(x[:M], wi, swiglu=True)
+        _close(got, F.silu(x[:M].float() @ wg.float().T) * (x[:M].float() @ wu.float().T), 1.2e-2, "skinny swiglu")
+
+
 def test_gemm_bf16_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a swapped C layout (cdna guide §3)."""
     ops = _ops()

@@ -21,6 +21,11 @@ SHAPES = [  # name, M, N, K, kind
     ("llama o       B64", 64 * 291, 4096, 4096, "resid"),
     ("llama gate/up B64", 64 * 291, 22016, 4096, "swiglu"),
     ("llama down    B64", 64 * 291, 4096, 11008, "resid"),
+    ("llama qkv dec B1", 1, 12288, 4096, "none"),
+    ("llama o   dec B1", 1, 4096, 4096, "resid"),
+    ("llama gu  dec B8", 8, 22016, 4096, "swiglu"),
+    ("llama dwn dec B8", 8, 4096, 11008, "resid"),
+    ("13b qkv   dec B8", 8, 15360, 5120, "none"),
     ("llama qkv dec B64", 64, 12288, 4096, "none"),
     ("llama gu dec  B64", 64, 22016, 4096, "swiglu"),
     ("clip qkv      B64", 64 * 257, 3072, 1024, "bias"),

@@ -30,7 +30,22 @@ def main():
         return (time.perf_counter() - t0) / n * 1e3, out
     ms_sam, emb = t(lambda: model.get_visual_embs_u8(frames, (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)))
     ms_clip, img = t(lambda: model.encode_images(clip))
+    model.decode_graphs = False
+    ms_gen_eager, _ = t(lambda: model.generate(clip, ids, 8, forced))
+    model.decode_graphs = True
     ms_gen, (out_ids, hidden) = t(lambda: model.generate(clip, ids, 8, forced))
+    print(f"generate eager {ms_gen_eager:.1f} ms | with decode graphs {ms_gen:.1f} ms")
+    cache = model._persistent_cache(1, 291 + 8)
+    cache["len"] = 291
+    nxt = torch.zeros((1,), dtype=torch.long, device=dev)
+
+    def one_step(graph):
+        model.decode_graphs = graph
+        cache["len"] = 291
+        return model._decode_step(nxt, cache)
+    ms_e, _ = t(lambda: one_step(False), 10)
+    ms_g, _ = t(lambda: one_step(True), 10)
+    print(f"one decode step: eager {ms_e:.2f} ms | graph replay {ms_g:.2f} ms")
     ms_seg, (pred, fidx, counts) = t(lambda: model.seg_embeddings(out_ids, hidden))
     ms_dec, dec = t(lambda: model.sam_decoder.decode(emb, fidx, pred))
     ms_post, _ = t(lambda: model.sam_decoder.postprocess(dec[0], (S, S), (S, S)))
