@@ -57,6 +57,7 @@ class SamEncoderHip:
         self.w_neck2 = sd[E + ".neck.2.weight"].permute(0, 2, 3, 1).reshape(s.out_chans, -1).to(dev, dtype).contiguous()
         self.neck3 = (_f32(sd[E + ".neck.3.weight"], dev), _f32(sd[E + ".neck.3.bias"], dev))
         self._maps = {}
+        self.fused_global_attention = True   # global blocks: rel-pos terms computed inside the attention kernel
         self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
 
     @staticmethod
@@ -148,6 +149,8 @@ class SamEncoderHip:
                 v = q5[:, :, 2].permute(0, 2, 1, 3)
                 if not blk["global"] and ops.window_attention_supported(q, S):
                     a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
+                elif blk["global"] and self.fused_global_attention and ops.global_attention_supported(q, S):
+                    a = ops.global_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
                 else:
                     relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
                     a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
