@@ -38,6 +38,7 @@ class LisaMI355:
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
         self.decode_graphs = True
         self._graphs = {}
+        self._graph_pool = None   # one memory pool shared by every captured step (replays never overlap)
         self._caches = {}
         sd, dev = state_dict, self.device
         assert cfg.clip.n_patches == N_IMG_PAD + 1, "the reference hard-codes 256 image tokens (LISA.py:461)"
@@ -118,15 +119,17 @@ class LisaMI355:
         key = (B, cache["tmax"], pos)
         ent = self._graphs.get(key)
         if ent is None:
-            if len(self._graphs) >= 1024:
+            if len(self._graphs) >= 256:
                 self._graphs.clear()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
             static_in = nxt.clone()
             # warm-up outside the capture (lazy one-time work inside the ops), then rewind the cache length
             self._decode_step_eager(static_in, cache)
             cache["len"] = pos
             torch.cuda.current_stream(self.device).synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
                 h1, out = self._decode_step_eager(static_in, cache)
             ent = self._graphs[key] = (g, static_in, h1, out)
             cache["len"] = pos
