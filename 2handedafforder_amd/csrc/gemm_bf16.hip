@@ -30,6 +30,11 @@
 
 namespace {
 
+// wave priority experiments (tools/gemm_variant.py): 3 = the held-back MFMAs right after the barrier run at priority 3,
+// so the first wave through the barrier is not starved by its SIMD neighbour still streaming the previous tile (+1-3 %)
+#ifndef HAFF_GEMM_PRIO
+#define HAFF_GEMM_PRIO 3
+#endif
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
@@ -267,13 +272,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       __builtin_amdgcn_sched_group_barrier(0x008, TN * HEAD, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) {
+#if HAFF_GEMM_PRIO >= 4
+        __builtin_amdgcn_s_setprio(0);
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt+1 landed; my reads of tile kt are done
         __builtin_amdgcn_s_barrier();
+#if HAFF_GEMM_PRIO == 1
+        __builtin_amdgcn_s_setprio(3);   // the wave issuing the next tile's DMA / first reads goes ahead of MFMA streams
+#endif
         if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
         read_frags(cur ^ 1, 0);
+#if HAFF_GEMM_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
+#if HAFF_GEMM_PRIO == 2
+      __builtin_amdgcn_s_setprio(2);
+#elif HAFF_GEMM_PRIO >= 3
+      __builtin_amdgcn_s_setprio(3);
+#endif
       mfma_rows(1, HEAD, TM);
+#if HAFF_GEMM_PRIO == 2 || HAFF_GEMM_PRIO == 3
+      __builtin_amdgcn_s_setprio(0);
+#elif HAFF_GEMM_PRIO == 4
+      __builtin_amdgcn_s_setprio(1);
+#elif HAFF_GEMM_PRIO == 5
+      __builtin_amdgcn_s_setprio(2);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
