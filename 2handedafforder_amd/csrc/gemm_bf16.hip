@@ -36,7 +36,7 @@ namespace {
 #define HAFF_GEMM_PRIO 3
 #endif
 constexpr int BK = 64;
-constexpr int GROUP_M = 8;
+
 
 __device__ __attribute__((aligned(16))) unsigned int haff_zero_page[8];  // 32 B of zeros for K-tail chunks
 
@@ -48,6 +48,7 @@ struct GemmArgs {
   const void* resid; long ldr;
   const int* row_map;
   const int* a_map;   // optional gather: logical A row m is stored at A row a_map[m]
+  int group_m;        // M-tiles per raster group (L2 reuse window), chosen by the launcher
   int M, N, K;
   int act, out_f32, swiglu;
   // batched launches (blockIdx.y = z): operand z lives at base + (z / nb_inner) * s?o + (z % nb_inner) * s?i elements
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     const int t = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = t & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    const int GROUP_M = p.group_m;
     const int per_group = GROUP_M * tiles_n;
     const int g = lin / per_group;
     const int first_m = g * GROUP_M;
@@ -619,7 +621,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || (ldc & 3) || resid)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
-             bias, resid, ldr, row_map, a_map, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
+             bias, resid, ldr, row_map, a_map, 8, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (M <= 16 && (K % 128) == 0 && tile_cfg == 0) {   // weight-streaming kernel for decode-sized M
     if (swiglu) hipLaunchKernelGGL((gemm_skinny_kernel<true>), dim3((N + 31) / 32), dim3(256), 0, s, p);
@@ -640,6 +642,10 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
     const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256) * 1.22;
     big = (M >= 256 && N >= 256 && e256 > e128);
   }
+  // Raster group depth: 8 M-tiles share their A panels across the N sweep; with a long K loop (>= 5120) and few N tiles
+  // the concurrently running tiles drift apart and a 2-deep group keeps more of the sweep in the 4 MiB L2
+  // (measured +5 % on 131072x1280x5120 and 18624x4096x11008, tools/gemm_variant.py).
+  if (big && K >= 5120 && (N + 255) / 256 <= 32) p.group_m = 2;
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
 
@@ -679,6 +685,6 @@ extern "C" int haff_gemm_bf16_batched(const void* A, long lda, long sAo, long sA
   if ((K & 7) || (lda & 7) || (ldw & 7) || (sAo & 7) || (sAi & 7) || (sWo & 7) || (sWi & 7)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
-             nullptr, nullptr, 0, nullptr, nullptr, M, N, K, 0, out_f32, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
+             nullptr, nullptr, 0, nullptr, nullptr, 8, M, N, K, 0, out_f32, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
   return launch_gemm<128, 128, 2, 2>(p, reinterpret_cast<hipStream_t>(stream), nb_outer * nb_inner);
 }

@@ -8,7 +8,7 @@ import sys
 import torch
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(78400, 3840, 1280), (65536, 1280, 5120), (18624, 12288, 4096), (8192, 8192, 8192)]
+SHAPES = [(131072, 1280, 5120), (18624, 4096, 4096), (18624, 4096, 11008), (16448, 1024, 4096), (16448, 4096, 1024), (65536, 1280, 5120)]
 
 
 def load(name):
