@@ -216,9 +216,11 @@ def main():
     if rank == 0:
         flops_frame = SURVEY_FLOPS.get(cfg.name) or hflops.frame_flops(cfg, args.text_tokens, args.n_gen)["total"]
         model.overlap_streams = False  # per-launch event timing needs the two HIP streams serialised
+        model.decode_graphs = False    # ... and every GEMM launch to go through the metered wrapper (no graph replays)
         with GemmMeter() as meter:
             step()
         model.overlap_streams = True
+        model.decode_graphs = True
         n_launch, gemm_ms, gemm_fl, gemm_bytes = meter.summary()
         # HBM traffic of the dominant kernel cannot be sampled from inside this process: it comes from the two
         # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of THIS command, summarised by tools/pmc_traffic.py into
