@@ -49,6 +49,11 @@ struct GemmArgs {
   const int* row_map;
   const int* a_map;   // optional gather: logical A row m is stored at A row a_map[m]
   int group_m;        // M-tiles per raster group (L2 reuse window), chosen by the launcher
+  // LayerNorm / RMSNorm folded into the product (gamma pre-multiplied into W, beta into bias by the caller):
+  //   C[m][n] = act( rstd_m * (acc[m][n] - mean_m * colsum[n]) + bias[n] ),  ln_stats[m] = {mean_m, rstd_m}
+  // colsum[n] = sum_k W[n][k] (of the gamma-scaled, bf16-rounded weights); null colsum (RMSNorm): mean term dropped.
+  const float* ln_stats;
+  const float* ln_colsum;
   int M, N, K;
   int act, out_f32, swiglu;
   // batched launches (blockIdx.y = z): operand z lives at base + (z / nb_inner) * s?o + (z % nb_inner) * s?i elements
@@ -370,6 +375,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         bias_r[ni][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
       }
   }
+  // folded norm: this wave's {mean, rstd} rows and column sums go through LDS (free stage memory past the staging
+  // images) so the per-pass code reads them back instead of holding 2*TM + 4*TN more registers
+  static_assert(WM * WN * 16 * RS * 4 <= STAGE_ELEMS * 2 && WM * WN * (2 * WROWS + WNC) * 4 <= STAGE_ELEMS * 2, "epilogue LDS");
+  float* sStat = reinterpret_cast<float*>(smem + STAGE_ELEMS) + wave * (2 * WROWS + WNC);   // stage 1 (staging images: stage 0)
+  float* sCsum = sStat + 2 * WROWS;
+  if (p.ln_stats) {
+#pragma unroll
+    for (int h = 0; h < WROWS / 64; ++h) {
+      const int m = min(m_wave + h * 64 + lane, p.M - 1);
+      const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)m);
+      *reinterpret_cast<float2*>(sStat + 2 * (h * 64 + lane)) = st;
+    }
+#pragma unroll
+    for (int h = 0; h < WNC / 64; ++h) {
+      const int n = n_wave_in + h * 64 + lane;
+      sCsum[h * 64 + lane] = (p.ln_colsum && n < p.N) ? p.ln_colsum[n] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   // output row of wave-row (lane) and (lane + 64): -1 = dropped. Distributed to the read-back lanes by ds_bpermute.
   int orow_l[WROWS / 64];
 #pragma unroll
@@ -401,6 +425,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     float* row = sEp + fr * RS + fh * 4;
+    if (p.ln_stats) {   // rstd * (acc - mean * colsum) in place; bias / activation follow as usual
+      const float2 st = *reinterpret_cast<const float2*>(sStat + 2 * (mi * 16 + fr));
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        float cs[4];
+        load4(sCsum + ni * 16 + fh * 4, cs);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = (acc[ni][mi][r] - st.x * cs[r]) * st.y;
+      }
+    }
     if (!SWIGLU) {
       // the activation is resolved ONCE per pass (wave-uniform switch) so the per-element code is straight-line
       auto write_side = [&](auto tag) {
@@ -565,6 +599,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     if (orow < 0) return;
   }
   const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
+  if (p.ln_stats) {
+    const float mean = p.ln_stats[2 * m], rstd = p.ln_stats[2 * m + 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = min(n0 + t * 16 + 4 * fh + r, p.N - 1);
+        o[t][r] = (o[t][r] - (p.ln_colsum ? mean * p.ln_colsum[n] : 0.f)) * rstd;
+      }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float val;
@@ -615,13 +659,14 @@ extern "C" int haff_gemm_trace_read(unsigned long long* host, int n_words) {
 
 static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, void* C,
                           long ldc, const float* bias, const void* resid, long ldr, const int* row_map, int M, int N,
-                          int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {
+                          int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream,
+                          const float* ln_stats = nullptr, const float* ln_colsum = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return HAFF_ERR_BAD_ARG;
   if ((K & 7) || (lda & 7) || (ldw & 7)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || (ldc & 3) || resid)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
-             bias, resid, ldr, row_map, a_map, 8, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
+             bias, resid, ldr, row_map, a_map, 8, ln_stats, ln_colsum, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (M <= 16 && (K % 128) == 0 && tile_cfg == 0) {   // weight-streaming kernel for decode-sized M
     if (swiglu) hipLaunchKernelGGL((gemm_skinny_kernel<true>), dim3((N + 31) / 32), dim3(256), 0, s, p);
@@ -676,6 +721,19 @@ extern "C" int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, 
                         0, stream);
 }
 
+// Product with a LayerNorm / RMSNorm folded in (see GemmArgs::ln_stats): the normalised activations never exist in
+// HBM. The caller scales W's columns by gamma, adds W.beta to the bias (haff side: sam.py / llava.py at load time) and
+// passes the per-row {mean, rstd} from haff_row_stats. Replaces norm1->qkv and norm2->lin1 of the SAM blocks
+// (image_encoder.py:179,191), input/post-attention RMSNorm -> qkv / gate-up of Llama, layer_norm1/2 of CLIP.
+extern "C" int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                                 const void* resid, long ldr, const int* row_map, const float* ln_stats,
+                                 const float* ln_colsum, int M, int N, int K, int act, int out_f32, int swiglu,
+                                 void* stream) {
+  if (!ln_stats) return HAFF_ERR_BAD_ARG;
+  return gemm_bf16_impl(A, lda, nullptr, 0, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0,
+                        stream, ln_stats, ln_colsum);
+}
+
 // Batched C_z = A_z . W_z^T (no epilogue): z = zo * nb_inner + zi, operand offsets zo * s?o + zi * s?i (elements).
 // Used by the training path for attention-shaped products over (batch, head) (scores, P.V and their gradients).
 extern "C" int haff_gemm_bf16_batched(const void* A, long lda, long sAo, long sAi, const void* W, long ldw, long sWo,
@@ -685,6 +743,6 @@ extern "C" int haff_gemm_bf16_batched(const void* A, long lda, long sAo, long sA
   if ((K & 7) || (lda & 7) || (ldw & 7) || (sAo & 7) || (sAi & 7) || (sWo & 7) || (sWi & 7)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
-             nullptr, nullptr, 0, nullptr, nullptr, 8, M, N, K, 0, out_f32, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
+             nullptr, nullptr, 0, nullptr, nullptr, 8, nullptr, nullptr, M, N, K, 0, out_f32, 0, nb_inner, sAo, sAi, sWo, sWi, sCo, sCi};
   return launch_gemm<128, 128, 2, 2>(p, reinterpret_cast<hipStream_t>(stream), nb_outer * nb_inner);
 }

@@ -110,6 +110,72 @@ int launch_norm(const void* x, long ldx, void* y, long ldy, const float* w, cons
   return HAFF_ERR_UNSUPPORTED;
 }
 
+// Row statistics only: stats[row] = {mean, rstd} (RMS: {0, rsqrt(mean(x^2) + eps)}). Half the HBM traffic of the norm
+// itself (no normalised copy is written); the consumer GEMM applies them in its epilogue (haff_gemm_bf16_ln).
+template <typename T, int NCH, bool RMS>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* x, long ldx, float* stats, int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < C) {
+      load8(x + (long)row * ldx + c, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += RMS ? v[i][j] * v[i][j] : v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  sum = wave_sum(sum);
+  float mean = 0.f, rstd;
+  if (RMS) {
+    rstd = 1.0f / sqrtf(sum / (float)C + eps);
+  } else {
+    mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dlt = v[i][j] - mean;
+          sq += dlt * dlt;
+        }
+      }
+    }
+    sq = wave_sum(sq);
+    rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  }
+  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (long)row) = make_float2(mean, rstd);
+}
+
+template <typename T, bool RMS>
+int launch_stats(const void* x, long ldx, float* stats, int rows, int C, float eps, hipStream_t s) {
+  const int nch = (C + 511) / 512;
+  dim3 grid((rows + 3) / 4), block(256);
+  const T* xp = reinterpret_cast<const T*>(x);
+#define HAFF_STATS_CASE(N)                                                                             \
+  if (nch <= N) {                                                                                      \
+    hipLaunchKernelGGL((row_stats_kernel<T, N, RMS>), grid, block, 0, s, xp, ldx, stats, rows, C, eps); \
+    return haff_check_launch();                                                                        \
+  }
+  HAFF_STATS_CASE(1)
+  HAFF_STATS_CASE(2)
+  HAFF_STATS_CASE(3)
+  HAFF_STATS_CASE(4)
+  HAFF_STATS_CASE(8)
+  HAFF_STATS_CASE(10)
+  HAFF_STATS_CASE(16)
+#undef HAFF_STATS_CASE
+  return HAFF_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 // dtype: 0 = bf16, 1 = f32 (x and y). w, b fp32 [C]. C % 8 == 0, C <= 8192, ldx/ldy % 8 == 0.
@@ -127,4 +193,14 @@ extern "C" int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const fl
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return dtype == 0 ? launch_norm<bf16_t, true>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s)
                     : launch_norm<float, true>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s);
+}
+
+// stats[rows][2] = {mean, rstd} of each row (rms != 0: {0, rsqrt(mean(x^2) + eps)} — LlamaRMSNorm). dtype: 0 = bf16,
+// 1 = f32. For haff_gemm_bf16_ln, which applies the normalisation inside the consumer product.
+extern "C" int haff_row_stats(const void* x, long ldx, float* stats, int rows, int C, float eps, int rms, int dtype,
+                              void* stream) {
+  if (rows <= 0 || C <= 0 || (C & 7) || (ldx & 7) || !stats) return HAFF_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == 0) return rms ? launch_stats<bf16_t, true>(x, ldx, stats, rows, C, eps, s) : launch_stats<bf16_t, false>(x, ldx, stats, rows, C, eps, s);
+  return rms ? launch_stats<float, true>(x, ldx, stats, rows, C, eps, s) : launch_stats<float, false>(x, ldx, stats, rows, C, eps, s);
 }

@@ -32,8 +32,37 @@ def _req(t, name):
         raise RuntimeError(f"{name} must live in HBM (cuda tensor); the hot path has no CPU fallback")
 
 
+def row_stats(x, eps, rms=False):
+    """Per-row {mean, rstd} (rms: {0, rsqrt(mean(x^2)+eps)}) as fp32 [rows, 2] — the normalisation itself is applied
+    by linear(..., ln_stats=, ln_colsum=)."""
+    lib = load_library()
+    _req(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    stats = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    rc = lib.haff_row_stats(x.data_ptr(), x.stride(0), stats.data_ptr(), x.shape[0], x.shape[1], float(eps),
+                            1 if rms else 0, _dt(x), _stream())
+    check(rc, "haff_row_stats")
+    return stats
+
+
+def fold_norm(w, gamma, beta=None, bias=None):
+    """Fold y = norm(x) * gamma + beta followed by y @ w.T + bias into the weights: returns (w_bf16 = bf16(w * gamma),
+    colsum fp32 [N] of the ROUNDED folded weights, bias' = bias + w @ beta)."""
+    wf = (w.float() * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    colsum = wf.float().sum(1).contiguous()
+    b = None
+    if beta is not None or bias is not None:
+        b = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
+        if bias is not None:
+            b += bias.float()
+        if beta is not None:
+            b += w.float() @ beta.float()
+        b = b.contiguous()
+    return wf, colsum, b
+
+
 def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, out_rows=None, out_dtype=None,
-           swiglu=False, tile_cfg=0, a_map=None):
+           swiglu=False, tile_cfg=0, a_map=None, ln_stats=None, ln_colsum=None):
     """y = epi(x @ w.T): x [M,K] (row stride free, unit inner stride), w [N,K], bias fp32 [N] or None.
 
     epilogue order: +bias -> act -> +resid (resid indexed like out). row_map (int32 [M]) redirects output
@@ -60,7 +89,16 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
         assert bias.dtype == torch.float32 and bias.numel() == N
     if row_map is not None:
         assert row_map.dtype == torch.int32 and row_map.numel() == M
-    if a_map is not None:
+    if ln_stats is not None:
+        assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a_map is None
+        assert ln_stats.dtype == torch.float32 and ln_stats.shape == (M, 2) and ln_stats.is_contiguous()
+        if ln_colsum is not None:
+            assert ln_colsum.dtype == torch.float32 and ln_colsum.numel() == N
+        rc = lib.haff_gemm_bf16_ln(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
+                                   out.stride(0), _p(bias), _p(resid), 0 if resid is None else resid.stride(0),
+                                   _p(row_map), ln_stats.data_ptr(), _p(ln_colsum), M, N, K, act,
+                                   1 if out.dtype == torch.float32 else 0, 1 if swiglu else 0, _stream())
+    elif a_map is not None:
         assert w.dtype == torch.bfloat16
         rc = lib.haff_gemm_bf16_gather(x.data_ptr(), x.stride(0), a_map.data_ptr(), x.shape[0], w.data_ptr(),
                                        w.stride(0), out.data_ptr(), out.stride(0), _p(bias), _p(resid),

@@ -44,6 +44,14 @@ int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C
 int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, void* C,
                           long ldc, const float* bias, const void* resid, long ldr, const int* row_map, int M, int N,
                           int K, int act, int out_f32, int swiglu, void* stream);
+/* haff_gemm_bf16 with a LayerNorm / RMSNorm folded into the product: the normalised activations never exist in HBM.
+ *   C[m][n] = act( rstd_m * (sum_k A[m][k] W'[n][k] - mean_m * colsum[n]) + bias'[n] )
+ * with W' = W * gamma (column scaling, done once by the caller), bias' = bias + W.beta, colsum[n] = sum_k W'[n][k]
+ * (null for RMSNorm), ln_stats[m] = {mean_m, rstd_m} from haff_row_stats. Replaces norm1 -> qkv and norm2 -> lin1 of the
+ * SAM blocks (image_encoder.py:179,191), the RMSNorms in front of Llama's qkv / gate-up, CLIP's layer_norm1/2. */
+int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                      const void* resid, long ldr, const int* row_map, const float* ln_stats, const float* ln_colsum,
+                      int M, int N, int K, int act, int out_f32, int swiglu, void* stream);
 /* parity-mode twin: everything f32. K % 4 == 0, lda/ldw % 4 == 0. */
 int haff_gemm_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, const float* bias,
                   const float* resid, long ldr, const int* row_map, int M, int N, int K, int act, int swiglu,
@@ -105,6 +113,8 @@ int haff_layernorm(const void* x, long ldx, void* y, long ldy, const float* w, c
                    int rows, int C, float eps, int dtype, void* stream);
 int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const float* w, int rows, int C, float eps, int dtype,
                  void* stream);
+/* per-row {mean, rstd} only (rms != 0: {0, rsqrt(mean(x^2)+eps)}): stats f32 [rows][2]; dtype 0 = bf16, 1 = f32. */
+int haff_row_stats(const void* x, long ldx, float* stats, int rows, int C, float eps, int rms, int dtype, void* stream);
 
 /* ---- data movement ------------------------------------------------------------------------------------------ */
 /* conv(k=s=P) rows: x [B][Cin][Hin][Win] -> out [B*gh*gw][Kp], column (c*P+ky)*P+kx, zero beyond Cin*P*P.

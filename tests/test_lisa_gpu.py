@@ -202,6 +202,7 @@ def test_sam_vith_width_windowed_blocks(dev):
     hw.round_to_bf16_(sd)
     rng = np.random.default_rng(12)
     images = torch.from_numpy(rng.standard_normal((2, 3, 1024, 1024), dtype=np.float32)).to(torch.bfloat16).float()
+    cfg.sam.fold_norms = True        # also build the norm-folded weights (haff_gemm_bf16_ln path, checked below)
     enc = SamEncoderHip(sd, cfg.sam, torch.bfloat16, dev)
     with torch.no_grad():
         taps_c, taps_p, taps_ref = {}, {}, {}
@@ -221,6 +222,13 @@ def test_sam_vith_width_windowed_blocks(dev):
         assert r <= 5e-2
     print(f"compact vs padded {d_cp:.3e}, compact vs oracle {d_ref:.3e}")
     assert d_cp <= 2e-2 and d_ref <= 1e-1
+    # norms folded into qkv / lin1 (row statistics + GEMM epilogue) against the same oracle
+    with torch.no_grad():
+        enc.compact_windows, enc.fold_norms = True, True
+        out_f = enc(images.to(dev)).float().cpu()
+    d_f = (out_f - ref_cl).abs().max().item() / scale
+    print(f"folded norms vs oracle {d_f:.3e}")
+    assert d_f <= 1e-1 and (out_f - out_c).abs().max().item() / scale <= 5e-2
 
 
 def test_decode_graphs_match_eager(dev):

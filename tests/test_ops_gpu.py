@@ -120,6 +120,50 @@ def test_gemm_skinny(dev, M, N, K):
         _close(got, F.silu(x[:M].float() @ wg.float().T) * (x[:M].float() @ wu.float().T), 1.2e-2, "skinny swiglu")
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 512, 1280), (5, 1003, 256), (16, 320, 1280), (300, 384, 128), (4096, 2560, 1280)])
+@pytest.mark.parametrize("rms", [False, True])
+def test_gemm_folded_norm(dev, M, N, K, rms):
+    """haff_row_stats + haff_gemm_bf16_ln == LayerNorm / RMSNorm followed by the Linear (every tile + the skinny path),
+    with activation, residual and an output row map; SwiGLU with RMSNorm as Llama's gate/up uses it."""
+    ops = _ops()
+    x = (_rand((M, K), dev, torch.float32, 19, 2.0) + 0.5).to(torch.bfloat16)
+    w = _rand((N, K), dev, torch.bfloat16, 20, K ** -0.5)
+    gamma = _rand((K,), dev, torch.float32, 21, 0.2) + 1.0
+    beta = None if rms else _rand((K,), dev, torch.float32, 22, 0.3)
+    bias = None if rms else _rand((N,), dev, torch.float32, 23)
+    resid = _rand((M, N), dev, torch.bfloat16, 24)
+    eps = 1e-5
+    xf = x.float()
+    if rms:
+        xn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * gamma
+        st_ref = torch.stack([torch.zeros(M, device=dev), torch.rsqrt(xf.pow(2).mean(-1) + eps)], 1)
+    else:
+        xn = F.layer_norm(xf, (K,), gamma, beta, eps)
+        st_ref = torch.stack([xf.mean(-1), torch.rsqrt(xf.var(-1, unbiased=False) + eps)], 1)
+    stats = ops.row_stats(x, eps, rms=rms)
+    _close(stats, st_ref, 1e-5, "row_stats")
+    wf, colsum, bf = ops.fold_norm(w, gamma, beta, bias)
+    y = xn @ w.float().T + (bias if bias is not None else 0.0)
+    for cfg in ((0,) if M <= 16 else (0, 1, 2)):
+        if cfg == 2 and K % 64:
+            continue
+        got = ops.linear(x, wf, bias=bf, act=1, resid=resid, ln_stats=stats, ln_colsum=None if rms else colsum, tile_cfg=cfg)
+        _close(got, F.gelu(y) + resid.float(), 2e-2, f"folded norm cfg{cfg} gelu+resid")
+    perm = torch.randperm(M + 3, device=dev)[:M].to(torch.int32)
+    out = torch.zeros((M + 3, N), dtype=torch.bfloat16, device=dev)
+    ops.linear(x, wf, bias=bf, row_map=perm, out=out, ln_stats=stats, ln_colsum=None if rms else colsum)
+    ref = torch.zeros((M + 3, N), dtype=torch.float32, device=dev)
+    ref[perm.long()] = y
+    _close(out, ref, 2e-2, "folded norm row_map")
+    if rms and N % 32 == 0:
+        F_ = N // 2
+        wg, wu = w[:F_], w[F_:]
+        wi = torch.stack([wg.reshape(F_ // 16, 16, K), wu.reshape(F_ // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+        wif, _, _ = ops.fold_norm(wi, gamma)
+        got = ops.linear(x, wif, swiglu=True, ln_stats=stats)
+        _close(got, F.silu(xn @ wg.float().T) * (xn @ wu.float().T), 2e-2, "folded rmsnorm swiglu")
+
+
 def test_gemm_bf16_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a swapped C layout (cdna guide §3)."""
     ops = _ops()
