@@ -1,6 +1,7 @@
 """CPU-side checks: the C-ABI library builds/loads here (hipcc cross-compiles gfx950 without a GPU) and exports
 exactly the entry points include/haff_hip.h declares; host-side helpers behave; nothing computes on a GPU."""
 import ctypes
+import json
 import os
 import re
 
@@ -150,3 +151,35 @@ def test_evaluation_harness(tmp_path):
     assert r3["count"] == 1 and abs(r3["iou"] - 16 / union.sum()) < 1e-9 and r3["iocm"] == 1.0
     assert abs(r7["iou"] - 9 / union.sum()) < 1e-9 and r7["iocm"] == 1.0
     assert res["best"]["threshold"] == "0.3" and res["mean_average_precision"] == 1.0
+
+
+def test_merge_lora_and_reload(tmp_path):
+    """merge_lora.py (merge_lora_weights_and_save_hf_model.py:146-155): W += (alpha/r) B A on q/v_proj, trained tensors
+    override the base, vision_tower keys dropped, sharded safetensors + index + config read back by checkpoint.py."""
+    from haff import checkpoint, merge_lora
+    cfg = hcfg.tiny()
+    base = weights.make_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(4)
+    r, alpha, H = 4, 8, cfg.llm.hidden
+    trained = {"model.embed_tokens.weight": torch.randn(base["model.embed_tokens.weight"].shape, generator=g),
+               "lm_head.weight": torch.randn(base["lm_head.weight"].shape, generator=g)}
+    for i in range(cfg.llm.layers):
+        for n in ("q_proj", "v_proj"):
+            trained[f"model.layers.{i}.self_attn.{n}.lora_A"] = torch.randn((r, H), generator=g) * 0.1
+            trained[f"model.layers.{i}.self_attn.{n}.lora_B"] = torch.randn((H, r), generator=g) * 0.1
+    merged = merge_lora.merge_state_dict(base, trained, r, alpha, torch.float32)
+    assert not any("lora_" in k or "vision_tower" in k for k in merged)
+    k = "model.layers.1.self_attn.v_proj"
+    want = base[k + ".weight"] + (alpha / r) * trained[k + ".lora_B"] @ trained[k + ".lora_A"]
+    assert torch.allclose(merged[k + ".weight"], want, atol=1e-6)
+    assert torch.equal(merged["model.layers.1.self_attn.k_proj.weight"], base["model.layers.1.self_attn.k_proj.weight"])
+    assert torch.equal(merged["lm_head.weight"], trained["lm_head.weight"])
+    files = merge_lora.save_pretrained(merged, str(tmp_path / "out"), merge_lora.hf_config(cfg, torch.float32),
+                                       max_shard_bytes=4 << 20)
+    assert len(files) > 1                                   # sharding exercised
+    back = checkpoint.load_hf_dir(str(tmp_path / "out"))
+    assert set(back) == set(merged) and all(torch.equal(back[kk], merged[kk]) for kk in merged)
+    idx = json.load(open(tmp_path / "out" / "model.safetensors.index.json"))
+    assert set(idx["weight_map"]) == set(merged)
+    with pytest.raises(ValueError):
+        merge_lora.merge_state_dict(base, trained, 8, alpha)

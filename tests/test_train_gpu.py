@@ -137,3 +137,31 @@ def test_train_ds_cli_runs_logs_checkpoints_and_resumes(dev, tmp_path, capsys):
     train_ds.main(argv[:3] + ["2"] + argv[4:])  # epochs=2 -> resumes at epoch 1
     out = capsys.readouterr().out
     assert "resume training from" in out and "start from epoch 1" in out and "Epoch: [1][1/2]" in out
+
+
+def test_merged_checkpoint_reproduces_lora_model(dev):
+    """train -> merge -> serve: the Llama stack of the LoRA model (adapters active, eval mode) and a plain LlamaHip built
+    from merge_lora.merge_state_dict's output give the same hidden states (merge_lora_weights_and_save_hf_model.py:146-149)."""
+    import haff  # noqa: F401
+    from haff import config as hcfg, merge_lora, weights as hw
+    from haff.llava import LlamaHip
+    from haff.train_model import LisaTrainable
+    cfg = hcfg.tiny()
+    sd = hw.round_to_bf16_(hw.make_state_dict(cfg, 21))
+    r, alpha = 8, 16
+    m = LisaTrainable(cfg, sd, dtype=torch.bfloat16, device=dev, lora_r=r, lora_alpha=alpha, lora_init_b_zero=False).eval()
+    B, T, H = 2, 24, cfg.llm.hidden
+    x = (torch.randn((B * T, H), generator=torch.Generator().manual_seed(5)) * 0.5).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        ref = m._llm(x.clone(), B, T).float().cpu()
+        merged = merge_lora.merge_state_dict(sd, m.state_dict(), r, alpha, torch.bfloat16)
+        llm = LlamaHip(merged, cfg.llm, torch.bfloat16, dev)
+        got = llm.forward(x.view(B, T, H).clone(), llm.new_cache(B, T)).float().cpu().view(B * T, H)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"merged vs LoRA-active hidden rel {err:.3e}")
+    assert err <= 3e-2
+    # and the adapters do change the result (the test would be vacuous with B = 0)
+    base = LlamaHip(sd, cfg.llm, torch.bfloat16, dev)
+    with torch.no_grad():
+        plain = base.forward(x.view(B, T, H).clone(), base.new_cache(B, T)).float().cpu().view(B * T, H)
+    assert (plain - ref).abs().max().item() / ref.abs().max().item() > 5 * err
