@@ -183,3 +183,32 @@ def test_merge_lora_and_reload(tmp_path):
     assert set(idx["weight_map"]) == set(merged)
     with pytest.raises(ValueError):
         merge_lora.merge_state_dict(base, trained, 8, alpha)
+
+
+def test_aff_records_dataset_feeds_collate():
+    """aff_dataset.AffRecordsDataset (aff_dataset.py:198-280 on HF-layout records) -> train_ds.collate_fn: contour masks,
+    templates, preprocessing shapes, taxonomy vectors, [SEG] in the supervised span."""
+    from haff import aff_dataset, checkpoint, train_ds
+    cfg = hcfg.tiny()
+    rng = np.random.default_rng(0)
+    sq = [[10, 10], [30, 10], [30, 25], [10, 25]]
+    recs = [{"narration": b"Cut The Bread", "inpainted": rng.integers(0, 255, (48, 64, 3), dtype=np.uint8), "taxonomy": [0, 0, 1, 0],
+             "masks": {"aff_left": [sq], "aff_right": [], "original_size": (48, 64)}},
+            {"text": "open bottle", "image": rng.integers(0, 255, (48, 64, 3), dtype=np.uint8), "taxonomy": 1,
+             "masks": {"aff_left": [], "aff_right": [[[40, 5], [60, 5], [50, 40]]], "original_size": (48, 64)}}]
+    m = aff_dataset.recreate_mask_from_contours([sq], (48, 64))
+    assert m.shape == (48, 64) and m[10:26, 10:31].all() and m.sum() == 16 * 21 and m.dtype == np.uint8
+    ds = aff_dataset.AffRecordsDataset(recs, cfg, samples_per_epoch=7, seed=3)
+    assert len(ds) == 7
+    items = [ds[i] for i in range(4)]
+    S = cfg.sam.img_size
+    for it in items:
+        _, image, clip, convs, ml, mr, tax, label, resize, questions, classes, inference = it
+        assert image.shape == (3, S, S) and clip.shape == (3, cfg.clip.image, cfg.clip.image)
+        assert ml.shape == (1, 48, 64) and mr.shape == (1, 48, 64) and len(tax) == 4 and abs(sum(tax) - 1) < 1e-9
+        assert max(resize) == S and "[SEG]" in convs[0] and "<image>" in convs[0] and classes[0].lower() in questions[0]
+        assert set(torch.unique(label["left"]).tolist()) <= {0, 255} and inference is False
+    tok = checkpoint.ByteTokenizer(cfg)
+    batch = train_ds.collate_fn(items, tok)
+    assert batch["images"].shape == (4, 3, S, S) and batch["taxonomies_list"].shape == (4, 4)
+    assert batch["offset"].tolist() == [0, 1, 2, 3, 4] and (batch["labels"] != -100).any()
