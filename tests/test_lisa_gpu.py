@@ -255,3 +255,34 @@ def test_decode_graphs_match_eager(dev):
         for got in (cap, rep):
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
             assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))
+
+
+def test_multiple_and_missing_seg_tokens(dev):
+    """n_seg differs per sample (LISA.py:467-485 cumsum split): two [SEG] in frame 0, none in frame 1, one in frame 2 —
+    mask lists, taxonomy rows and values against the oracle (fp32 parity mode)."""
+    from haff.lisa import LisaMI355
+    from oracle import lisa_oracle as O
+    cfg, sd, images, images_clip, ids, forced = _setup("tiny", "f32", B=3, n_gen=5)
+    forced = forced.clone()
+    forced[:, :-1] = 7
+    forced[0, 1] = forced[0, 3] = cfg.seg_token_idx
+    forced[2, 2] = cfg.seg_token_idx
+    forced[:, -1] = cfg.eos_token_id
+    S = cfg.sam.img_size
+    sizes = [(S, S)] * 3
+    with torch.no_grad():
+        ref_ids, ref_l, ref_r, ref_t = O.lisa_evaluate(sd, cfg, images_clip, images, ids, sizes, sizes,
+                                                       max_new_tokens=5, forced_answer=forced, use_cache=False)
+        model = LisaMI355(cfg, sd, dtype=torch.float32, device=dev)
+        out_ids, left, right, tax = model.evaluate(images_clip.to(dev), images.to(dev), ids.to(dev), sizes, sizes,
+                                                   max_new_tokens=5, forced_answer=forced)
+    assert torch.equal(out_ids.cpu(), ref_ids)
+    assert [m.shape[0] for m in left] == [2, 0, 1] == [m.shape[0] for m in ref_l]
+    assert [t.shape for t in tax] == [t.shape for t in ref_t]
+    for got, ref in zip(left + right, ref_l + ref_r):
+        assert got.shape == ref.shape
+        if ref.numel():
+            assert (got.cpu() - ref).abs().max().item() <= 1e-3
+    for got, ref in zip(tax, ref_t):
+        if ref.numel():
+            assert (got.cpu() - ref).abs().max().item() <= 1e-4
