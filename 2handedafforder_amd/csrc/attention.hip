@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int j = 0; j < 4; ++j) {
           const int r = min(max(qw - (16 * t + 4 * fh + j) + 63, 0), 126);
           relw_r[qt][t][j] = scr[fr * SR + r] * LOG2E;
+          asm volatile("" : "+v"(relw_r[qt][t][j]));   // scale here, not in the tile loop (see the note at the entry point)
         }
       __builtin_amdgcn_wave_barrier();
       {
@@ -688,6 +689,12 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   return launch_attn<128, 0, false>(p, s);
 }
 
+// EXPERIMENTAL, not on the default path (sam.py: fused_global_attention = False). Inside the full ViT-H encoder, at two
+// workgroups per CU, this kernel intermittently produced wrong rel-pos terms for whole 16-query tiles of first-wave
+// workgroups (tests/test_fullsize_gpu.py caught it as run-to-run differences); the same launch replayed with warm
+// caches, the kernel at one workgroup per CU, and the generic BIAS == 2 kernel at the same LDS size and occupancy were
+// all stable. The cause was not found; pinning the rel_w terms in registers as soon as they are read
+// made every observed run stable, which is kept, but the generic path stays the default until the cause is known.
 // SAM GLOBAL attention (64 x 64 tokens) with the decomposed rel-pos terms computed in the kernel from the bf16 tables:
 // replaces haff_relpos_tables_bf16 + haff_attention_bf16(relh, relw) for the 4 global ViT-H blocks. q/k/v/o as in
 // haff_attention_bf16 with Nq == Nk == S*S; tab_h/tab_w: bf16 [2S-1][d] contiguous. Supported: S == 64, d == 80.

@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--text-tokens", type=int, default=32)
     ap.add_argument("--n-gen", type=int, default=8)
     ap.add_argument("--sam-chunk", type=int, default=32)
+    ap.add_argument("--overlap-streams", action="store_true",
+                    help="SAM encoder on a second HIP stream (not the product default: see lisa.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
     args = ap.parse_args()
@@ -195,6 +197,7 @@ def main():
     cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
     sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
     model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=device, sam_chunk=args.sam_chunk)
+    model.overlap_streams = bool(args.overlap_streams)
     del sd
     torch.cuda.empty_cache()
     B, S = args.batch, cfg.sam.img_size
@@ -215,12 +218,12 @@ def main():
 
     if rank == 0:
         flops_frame = SURVEY_FLOPS.get(cfg.name) or hflops.frame_flops(cfg, args.text_tokens, args.n_gen)["total"]
-        model.overlap_streams = False  # per-launch event timing needs the two HIP streams serialised
+        prev = (model.overlap_streams, model.decode_graphs)
+        model.overlap_streams = False  # per-launch event timing needs a single HIP stream
         model.decode_graphs = False    # ... and every GEMM launch to go through the metered wrapper (no graph replays)
         with GemmMeter() as meter:
             step()
-        model.overlap_streams = True
-        model.decode_graphs = True
+        model.overlap_streams, model.decode_graphs = prev
         n_launch, gemm_ms, gemm_fl, gemm_bytes = meter.summary()
         # HBM traffic of the dominant kernel cannot be sampled from inside this process: it comes from the two
         # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of THIS command, summarised by tools/pmc_traffic.py into
@@ -252,7 +255,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: %s, %d x %dx%d uint8 NHWC frames/step/GPU, %d-token prompt "
                                    "(T=%d), %d forced answer tokens with [SEG], KV-cached greedy decode, random-init weights"
                                    % (cfg.name, B, S, S, args.text_tokens, 4 + args.text_tokens + cfg.clip.n_patches - 1, args.n_gen),
-                       "frames_per_step_per_gpu": B, "parallelism": "frame-sharded replicas x%d (no collective)" % world},
+                       "frames_per_step_per_gpu": B, "parallelism": "frame-sharded replicas x%d (no collective)" % world,
+                       "hip_streams": 2 if model.overlap_streams else 1},
             "frames_per_s_per_gpu": fps / world,
             "roofline": roofline,
         }
