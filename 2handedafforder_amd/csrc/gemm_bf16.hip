@@ -534,64 +534,100 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Skinny GEMM for M <= 16 (KV-cached decode at small batch, the [SEG] MLP, decoder token projections): the product is
+// Skinny GEMM for M <= 64 (KV-cached decode steps, the [SEG] MLP, decoder token projections): the product is
 // a stream over W — HBM-bound, 2*N*K bytes — so the grid is laid out for bandwidth, not for MFMA reuse:
 // one workgroup per 16 weight rows (32 for SwiGLU pairs), its 4 waves split K into quarters, each wave streams its
-// 16 x K/4 slab straight from HBM into MFMA A-fragments (16 B per lane, 8 loads in flight), the activation rows (<= 16,
-// L2-resident) are the B operand, and the four partial 16x16 tiles meet in LDS. N = 4096 still gives 256 workgroups x
+// 16 x K/4 slab straight from HBM into MFMA A-fragments (16 B per lane), the activation rows (MT tiles of 16,
+// L2-resident) are the B operand, and the four partial tiles meet in LDS. N = 4096 still gives 256 workgroups x
 // 4 waves; the 128x128 tile launched 32 workgroups there (1.3 TB/s).
-template <bool SWIGLU>
+constexpr int skinny_batch(int nt, int mt) {   // k-steps per batch of loads: two register sets of W and x + accumulators
+  const int u = (232 - 4 * nt * mt) / (8 * (nt + mt));
+  return u >= 8 ? 8 : (u >= 4 ? 4 : 2);
+}
+
+template <int MT, int NT, bool SWIGLU>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
-  constexpr int NT = SWIGLU ? 2 : 1;   // 16-row weight tiles per workgroup
-  __shared__ float red[4][NT][64][4];
+  static_assert(!SWIGLU || (NT % 2) == 0, "SwiGLU pairs a gate tile with an up tile");
+  constexpr int U = skinny_batch(NT, MT);
+  __shared__ float red[4][MT][64][4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int fr = lane & 15, fh = lane >> 4;
   const int n0 = blockIdx.x * 16 * NT;
   const int kq = p.K >> 2;                     // K % 128 == 0: every wave gets whole 32-deep k-steps
   const int k_lo = wave * kq;
-  const bf16_t* xrow = p.A + (long)(p.a_map ? p.a_map[min(fr, p.M - 1)] : min(fr, p.M - 1)) * p.lda + k_lo + fh * 8;
+  const bf16_t* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = min(mt * 16 + fr, p.M - 1);
+    xrow[mt] = p.A + (long)(p.a_map ? p.a_map[m] : m) * p.lda + k_lo + fh * 8;
+  }
   const bf16_t* wrow[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wrow[t] = p.W + (long)min(n0 + t * 16 + fr, p.N - 1) * p.ldw + k_lo + fh * 8;
 
-  f32x4 acc[NT];
+  f32x4 acc[NT][MT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 8;                         // k-steps per batch of loads
-  for (int k = 0; k < kq; k += 32 * U) {
-    uint4 wv[NT][U], xv[U];
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Weight slab and activation fragments are streamed through two register sets each: the loads of batch b+1 (HBM for
+  // W, L2 for x) are in flight while batch b is multiplied.
+  uint4 wv[2][NT][U], xv[2][MT][U];
+  auto load = [&](int set, int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int kk = min(k + 32 * u, kq - 32);   // tail batches re-read the last step; masked below
+      const int kk = min(k + 32 * u, kq - 32);   // tail batches re-read the last step; masked at the MFMA
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wv[t][u] = *reinterpret_cast<const uint4*>(wrow[t] + kk);
-      xv[u] = *reinterpret_cast<const uint4*>(xrow + kk);
+      for (int t = 0; t < NT; ++t) wv[set][t][u] = *reinterpret_cast<const uint4*>(wrow[t] + kk);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xv[set][mt][u] = *reinterpret_cast<const uint4*>(xrow[mt] + kk);
     }
+  };
+  auto compute = [&](int set, int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (k + 32 * u < kq) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[t][u]),
-                                                           __builtin_bit_cast(bf16x8, xv[u]), acc[t], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[set][t][u]),
+                                                                 __builtin_bit_cast(bf16x8, xv[set][mt][u]), acc[t][mt], 0, 0, 0);
       }
     }
+  };
+  constexpr int KB = 32 * U;
+  load(0, 0);
+  for (int k = 0; k < kq; k += 2 * KB) {
+    if (k + KB < kq) load(1, k + KB);
+    compute(0, k);
+    if (k + KB < kq) {
+      if (k + 2 * KB < kq) load(0, k + 2 * KB);
+      compute(1, k + KB);
+    }
   }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-    store4(&red[wave][t][lane][0], v);
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  // lane holds D[n = 4*fh + r][m = fr] of each tile
+  // the four K-quarters meet in LDS, one weight tile at a time; wave w then owns activation tile w of every weight
+  // tile (lane holds D[n = 4*fh + r][m = 16*w + fr])
   float o[NT][4];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[t][r] = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r];
-  const int m = fr;
+    for (int mt = 0; mt < MT; ++mt) {
+      float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
+      store4(&red[wave][mt][lane][0], v);
+    }
+    __syncthreads();
+    if (wave < MT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        o[t][r] = red[0][wave][lane][r] + red[1][wave][lane][r] + red[2][wave][lane][r] + red[3][wave][lane][r];
+    }
+    if (t + 1 < NT) __syncthreads();
+  }
+  if (wave >= MT) return;
+  const int m = wave * 16 + fr;
   if (m >= p.M) return;
   long orow = m;
   if (p.row_map) {
@@ -609,28 +645,69 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
         o[t][r] = (o[t][r] - (p.ln_colsum ? mean * p.ln_colsum[n] : 0.f)) * rstd;
       }
   }
+  constexpr int NOUT = SWIGLU ? NT / 2 : NT;     // 16-column output tiles of this workgroup
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float val;
-    int n_out;
-    if (SWIGLU) {
-      const int ng = n0 + 4 * fh + r, nu = ng + 16;
-      const float g = o[0][r] + (p.bias ? p.bias[min(ng, p.N - 1)] : 0.f);
-      const float u = o[1][r] + (p.bias ? p.bias[min(nu, p.N - 1)] : 0.f);
-      val = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u;
-      n_out = (n0 >> 1) + 4 * fh + r;
-    } else {
-      n_out = n0 + 4 * fh + r;
-      val = apply_act(o[0][r] + (p.bias ? p.bias[min(n_out, p.N - 1)] : 0.f), p.act);
+  for (int j = 0; j < NOUT; ++j) {
+    float val[4];
+    const int nb = (SWIGLU ? (n0 >> 1) : n0) + 16 * j + 4 * fh;   // first of this lane's 4 consecutive output columns
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (SWIGLU) {
+        const int ng = n0 + 32 * j + 4 * fh + r, nu = ng + 16;
+        const float g = o[2 * j][r] + (p.bias ? p.bias[min(ng, p.N - 1)] : 0.f);
+        const float u = o[2 * j + 1][r] + (p.bias ? p.bias[min(nu, p.N - 1)] : 0.f);
+        val[r] = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u;
+      } else {
+        val[r] = apply_act(o[j][r] + (p.bias ? p.bias[min(nb + r, p.N - 1)] : 0.f), p.act);
+      }
     }
-    if (n_out >= n_total_out) continue;
+    if (nb >= n_total_out) continue;
+    const bool whole = nb + 3 < n_total_out;
     if (p.out_f32) {
-      if (p.resid) val += reinterpret_cast<const float*>(p.resid)[orow * p.ldr + n_out];
-      reinterpret_cast<float*>(p.C)[orow * p.ldc + n_out] = val;
+      float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
+      const float* rs = p.resid ? reinterpret_cast<const float*>(p.resid) + orow * p.ldr + nb : nullptr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < n_total_out) c[r] = val[r] + (rs ? rs[r] : 0.f);
     } else {
-      if (p.resid) val += bf16_to_f32(reinterpret_cast<const bf16_t*>(p.resid)[orow * p.ldr + n_out]);
-      reinterpret_cast<bf16_t*>(p.C)[orow * p.ldc + n_out] = f32_to_bf16(val);
+      bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + orow * p.ldc + nb;
+      const bf16_t* rs = p.resid ? reinterpret_cast<const bf16_t*>(p.resid) + orow * p.ldr + nb : nullptr;
+      if (whole && ((reinterpret_cast<uintptr_t>(c) & 7) == 0) && (!rs || (reinterpret_cast<uintptr_t>(rs) & 7) == 0)) {
+        if (rs) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(rs);
+          val[0] += __builtin_bit_cast(float, rv.x << 16); val[1] += __builtin_bit_cast(float, rv.x & 0xffff0000u);
+          val[2] += __builtin_bit_cast(float, rv.y << 16); val[3] += __builtin_bit_cast(float, rv.y & 0xffff0000u);
+        }
+        uint2 ov;
+        ov.x = pack_bf16x2(val[0], val[1]);
+        ov.y = pack_bf16x2(val[2], val[3]);
+        *reinterpret_cast<uint2*>(c) = ov;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < n_total_out) c[r] = f32_to_bf16(val[r] + (rs ? bf16_to_f32(rs[r]) : 0.f));
+      }
     }
+  }
+}
+
+template <int MT>
+static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
+  // Weight rows per workgroup (16 * NT): every workgroup re-reads the activations (from L2), so the bytes a launch moves
+  // are N*K*2 * (1 + MT/NT) and the fabric delivers ~7 TB/s of that mix: take the widest workgroup that still leaves
+  // >= 192 of them (fewer, wider workgroups measured slower: N = 4096 stays at 256 x 16 rows). With one activation
+  // tile (M <= 16) the narrow workgroups stream better (M = 1: 22 vs 28 us on qkv; M = 16 gate/up: 48 vs 55 us).
+  const int tiles = (N + 15) / 16;
+  const dim3 b(256);
+  const bool nt4 = MT >= 2 && tiles / 4 >= 192;
+  const bool nt2 = MT >= 2 && tiles / 2 >= 192;
+  if (swiglu) {
+    if (nt4) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 4, true>), dim3((tiles + 3) / 4), b, 0, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2, true>), dim3((tiles + 1) / 2), b, 0, s, p);
+  } else {
+    if (nt4) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 4, false>), dim3((tiles + 3) / 4), b, 0, s, p);
+    else if (nt2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2, false>), dim3((tiles + 1) / 2), b, 0, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, 1, false>), dim3(tiles), b, 0, s, p);
   }
 }
 
@@ -668,9 +745,12 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
              bias, resid, ldr, row_map, a_map, 8, ln_stats, ln_colsum, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (M <= 16 && (K % 128) == 0 && tile_cfg == 0) {   // weight-streaming kernel for decode-sized M
-    if (swiglu) hipLaunchKernelGGL((gemm_skinny_kernel<true>), dim3((N + 31) / 32), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<false>), dim3((N + 15) / 16), dim3(256), 0, s, p);
+  // weight-streaming kernel for decode-sized M; past 32 rows the 128x128 tile is faster again on very wide outputs
+  // (M = 64: gate/up 53 vs 75 us, lm_head 68 vs 84 us; qkv 49 vs 42, o_proj 46 vs 24, down 113 vs 63)
+  if (M <= 64 && (K % 128) == 0 && tile_cfg == 0 && !(M > 32 && N >= 16384)) {
+    if (M <= 16) launch_skinny<1>(p, N, swiglu, s);
+    else if (M <= 32) launch_skinny<2>(p, N, swiglu, s);
+    else launch_skinny<4>(p, N, swiglu, s);
     return haff_check_launch();
   }
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path

@@ -176,8 +176,8 @@ def cpu_baseline(cfg, text_tokens, n_gen, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="7b", choices=["7b", "13b", "tiny", "mid"])
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--text-tokens", type=int, default=32)

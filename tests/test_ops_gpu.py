@@ -88,11 +88,12 @@ def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
         _close(got, F.silu(x.float() @ wg.float().T) * (x.float() @ wu.float().T), 1.2e-2, f"cfg{tile_cfg} swiglu")
 
 
-@pytest.mark.parametrize("M", [1, 3, 8, 16])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (1003, 256), (320, 11008), (64, 128)])
+@pytest.mark.parametrize("M", [1, 3, 8, 16, 17, 31, 32, 33, 50, 64])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1003, 256), (320, 11008), (64, 128), (998, 384)])
 def test_gemm_skinny(dev, M, N, K):
-    """M <= 16 takes the weight-streaming kernel (one workgroup per 16 weight rows, K split over 4 waves): every
-    epilogue feature, ragged N, gather and scatter maps."""
+    """M <= 64 takes the weight-streaming kernel (one workgroup per 16 weight rows, K split over 4 waves, 1 / 2 / 4
+    activation tiles of 16 rows): every epilogue feature, ragged M and N (N = 998: the packed 8-byte store falls back
+    to element stores on the last column group and on odd row pitches), gather and scatter maps."""
     ops = _ops()
     x = _rand((M + 5, K), dev, torch.bfloat16, 15)
     w = _rand((N, K), dev, torch.bfloat16, 16, K ** -0.5)
@@ -120,7 +121,7 @@ def test_gemm_skinny(dev, M, N, K):
         _close(got, F.silu(x[:M].float() @ wg.float().T) * (x[:M].float() @ wu.float().T), 1.2e-2, "skinny swiglu")
 
 
-@pytest.mark.parametrize("M,N,K", [(700, 512, 1280), (5, 1003, 256), (16, 320, 1280), (300, 384, 128), (4096, 2560, 1280)])
+@pytest.mark.parametrize("M,N,K", [(700, 512, 1280), (5, 1003, 256), (16, 320, 1280), (40, 320, 1280), (300, 384, 128), (4096, 2560, 1280)])
 @pytest.mark.parametrize("rms", [False, True])
 def test_gemm_folded_norm(dev, M, N, K, rms):
     """haff_row_stats + haff_gemm_bf16_ln == LayerNorm / RMSNorm followed by the Linear (every tile + the skinny path),
@@ -144,7 +145,7 @@ def test_gemm_folded_norm(dev, M, N, K, rms):
     _close(stats, st_ref, 1e-5, "row_stats")
     wf, colsum, bf = ops.fold_norm(w, gamma, beta, bias)
     y = xn @ w.float().T + (bias if bias is not None else 0.0)
-    for cfg in ((0,) if M <= 16 else (0, 1, 2)):
+    for cfg in ((0,) if M <= 64 else (0, 1, 2)):
         if cfg == 2 and K % 64:
             continue
         got = ops.linear(x, wf, bias=bf, act=1, resid=resid, ln_stats=stats, ln_colsum=None if rms else colsum, tile_cfg=cfg)
