@@ -568,10 +568,16 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
   return v;
 }
 
+// SPLIT: the four waves of a workgroup share ONE (batch, head) and take every fourth batch of 16 keys each (small
+// B*H: one wave per head left the step latency-bound — 35 us per layer at batch 1 for 4.7 MB of K/V); their partial
+// (max, sum, P.V) meet in LDS.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
+  __shared__ float s_ml[4][2];
+  __shared__ float s_o[4][DEC_D];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x * 4 + wave;
+  const int bh = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
   if (bh >= p.B * p.H) return;
   const int b = bh / p.H, h = bh - b * p.H;
   const int g = lane >> 4, c = lane & 15;
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   float m_run = -1e30f, l_run = 0.f;
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int n_it = (p.Nk + 3) / 4;
-  for (int it0 = 0; it0 < n_it; it0 += DEC_UNROLL) {
+  for (int it0 = SPLIT ? wave * DEC_UNROLL : 0; it0 < n_it; it0 += (SPLIT ? 4 : 1) * DEC_UNROLL) {
     uint4 kr[DEC_UNROLL], vr[DEC_UNROLL];
 #pragma unroll
     for (int u = 0; u < DEC_UNROLL; ++u) {
@@ -633,9 +639,34 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     float x = o[j] * w;
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
-    o[j] = x / l;
+    o[j] = x;
   }
-  if (g == 0) store8(p.o + (long)b * p.o_sb + (long)h * p.o_sh + c * 8, o);
+  if (!SPLIT) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] /= l;
+    if (g == 0) store8(p.o + (long)b * p.o_sb + (long)h * p.o_sh + c * 8, o);
+    return;
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_o[wave][c * 8 + j] = o[j];
+    if (c == 0) { s_ml[wave][0] = m_all; s_ml[wave][1] = l; }
+  }
+  __syncthreads();
+  if (wave == 0 && g == 0) {
+    const float M = fmaxf(fmaxf(s_ml[0][0], s_ml[1][0]), fmaxf(s_ml[2][0], s_ml[3][0]));
+    float L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) {
+      const float f = __builtin_amdgcn_exp2f(s_ml[w4][0] - M);   // a wave that saw no key carries max -1e30, sum 0
+      L += s_ml[w4][1] * f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += s_o[w4][c * 8 + j] * f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] /= L;
+    store8(p.o + (long)b * p.o_sb + (long)h * p.o_sh + c * 8, acc);
+  }
 }
 
 }  // namespace
@@ -662,7 +693,8 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-    hipLaunchKernelGGL(attn_decode_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, p);
+    if (B * H <= 1024) hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * H), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_decode_kernel<false>, dim3((B * H + 3) / 4), dim3(256), 0, s, p);
     return haff_check_launch();
   }
   const int dp = d <= 64 ? 64 : (d <= 96 ? 96 : 128);

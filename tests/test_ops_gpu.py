@@ -246,6 +246,8 @@ ATTN_CASES = [
     (2, 3, 1, 1, 128, False, 0),     # decode kernel: single key
     (2, 3, 1, 7, 128, False, 0),     # decode kernel: ragged last group of 4 keys
     (5, 7, 1, 300, 128, True, 0),    # decode through the causal flag (q_pos0 = Nk-1: every key visible)
+    (1, 32, 1, 33, 128, False, 0),   # decode kernel, keys split over the 4 waves of a workgroup: the last wave sees none
+    (40, 32, 1, 50, 128, False, 0),  # decode kernel, B*H > 1024: one wave per (batch, head)
     (2, 8, 6, 4096, 16, False, 0),
     (2, 8, 4096, 6, 16, False, 0),
     (2, 8, 6, 6, 32, False, 0),
