@@ -545,16 +545,16 @@ constexpr int skinny_batch(int nt, int mt) {   // k-steps per batch of loads: tw
   return u >= 8 ? 8 : (u >= 4 ? 4 : 2);
 }
 
-template <int MT, int NT, bool SWIGLU>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+template <int MT, int NT, bool SWIGLU, int KW = 4>
+__global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
   static_assert(!SWIGLU || (NT % 2) == 0, "SwiGLU pairs a gate tile with an up tile");
   constexpr int U = skinny_batch(NT, MT);
-  __shared__ float red[4][MT][64][4];
+  __shared__ float red[KW][MT][64][4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int fr = lane & 15, fh = lane >> 4;
   const int n0 = blockIdx.x * 16 * NT;
-  const int kq = p.K >> 2;                     // K % 128 == 0: every wave gets whole 32-deep k-steps
+  const int kq = p.K / KW;                     // K % (32 * KW) == 0: every wave gets whole 32-deep k-steps
   const int k_lo = wave * kq;
   const bf16_t* xrow[MT];
 #pragma unroll
@@ -576,13 +576,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   // W, L2 for x) are in flight while batch b is multiplied.
   uint4 wv[2][NT][U], xv[2][MT][U];
   auto load = [&](int set, int k) {
+    // a 32-deep k-step takes 64 B of a row: the two k-steps that share a 128-B line are requested back to back, so
+    // the second request meets the first in L1 instead of going to L2 again (PMC: L2 requests were 2x the bytes)
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kk = min(k + 32 * u, kq - 32);   // tail batches re-read the last step; masked at the MFMA
+    for (int u = 0; u < U; u += 2) {
+      const int k0 = min(k + 32 * u, kq - 32), k1 = min(k + 32 * u + 32, kq - 32);   // tail: re-read, masked at the MFMA
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wv[set][t][u] = *reinterpret_cast<const uint4*>(wrow[t] + kk);
+      for (int t = 0; t < NT; ++t) {
+        wv[set][t][u] = *reinterpret_cast<const uint4*>(wrow[t] + k0);
+        wv[set][t][u + 1] = *reinterpret_cast<const uint4*>(wrow[t] + k1);
+      }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xv[set][mt][u] = *reinterpret_cast<const uint4*>(xrow[mt] + kk);
+      for (int mt = 0; mt < MT; ++mt) {
+        xv[set][mt][u] = *reinterpret_cast<const uint4*>(xrow[mt] + k0);
+        xv[set][mt][u + 1] = *reinterpret_cast<const uint4*>(xrow[mt] + k1);
+      }
     }
   };
   auto compute = [&](int set, int k) {
@@ -621,8 +629,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     __syncthreads();
     if (wave < MT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        o[t][r] = red[0][wave][lane][r] + red[1][wave][lane][r] + red[2][wave][lane][r] + red[3][wave][lane][r];
+      for (int r = 0; r < 4; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < KW; ++w4) sum += red[w4][wave][lane][r];
+        o[t][r] = sum;
+      }
     }
     if (t + 1 < NT) __syncthreads();
   }
