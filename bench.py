@@ -73,7 +73,10 @@ class GemmMeter:
             byts = 2.0 * (M * K + N * K + M * n_out + (M * n_out if kw.get("resid") is not None else 0))
             if out.dtype == torch.float32:
                 byts += 2.0 * M * n_out
-            meter.records.append((e0, e1, 2.0 * M * K * N, byts))
+            # which kernel family the C-ABI dispatches to (gemm_bf16.hip: gemm_bf16_impl): the weight-streaming kernel
+            # for M <= 64 (HBM-bound), the MFMA tile kernel otherwise — the roofline below is the tile kernel's
+            stream = M <= 64 and K % 128 == 0 and not (M > 32 and N >= 16384) and not kw.get("tile_cfg")
+            meter.records.append((e0, e1, 2.0 * M * K * N, byts, stream, 2.0 * N * K))
             return out
         ops.linear = timed
         return self
@@ -82,11 +85,18 @@ class GemmMeter:
         ops.linear = self._orig
 
     def summary(self):
+        """(launches, ms, flop, algorithmic bytes) of the MFMA tile kernel launches."""
         torch.cuda.synchronize()
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        fl = sum(r[2] for r in self.records)
-        by = sum(r[3] for r in self.records)
-        return len(self.records), ms, fl, by
+        rec = [r for r in self.records if not r[4]]
+        ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+        fl = sum(r[2] for r in rec)
+        by = sum(r[3] for r in rec)
+        return len(rec), ms, fl, by
+
+    def stream_summary(self):
+        """(launches, ms, weight bytes) of the weight-streaming (M <= 64) launches."""
+        rec = [r for r in self.records if r[4]]
+        return len(rec), sum(r[0].elapsed_time(r[1]) for r in rec), sum(r[5] for r in rec)
 
 
 def cpu_baseline(cfg, text_tokens, n_gen, threads):
@@ -225,6 +235,7 @@ def main():
             step()
         model.overlap_streams, model.decode_graphs = prev
         n_launch, gemm_ms, gemm_fl, gemm_bytes = meter.summary()
+        ws_n, ws_ms, ws_bytes = meter.stream_summary()
         # HBM traffic of the dominant kernel cannot be sampled from inside this process: it comes from the two
         # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of THIS command, summarised by tools/pmc_traffic.py into
         # profiles/ (FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes). null when no summary matches.
@@ -238,12 +249,16 @@ def main():
                 traffic_src = "profiles/pmc_gemm_traffic.json (%s)" % pmc.get("collected", "")
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         roofline = {
-            "bound": "mfma", "kernel": "gemm_bf16_kernel (haff_gemm_bf16, all epilogue variants)",
+            "bound": "mfma", "kernel": "gemm_bf16_kernel (haff_gemm_bf16 with M > 64: the 256x256 / 128x128 MFMA tiles, all epilogue variants)",
             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch_avg": gemm_bytes / n_launch,
             "launches_per_step": n_launch, "avg_launch_us": 1e3 * gemm_ms / n_launch,
             "flops_per_launch_avg": gemm_fl / n_launch, "gemm_share_of_step": gemm_ms / ms_per_step,
+            "weight_streaming_gemm": {"kernel": "gemm_skinny_kernel (haff_gemm_bf16 with M <= 64: KV-cached decode steps, [SEG] MLP)",
+                                      "bound": "hbm", "launches_per_step": ws_n, "share_of_step": ws_ms / ms_per_step,
+                                      "achieved": (ws_bytes / (ws_ms * 1e-3) / 1e9) if ws_ms > 0 else None, "peak": 8000.0,
+                                      "unit": "GB/s", "algorithmic_bytes": "2*N*K (the weight matrix, read once)"},
             "whole_path": {"flops_per_frame": flops_frame, "achieved": fps / world * flops_frame / 1e12,
                            "frac": fps / world * flops_frame / 1e12 / PEAK_BF16_TFLOPS},
         }
