@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time haff_gemm_bf16_cfg from an explicitly named build of gemm_bf16.hip (experiment variants compiled with -D flags
-into 2handedafforder_amd/lib/libhaff_gemm_<name>.so). usage: gemm_variant.py name [name ...]"""
+into 2handedafforder_amd/lib/libhaff_gemm_<name>.so). usage: [ACT=1] gemm_variant.py name [name ...]
+(ACT: epilogue activation code of haff_hip.h, with a bias vector; default 0 = plain product)"""
 import ctypes
 import os
 import sys
@@ -8,7 +9,7 @@ import sys
 import torch
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(131072, 1280, 5120), (18624, 4096, 4096), (18624, 4096, 11008), (16448, 1024, 4096), (16448, 4096, 1024), (65536, 1280, 5120)]
+SHAPES = [(131072, 5120, 1280), (131072, 1280, 5120), (18624, 4096, 4096), (18624, 4096, 11008), (16448, 1024, 4096), (16448, 4096, 1024), (65536, 1280, 5120)]
 
 
 def load(name):
@@ -27,14 +28,17 @@ def main():
         x = torch.randn((M, K), device=dev).to(torch.bfloat16)
         w = (torch.randn((N, K), device=dev) * K ** -0.5).to(torch.bfloat16)
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        act = int(os.environ.get("ACT", "0"))
+        bias = torch.randn((N,), device=dev) if act else None
         res = {n: [] for n in names}
         for r in range(4):
             for n in names:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    rc = libs[n].haff_gemm_bf16_cfg(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, None, None, 0,
-                                                    None, M, N, K, 0, 0, 0, 2, None)
+                    rc = libs[n].haff_gemm_bf16_cfg(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N,
+                                                    bias.data_ptr() if act else None, None, 0,
+                                                    None, M, N, K, act, 0, 0, 2, None)
                     assert rc == 0
                 e1.record()
                 torch.cuda.synchronize()
