@@ -801,6 +801,8 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(const T* q, long q_s
 // to a multiple of 32), land in LDS, and the diagonal gather relh[q][kh] = P_h[q][qh - kh + S - 1] (same for w)
 // writes coalesced rows. ~50 MFMAs per 16 queries at S=64 instead of 10k scalar FMAs per query.
 namespace {
+constexpr int RELPOS_QT = 4;   // 16-query tiles per wave: a table's fragments are fetched once and reused for all of them
+
 template <int NKD>  // k-steps of 32 over the (padded) head dim
 __global__ __launch_bounds__(256) void relpos_tables_mfma_kernel(const bf16_t* q, long q_sb, long q_sh, long q_st,
                                                                const bf16_t* tab_h, const bf16_t* tab_w,
@@ -813,49 +815,90 @@ __global__ __launch_bounds__(256) void relpos_tables_mfma_kernel(const bf16_t* q
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fh = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
-  float* sP = reinterpret_cast<float*>(smem_raw) + (long)wave * 2 * 16 * PS;  // [table][q][PS]
+  const int qbase = (blockIdx.x * 4 + wave) * (16 * RELPOS_QT);
+  if (qbase >= N) return;
+  // wave-private [16 queries][PS] image of ONE table's products for ONE query tile at a time (LDS ops of a wave
+  // execute in order, so the gather sees the stores without a workgroup barrier): 8.4 KB per wave at S = 64
+  float* sP = reinterpret_cast<float*>(smem_raw) + (long)wave * 16 * PS;
   const bf16_t* qb = q + (long)b * q_sb + (long)h * q_sh;
-  if (q0 < N) {
-    bf16x8 qf[NKD];
-    const int qi = min(q0 + fr, N - 1);
+  bf16x8 qf[RELPOS_QT][NKD];
+#pragma unroll
+  for (int qt = 0; qt < RELPOS_QT; ++qt) {
+    const int qi = min(qbase + qt * 16 + fr, N - 1);
 #pragma unroll
     for (int kd = 0; kd < NKD; ++kd) {
       const int col = kd * 32 + fh * 8;
       uint4 r = make_uint4(0, 0, 0, 0);
       if (col < d) r = *reinterpret_cast<const uint4*>(qb + (long)qi * q_st + col);
-      qf[kd] = __builtin_bit_cast(bf16x8, r);
-    }
-    for (int tb = 0; tb < 2; ++tb) {
-      const bf16_t* tab = tb == 0 ? tab_h : tab_w;
-      for (int rt = 0; rt < RT; ++rt) {
-        const int row = min(rt * 16 + fr, L - 1);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kd = 0; kd < NKD; ++kd) {
-          const int col = kd * 32 + fh * 8;
-          uint4 r = make_uint4(0, 0, 0, 0);
-          if (col < d) r = *reinterpret_cast<const uint4*>(tab + (long)row * d + col);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r), qf[kd], acc, 0, 0, 0);
-        }
-        // D[i = table row 4fh + reg][j = query fr]
-        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-        store4(sP + ((long)tb * 16 + fr) * PS + rt * 16 + fh * 4, v);
-      }
+      qf[qt][kd] = __builtin_bit_cast(bf16x8, r);
     }
   }
-  __syncthreads();
-  if (q0 >= N) return;
   const long bh = (long)b * H + h;
-  const int per_q = 2 * S;
-  for (int idx = lane; idx < 16 * per_q; idx += 64) {
-    const int ql = idx / per_q;
-    const int j = idx - ql * per_q;
-    const int qi = q0 + ql;
-    if (qi >= N) continue;
-    const int qh = qi / S, qw = qi - qh * S;
-    if (j < S) relh[(bh * N + qi) * S + j] = sP[(long)ql * PS + (qh - j + S - 1)];
-    else relw[(bh * N + qi) * S + (j - S)] = sP[((long)16 + ql) * PS + (qw - (j - S) + S - 1)];
+  const bool one_chunk = RT <= 8;   // S <= 64: the whole table (8 row tiles x NKD fragments) stays in registers
+  uint4 tf[8][NKD];
+  auto load_tf = [&](const bf16_t* tab, int rc) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int row = min((rc + g) * 16 + fr, L - 1);
+#pragma unroll
+      for (int kd = 0; kd < NKD; ++kd) {
+        const int col = kd * 32 + fh * 8;
+        tf[g][kd] = make_uint4(0, 0, 0, 0);
+        if (col < d) tf[g][kd] = *reinterpret_cast<const uint4*>(tab + (long)row * d + col);
+      }
+    }
+  };
+  for (int tb = 0; tb < 2; ++tb) {
+    const bf16_t* tab = tb == 0 ? tab_h : tab_w;
+    float* out = tb == 0 ? relh : relw;
+    if (one_chunk) load_tf(tab, 0);
+#pragma unroll
+    for (int qt = 0; qt < RELPOS_QT; ++qt) {
+      const int q0 = qbase + qt * 16;
+      if (q0 >= N) break;
+      for (int rc = 0; rc < RT; rc += 8) {
+        if (!one_chunk) load_tf(tab, rc);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          if (rc + g < RT) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kd = 0; kd < NKD; ++kd)
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, tf[g][kd]), qf[qt][kd], acc, 0, 0, 0);
+            // D[i = table row 4fh + reg][j = query fr]
+            float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+            store4(sP + (long)fr * PS + (rc + g) * 16 + fh * 4, v);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // diagonal gather: term j of query (qh, qw) is product row (qh or qw) - j + S - 1
+      if ((S & 3) == 0) {
+        // 16-B stores: a lane gathers 4 consecutive terms (descending LDS addresses) of one query; a 16-lane row of
+        // the wave covers one 256-B output row when S == 64 (4-byte stores ran this kernel at 1 TB/s of output)
+        const int s4 = S >> 2;
+        for (int idx = lane; idx < 16 * s4; idx += 64) {
+          const int ql = idx / s4;
+          const int j = (idx - ql * s4) << 2;
+          const int qi = q0 + ql;
+          if (qi >= N) continue;
+          const int qh = qi / S, qw = qi - qh * S;
+          const float* src = sP + (long)ql * PS + ((tb == 0 ? qh : qw) - j + S - 1);
+          float v[4] = {src[0], src[-1], src[-2], src[-3]};
+          store4(out + (bh * N + qi) * S + j, v);
+        }
+      } else {
+        for (int idx = lane; idx < 16 * S; idx += 64) {
+          const int ql = idx / S;
+          const int j = idx - ql * S;
+          const int qi = q0 + ql;
+          if (qi >= N) continue;
+          const int qh = qi / S, qw = qi - qh * S;
+          out[(bh * N + qi) * S + j] = sP[(long)ql * PS + ((tb == 0 ? qh : qw) - j + S - 1)];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 }  // namespace
@@ -867,11 +910,11 @@ extern "C" int haff_relpos_tables_bf16(const void* q, long q_sb, long q_sh, long
   if (B <= 0 || H <= 0 || S <= 0 || d <= 0 || d > 128 || (d & 7) || (q_st & 7) || (q_sh & 7) || (q_sb & 7)) return HAFF_ERR_BAD_ARG;
   const int N = S * S;
   const int RT = (2 * S - 1 + 15) / 16;
-  const size_t lds = (size_t)4 * 2 * 16 * (RT * 16 + 4) * sizeof(float);
+  const size_t lds = (size_t)4 * 16 * (RT * 16 + 4) * sizeof(float);   // one table's products per wave at a time
   if (lds > 150 * 1024) return HAFF_ERR_UNSUPPORTED;
-  dim3 grid((N + 63) / 64, H, B), block(256);
+  dim3 grid((N + 64 * RELPOS_QT - 1) / (64 * RELPOS_QT), H, B), block(256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (lds > 64 * 1024) {  // S = 64 needs 66 KiB of the CU's 160 KiB
+  if (lds > 64 * 1024) {  // S > 120
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_tables_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_tables_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_tables_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
