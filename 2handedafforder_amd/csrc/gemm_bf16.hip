@@ -321,18 +321,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
-    // 4-wave tile: two workgroups per CU cover for each other, and the plain double-buffered loop (next tile's DMA
-    // in flight across a counted wait, two barriers per K-tile) measured faster than the pipelined one here.
+    // 4-wave tile: two workgroups per CU cover for each other. One barrier per K-tile, and ONLY vmcnt(0) waits:
+    // tile kt+1's DMA is issued at the top of iteration kt (its buffer was last read in iteration kt-1, which ended with
+    // the barrier), has the whole MFMA phase to land, and is waited for in full before the barrier that publishes it.
+    // (The previous form issued it the same way but waited with a COUNTED vmcnt(8) for "the older tile": LDS-DMA
+    // operations do not retire in issue order when some hit L2 and others go to HBM, so under memory contention the
+    // count was reached with a piece of the older tile still in flight — rare stale 8-row x 32-deep fragments, found as
+    // run-to-run differences once a second HIP stream was active)
     stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) {
-        stage(cur ^ 1, (kt + 1) * BK);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
       if (kt == 0) HAFF_TRACE(1);
       read_frags(cur, 0);
       read_frags(cur, 1);
@@ -345,7 +346,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_group_barrier(0x100, (TN + TM + TM - 1) / TM, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);
-      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
   }
   __builtin_amdgcn_s_barrier();  // the epilogue reuses stage memory: every wave is done reading fragments

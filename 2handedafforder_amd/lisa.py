@@ -32,11 +32,10 @@ class LisaMI355:
         self.seg_token_idx = cfg.seg_token_idx
         self.sam_chunk = sam_chunk
         self._sam_stream = torch.cuda.Stream(device=self.device)
-        # True runs the SAM encoder on its own HIP stream beside the language model (+4 % frames/s). OFF by default:
-        # with two queues active the 8-wave 256x256 GEMM tile was observed to return wrong K-step fragments in a few
-        # percent of its launches (tools/concurrency_stress.py reproduces it at the op level; the same launches are
-        # bit-stable on a single stream). Cause not established, so the product path is serial.
-        self.overlap_streams = False
+        # The SAM encoder runs on its own HIP stream beside the language model and joins before the mask decoders
+        # (+4-5 % frames/s); False serialises everything on the caller's stream (per-kernel measurements). Results are
+        # bit-identical either way (tests/test_fullsize_gpu.py; the history of that check: DESIGN.md section 10a).
+        self.overlap_streams = True
         # KV-cached decode steps are launch-bound at small batch (32 layers x 9 launches per token): each step is
         # captured once per (batch, position) into a hipGraph and replayed. The KV cache is persistent per
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.

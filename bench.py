@@ -193,8 +193,8 @@ def main():
     ap.add_argument("--text-tokens", type=int, default=32)
     ap.add_argument("--n-gen", type=int, default=8)
     ap.add_argument("--sam-chunk", type=int, default=32)
-    ap.add_argument("--overlap-streams", action="store_true",
-                    help="SAM encoder on a second HIP stream (not the product default: see lisa.py)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
     args = ap.parse_args()
@@ -207,7 +207,7 @@ def main():
     cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
     sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
     model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=device, sam_chunk=args.sam_chunk)
-    model.overlap_streams = bool(args.overlap_streams)
+    model.overlap_streams = not args.single_stream
     del sd
     torch.cuda.empty_cache()
     B, S = args.batch, cfg.sam.img_size

@@ -586,3 +586,29 @@ def test_upscale_mask_and_resize(dev, dtype):
     _close(crop, ref, 1e-6, "resize crop")
     th = ops.threshold_masks(crop, 0.0)
     assert torch.equal(th, ((crop > 0).to(torch.uint8) * 255))
+
+
+@pytest.mark.parametrize("tile_cfg", [1, 2, 3])
+def test_gemm_stable_beside_second_stream(dev, tile_cfg):
+    """Regression for the counted-vmcnt race of the 128x128 tile: a GEMM on structured operands (every
+    K-tile of A holds one small integer, W is all ones: the fp32 result is exact, any stale K fragment is an exact
+    multiple of 16) launched repeatedly while (LayerNorm, qkv GEMM) pairs run on another HIP stream must return the
+    same bits every time. Before the fix 5-10 % of the 128x128 launches differed."""
+    ops = _ops()
+    k = torch.arange(4096, device=dev)
+    a = (1 + (k // 64) % 4).to(torch.bfloat16)[None, :].expand(592, 4096).contiguous()
+    w = torch.ones(4096, 4096, dtype=torch.bfloat16, device=dev)
+    x = _rand((9800, 1280), dev, torch.bfloat16, 31)
+    wq = _rand((3840, 1280), dev, torch.bfloat16, 32, 1280 ** -0.5)
+    lw, lb = torch.ones(1280, device=dev), torch.zeros(1280, device=dev)
+    ref = ops.linear(a, w, tile_cfg=tile_cfg, out_dtype=torch.float32).clone()
+    assert float(ref.min()) == float(ref.max()) == 64.0 * 16 * (1 + 2 + 3 + 4)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            ops.linear(ops.layernorm(x, lw, lb, 1e-6), wq)
+    outs = [ops.linear(a, w, tile_cfg=tile_cfg, out_dtype=torch.float32) for _ in range(200)]
+    torch.cuda.synchronize()
+    bad = sum(int(not torch.equal(o, ref)) for o in outs)
+    assert bad == 0, f"{bad}/200 launches differ with a second stream active"

@@ -1,9 +1,10 @@
-"""Reproducer for the open two-queue issue: a victim GEMM (structured data: A holds 1 + (k // 64) % 4,
-W is all ones, so every wrong K fragment shows up as an exact multiple of 16 in the fp32 output) is launched 300 times on
-the default stream while (layernorm, qkv GEMM) pairs of the SAM block run on a second stream. Observed on MI355X / ROCm 7.2:
-the 8-wave 256x256 tile returns wrong results in ~5-10 % of its launches (differences of +-64 = one 32-deep k-step of
-8 rows holding the staging buffer's content of two K-tiles earlier), the 4-wave 256x256 and 128x128 tiles and hipBLASLt
-never do; on a single stream every tile is bit-stable.   usage: python tools/concurrency_stress.py"""
+"""Two-queue regression probe: a victim GEMM (structured data: A holds 1 + (k // 64) % 4, W is all
+ones, so every wrong K fragment shows up as an exact multiple of 16 in the fp32 output) is launched 300 times on the
+default stream while (layernorm, qkv GEMM) pairs of the SAM block run on a second stream. History: the 128x128 tile
+waited for "the older K-tile" of its LDS-DMA double buffer with a COUNTED s_waitcnt vmcnt(8); LDS-DMA operations do not
+retire in issue order under memory contention, and 5-10 % of its launches came back with one 32-deep k-step of 8 rows
+holding the buffer's previous content (differences of exactly +-64). With vmcnt(0)-only waits every tile is clean.
+usage: python tools/concurrency_stress.py"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 import haff
@@ -38,7 +39,7 @@ A = (1 + (k // 64) % 4).to(torch.bfloat16)[None, :].expand(592, 4096).contiguous
 W = torch.ones(4096, 4096, dtype=torch.bfloat16, device=dev)
 side = torch.cuda.Stream(dev)
 seq = (ln, qkv)
-for tile, tname in ((1, "256x256, 8 waves"), (3, "256x256, 4 waves"), (2, "128x128, 4 waves")):
+for tile, tname in ((2, "256x256, 8 waves"), (3, "256x256, 4 waves"), (1, "128x128, 4 waves")):
     f = lambda: ops.linear(A, W, tile_cfg=tile, out_dtype=torch.float32)
     ref = f().clone(); torch.cuda.synchronize()
     tot = 0
