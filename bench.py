@@ -99,6 +99,42 @@ class GemmMeter:
         return len(rec), sum(r[0].elapsed_time(r[1]) for r in rec), sum(r[5] for r in rec)
 
 
+def parity_vs_oracle(device):
+    """BASELINE.json configs[0] (tiny LISA, the reference's own CPU-runnable case) through the HIP path in both numeric
+    modes against the CPU oracle on the same seeded inputs: the 'mask IoU vs ref' half of the metric. The oracle is the
+    checker only (tests/ pin it to the reference's golden vectors)."""
+    import numpy as np
+    from oracle import lisa_oracle as O
+    cfg = hcfg.tiny()
+    sd = hw.round_to_bf16_(hw.make_state_dict(cfg, 3))
+    rng = np.random.default_rng(3)
+    S = cfg.sam.img_size
+    images = torch.from_numpy(rng.standard_normal((1, 3, S, S), dtype=np.float32)).to(torch.bfloat16).float()
+    images_clip = torch.from_numpy(rng.standard_normal((1, 3, 224, 224), dtype=np.float32)).to(torch.bfloat16).float()
+    ids = torch.tensor([[cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx, 11, 12, 13, 14, 15, 16, 17, 18]])
+    forced = torch.tensor([[7, cfg.seg_token_idx, 9, cfg.eos_token_id]])
+    with torch.no_grad():
+        r_ids, r_left, r_right, r_tax = O.lisa_evaluate(sd, cfg, images_clip, images, ids, [(S, S)], [(S, S)],
+                                                         max_new_tokens=4, forced_answer=forced)
+    out = {"config": "BASELINE.json configs[0] (tiny), 1 frame, forced answer with one [SEG]", "oracle": "oracle/lisa_oracle.py (fp32, CPU)"}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        model = LisaMI355(cfg, sd, dtype=dt, device=device)
+        o_ids, left, right, tax = model.evaluate(images_clip.to(device), images.to(device), ids.to(device), [(S, S)], [(S, S)],
+                                                 max_new_tokens=4, forced_answer=forced)
+        ious, errs = [], []
+        for got, ref in ((left[0], r_left[0]), (right[0], r_right[0])):
+            g, r = got.float().cpu(), ref
+            inter = ((g > 0) & (r > 0)).sum().item()
+            union = ((g > 0) | (r > 0)).sum().item()
+            ious.append(inter / union if union else 1.0)
+            errs.append((g - r).abs().max().item() / max(r.abs().max().item(), 1e-30))
+        out[name] = {"mask_iou_vs_oracle": min(ious), "mask_logit_max_err_rel": max(errs),
+                     "taxonomy_max_abs_err": (tax[0].float().cpu() - r_tax[0]).abs().max().item(),
+                     "token_ids_equal": bool(torch.equal(o_ids.cpu(), r_ids))}
+        del model
+    return out
+
+
 def cpu_baseline(cfg, text_tokens, n_gen, threads):
     """The CPU oracle (fp32 torch eager restatement of the reference) on a bounded sample: full-width layers,
     reduced depth, one 1024^2 frame; per-layer times are extrapolated to the full depth."""
@@ -196,6 +232,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
     args = ap.parse_args()
 
@@ -312,6 +349,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, args.text_tokens, args.n_gen, threads)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_parity:
+            del model
+            line["parity"] = parity_vs_oracle(device)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
