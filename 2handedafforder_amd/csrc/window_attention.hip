@@ -142,7 +142,11 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
   }
   uint4 qnext[C::QPW][C::NKD];
   const int qcol = min(fr, S - 1);       // the lane's query column inside a grid row (masked lanes duplicate S-1)
-  auto issue_loads = [&](int id, int buf) {
+  // state of the prefetch in flight (the next item's K/V view), set by begin_loads, used by issue_dma
+  const bf16_t* nx_kb = p.k;
+  int nx_pad_h0 = S, nx_pad_w0 = S;
+  unsigned nx_pad_base = 0, nx_lds0 = 0;
+  auto begin_loads = [&](int id, int buf) {
     int win, h;
     decode(id, win, h);
     const bf16_t* qb = p.q + (long)win * p.q_sb + (long)h * p.q_sh;
@@ -167,20 +171,32 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
         if (col < D) qnext[t][kd] = *reinterpret_cast<const uint4*>(qsrc + col);
       }
     }
-    const unsigned lds0 = (unsigned)(uintptr_t)(wlptr_t)(wsm + buf * C::BUF_BYTES) + wave * 1024;  // hardware adds lane*16
-    // inline asm, not the builtin: the compiler's LDS-DMA tracking puts a vmcnt(0) in front of the next LDS access
-    // (it cannot prove the scratch / other buffer do not alias), which would drain the prefetch at once.
-    // Completion is waited for by hand (vmcnt(0) before the end-of-item barrier). M0 is otherwise unused here.
+    nx_kb = kb;
+    nx_pad_h0 = pad_h0;
+    nx_pad_w0 = pad_w0;
+    nx_pad_base = pad_base;
+    nx_lds0 = (unsigned)(uintptr_t)(wlptr_t)(wsm + buf * C::BUF_BYTES) + wave * 1024;  // hardware adds lane*16
+  };
+  // DMA instructions [i0, i1) of the item begin_loads prepared. Inline asm, not the builtin: the compiler's LDS-DMA
+  // tracking puts a vmcnt(0) in front of the next LDS access (it cannot prove the scratch / other buffer do not alias),
+  // which would drain the prefetch at once. Completion is waited for by hand (vmcnt(0) before the end-of-item barrier).
+  // M0 is otherwise unused here. The 10 instructions of an item are NOT issued in one go: the CU accepts requests at the
+  // rate HBM serves them (~24 GB/s per CU), so a wave that issues its whole 9 KB share sits in the issue stage for
+  // ~4 us of an ~11 us item (tools/window_attn_trace.py); spread over the compute phases the requests queue behind
+  // the MFMA / softmax work instead.
+  auto issue_dma = [&](int i0, int i1) {
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-      const unsigned m0v = lds0 + i * C::NTHREADS * 16;
-      const bool is_pad = (int)(slot_pad[i] >> 28) >= pad_h0 || (int)((slot_pad[i] >> 24) & 15u) >= pad_w0;
-      const unsigned off = is_pad ? pad_base + (slot_pad[i] & 0xffffffu) : slot_off[i];
+      if (i < i0 || i >= i1) continue;
+      const unsigned m0v = nx_lds0 + i * C::NTHREADS * 16;
+      const bool is_pad = (int)(slot_pad[i] >> 28) >= nx_pad_h0 || (int)((slot_pad[i] >> 24) & 15u) >= nx_pad_w0;
+      const unsigned off = is_pad ? nx_pad_base + (slot_pad[i] & 0xffffffu) : slot_off[i];
       if ((i + 1) * C::NTHREADS <= C::PAD_SLOTS || (i * C::NTHREADS + wave * 64) < C::PAD_SLOTS)   // wave-uniform
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(kb), "s"(m0v)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(nx_kb), "s"(m0v)
                      : "memory");
     }
   };
+  constexpr int DMA_Q1 = (NDMA + 3) / 4, DMA_Q2 = (NDMA + 1) / 2, DMA_Q3 = (3 * NDMA + 3) / 4;
 
   // The DMA is invisible to the compiler's vmcnt bookkeeping, so its own counted waits must never be needed while a
   // prefetch is in flight: after each hand-placed vmcnt(0) the prefetched Q registers are passed through an empty
@@ -195,7 +211,8 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
 
   int item = blockIdx.x;
   if (item >= n_items) return;
-  issue_loads(item, 0);
+  begin_loads(item, 0);
+  issue_dma(0, NDMA);
 
   // ---- rel-pos table fragments (A operand: lane = (table row fr, d-chunk fh)); constant for the workgroup ----
   bf16x8 th[2][C::NKD], tw[2][C::NKD];
@@ -248,7 +265,10 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
     const int next = item + gridDim.x;
     const bool has_next = next < n_items;
     WTRACE(0);
-    if (has_next) issue_loads(next, buf ^ 1);   // HBM -> the other LDS buffer (last read one item ago), in flight during the compute
+    if (has_next) {   // HBM -> the other LDS buffer (last read one item ago), in flight during the compute
+      begin_loads(next, buf ^ 1);
+      issue_dma(0, DMA_Q1);
+    }
     WTRACE(1);
 
 #pragma unroll
@@ -337,6 +357,10 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
       }
 
       WTRACE(3 + 5 * t);
+      if (has_next) {
+        if (t == 0) issue_dma(DMA_Q1, DMA_Q2);
+        else issue_dma(DMA_Q3, NDMA);
+      }
       // ---- softmax over the whole row block (lane owns query column fr; its 4 keys per tile are kw = 4fh+j) ----
       float mx = -1e30f;
 #pragma unroll
@@ -385,6 +409,7 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
       }
 
       WTRACE(5 + 5 * t);
+      if (has_next && t == 0) issue_dma(DMA_Q2, DMA_Q3);
       // ---- out[q][16dt + 4fh + j] = O^T / sum ----
       const float inv = 1.0f / psum;
       if (fr < S) {
