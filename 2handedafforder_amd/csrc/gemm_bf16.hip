@@ -274,12 +274,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     HAFF_TRACE(1);
+    // SIMD partners (waves w and w+4) issue their share of the next tile's DMA at different points after the barrier:
+    // a wave's 8 DMA instructions take ~340 ns to issue (the CU accepts requests at the rate memory serves them;
+    // -DHAFF_GEMM_TRACE slots 5/6) and it issues no MFMA meanwhile. Waves 0-3 issue before their fragment reads, waves
+    // 4-7 after their held-back MFMAs, so one partner's issue stall sits under the other's reads and MFMAs
+    // (+2.5...+7 % per shape, tools/gemm_variant.py; both partners right after the barrier idled the matrix pipe;
+    // moving the late group's issue into the middle of the next K-tile's MFMA stream instead cost 10-18 %).
+    const bool late = wave >= 4;
     if (nk > 1) stage(1, BK);
     read_frags(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
+#ifdef HAFF_GEMM_TRACE
+      if (kt == 5) HAFF_TRACE(7);
+#endif
       read_frags(cur, 1);
       mfma_rows(0, 0, TM);
+
       mfma_rows(1, 0, HEAD);
       // k-step-1 reads trickle in between the k-step-0 MFMA groups (lgkmcnt is 4 bits: keep <= 15 reads outstanding)
 #pragma unroll
@@ -298,7 +309,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #if HAFF_GEMM_PRIO == 1
         __builtin_amdgcn_s_setprio(3);   // the wave issuing the next tile's DMA / first reads goes ahead of MFMA streams
 #endif
-        if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
+#ifdef HAFF_GEMM_TRACE
+        if (kt == 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); HAFF_TRACE(5); }
+#endif
+        if (!late && kt + 2 < nk) stage(cur, (kt + 2) * BK);
+#ifdef HAFF_GEMM_TRACE
+        if (kt == 4) HAFF_TRACE(6);
+#endif
         read_frags(cur ^ 1, 0);
 #if HAFF_GEMM_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
@@ -311,6 +328,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       __builtin_amdgcn_s_setprio(3);
 #endif
       mfma_rows(1, HEAD, TM);
+      if (late && kt + 2 < nk) {   // the partner issued its share before its fragment reads; this wave after its tail MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        stage(cur, (kt + 2) * BK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #if HAFF_GEMM_PRIO == 2 || HAFF_GEMM_PRIO == 3
       __builtin_amdgcn_s_setprio(0);
 #elif HAFF_GEMM_PRIO == 4
