@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+      if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);   // (issuing it after the fragment reads instead measured -5 %)
       if (kt == 0) HAFF_TRACE(1);
       read_frags(cur, 0);
       read_frags(cur, 1);
