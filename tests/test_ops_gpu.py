@@ -612,3 +612,58 @@ def test_gemm_stable_beside_second_stream(dev, tile_cfg):
     torch.cuda.synchronize()
     bad = sum(int(not torch.equal(o, ref)) for o in outs)
     assert bad == 0, f"{bad}/200 launches differ with a second stream active"
+
+
+def test_kernels_stable_beside_second_stream(dev):
+    """Every hot kernel, launched repeatedly while (LayerNorm, qkv GEMM) pairs run on another HIP stream, must return the
+    same bits as alone on the GPU. Memory contention changes the order in which a kernel's loads complete; a kernel
+    that depended on that order (the 128x128 GEMM tile once did: DESIGN.md 10a) fails here."""
+    ops = _ops()
+    x = _rand((9800, 1280), dev, torch.bfloat16, 51)
+    wq = _rand((3840, 1280), dev, torch.bfloat16, 52, 1280 ** -0.5)
+    lw, lb = torch.ones(1280, device=dev), torch.zeros(1280, device=dev)
+    qkv_w = _rand((50 * 196 + 1, 3840), dev, torch.bfloat16, 53, 0.5)
+    qkv_g = _rand((2 * 4096, 3840), dev, torch.bfloat16, 54, 0.5)
+    t14 = (_rand((27, 80), dev, torch.float32, 55, 0.1), _rand((27, 80), dev, torch.float32, 56, 0.1))
+    t64 = (_rand((127, 80), dev, torch.float32, 57, 0.1), _rand((127, 80), dev, torch.float32, 58, 0.1))
+    qp = _rand((2, 291, 3, 32, 128), dev, torch.bfloat16, 59, 0.5)
+    kc = _rand((8, 300, 32, 128), dev, torch.bfloat16, 60, 0.5)
+    xs, ws = _rand((64, 4096), dev, torch.bfloat16, 61), _rand((4096, 4096), dev, torch.bfloat16, 62, 4096 ** -0.5)
+    xb, wb = _rand((4096, 1280), dev, torch.bfloat16, 63), _rand((5120, 1280), dev, torch.bfloat16, 64, 1280 ** -0.5)
+    bias = _rand((5120,), dev, torch.float32, 65)
+
+    def win():
+        v = qkv_w[:50 * 196].view(50, 196, 3, 16, 80).permute(2, 0, 3, 1, 4)
+        return ops.window_attention(v[0], v[1], v[2], 80 ** -0.5, t14[0], t14[1], 14)
+
+    def glob():
+        v = qkv_g.view(2, 4096, 3, 16, 80).permute(2, 0, 3, 1, 4)
+        rh, rw = ops.relpos_tables(v[0], t64[0], t64[1], 64)
+        return ops.attention(v[0], v[1], v[2], 80 ** -0.5, relh=rh, relw=rw, S=64)
+
+    def prefill():
+        v = qp.permute(2, 0, 3, 1, 4)
+        return ops.attention(v[0], v[1], v[2], 128 ** -0.5, causal=True)
+
+    def decode():
+        q = kc[:, :1].permute(0, 2, 1, 3)
+        k = kc.permute(0, 2, 1, 3)
+        return ops.attention(q, k, k, 128 ** -0.5)
+
+    cases = {"window attention": win, "global attention + rel-pos tables": glob, "causal prefill attention": prefill,
+             "decode attention": decode, "weight-streaming GEMM M=64": lambda: ops.linear(xs, ws),
+             "weight-streaming GEMM M=8": lambda: ops.linear(xs[:8], ws, resid=xs[:8]),
+             "256x256 GEMM + GELU": lambda: ops.linear(xb, wb, bias=bias, act=1),
+             "layernorm": lambda: ops.layernorm(xb, lw, lb, 1e-6), "rmsnorm": lambda: ops.rmsnorm(xs, torch.ones(4096, device=dev), 1e-5)}
+    side = torch.cuda.Stream(dev)
+    for name, f in cases.items():
+        ref = f().clone()
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(30):
+                ops.linear(ops.layernorm(x, lw, lb, 1e-6), wq)
+        outs = [f() for _ in range(40)]
+        torch.cuda.synchronize()
+        bad = sum(int(not torch.equal(o, ref)) for o in outs)
+        assert bad == 0, f"{name}: {bad}/40 launches differ with a second stream active"
