@@ -13,28 +13,25 @@ import torch
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import haff  # noqa: F401
-    from haff import prompt as hprompt
+    from haff import postprocess, prompt as hprompt
     from haff.inference import build_model_and_tokenizer, load_rgb, parse_args, prepare_frame
 else:
-    from . import prompt as hprompt
+    from . import postprocess, prompt as hprompt
     from .inference import build_model_and_tokenizer, load_rgb, parse_args, prepare_frame
 
 IMAGE_TOKEN_INDEX = -200
 
 
 def render_outputs(image_np, mask_left, mask_right, taxonomy):
-    """chat.py:226-269 as pure numpy: gated boolean masks and the overlay image."""
-    t = int(torch.as_tensor(taxonomy).reshape(-1).argmax())
-    left = mask_left > 0
-    right = mask_right > 0
-    if t == 1:
-        left = np.zeros_like(left)
-    if t == 0:
-        right = np.zeros_like(right)
+    """chat.py:226-269: gated mask planes (uint8, mask * 100 — what the reference hands to cv2.imwrite) from the device
+    (haff_gate_threshold_masks: `mask > 0`, taxonomy argmax 1 blanks the left hand, 0 the right) and the overlay image."""
+    left100 = postprocess.chat_plane(mask_left, taxonomy, "left").cpu().numpy()
+    right100 = postprocess.chat_plane(mask_right, taxonomy, "right").cpu().numpy()
+    left, right = left100 > 0, right100 > 0
     overlay = image_np.copy()
     overlay[left] = (image_np * 0.5 + left[:, :, None].astype(np.uint8) * np.array([255, 0, 0]) * 0.5)[left]
     overlay[right] = (image_np * 0.5 + right[:, :, None].astype(np.uint8) * np.array([0, 0, 255]) * 0.5)[right]
-    return left, right, overlay
+    return left100, right100, overlay
 
 
 def main(argv, input_fn=input, max_turns=None):
@@ -63,8 +60,8 @@ def main(argv, input_fn=input, max_turns=None):
         for i, (ml, mr, tax) in enumerate(zip(masks_left, masks_right, taxonomies)):
             if ml.shape[0] == 0:
                 continue
-            left, right, overlay = render_outputs(image_np, ml[0].cpu().numpy(), mr[0].cpu().numpy(), tax)
-            for name, arr in (("mask_left", left.astype(np.uint8) * 100), ("mask_right", right.astype(np.uint8) * 100)):
+            left100, right100, overlay = render_outputs(image_np, ml[0], mr[0], tax)
+            for name, arr in (("mask_left", left100), ("mask_right", right100)):
                 save_path = "{}/{}_{}{}.jpg".format(args.vis_save_path, stem, name, i)
                 Image.fromarray(arr).save(save_path)
                 print("{} has been saved.".format(save_path))

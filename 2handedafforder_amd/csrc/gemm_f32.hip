@@ -1,17 +1,24 @@
-// fp32 GEMM with the same fused epilogues as haff_gemm_bf16 — the PARITY-MODE twin.
+// fp32 GEMM with the same fused epilogues as haff_gemm_bf16 — exact-f32 twin on the f32-input matrix cores.
 //
-//   C[M,N] = epi( A[M,K] · W[N,K]^T ), everything fp32, k-ordered fmaf accumulation.
+//   C[M,N] = epi( A[M,K] · W[N,K]^T ), everything fp32: v_mfma_f32_16x16x4_f32 is bit-for-bit an f32 fmaf chain
+//   (one rounding per product, no wider accumulator), at the f32 vector peak (64 FLOP/clk/SIMD).
 //
-// BASELINE.json's north_star asks for mask logits within 1e-3 of the reference's fp32 CPU forward; a bf16
-// pipeline cannot promise that across 32+32 transformer layers, so the host side can run the whole path in
-// fp32 ("parity mode") through this kernel, while the bf16 MFMA kernel is the throughput mode. This one is a
-// plain LDS-tiled VALU kernel (64x64x16 tile, 4x4 outputs per thread, strided so stores coalesce and SwiGLU
-// gate/up pairs land in one thread); it is not a performance path.
+// Two users: (1) the fp32 "parity mode" of the whole path (mask logits within 1e-3 of the fp32 CPU forward,
+// BASELINE.json north_star); (2) the fp32 DECODER TAIL of the bf16 throughput mode — text_hidden_fcs, both two-way
+// mask decoders, hypernetwork / IoU / taxonomy MLPs and the first transposed conv run in fp32 on fp32 image
+// embeddings (7 GFLOP per frame; SURVEY section 7, hard part 3).
+//
+// 128x128x16 tile, 4 waves (2x2), 64x64 per wave = 4x4 MFMA tiles. Operands are staged through registers into LDS
+// rows of 16 floats padded to 20 (80 B: the 16 rows of a fragment start on 16 different 16-B bank groups); a
+// fragment is ONE ds_read_b128 per lane — lane (r = l & 15, g = l >> 4) reads k = 4g .. 4g+3 of row r — and the four
+// components feed four MFMAs: MFMA c sums k = {c, 4+c, 8+c, 12+c}, the same permutation on both operands, so the 16
+// k of the tile are covered once. Swapped orientation (W is the MFMA's A operand): a lane's 4 accumulator registers
+// are 4 CONSECUTIVE output columns of one row -> 16-B epilogue loads/stores, SwiGLU (gate, up) pairs in one lane.
 #include "haff_common.h"
 
 namespace {
 
-constexpr int TM = 64, TN = 64, TK = 16;
+constexpr int TM = 128, TN = 128, TK = 16, RS = 20;
 
 struct GemmF32Args {
   const float* A; long lda;
@@ -27,54 +34,80 @@ struct GemmF32Args {
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
-  __shared__ float sA[TK][TM + 1];
-  __shared__ float sW[TK][TN + 1];
+  __shared__ __attribute__((aligned(16))) float sA[2][TM * RS];
+  __shared__ __attribute__((aligned(16))) float sW[2][TN * RS];
   if (p.nb_inner > 0) {
     const int zo = blockIdx.y / p.nb_inner, zi = blockIdx.y - zo * p.nb_inner;
     p.A += zo * p.sAo + zi * p.sAi;
     p.W += zo * p.sWo + zi * p.sWi;
     p.C += zo * p.sCo + zi * p.sCi;
   }
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fg = lane >> 4;
   const int tiles_n = (p.N + TN - 1) / TN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
 
-  float acc[4][4];
+  f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // staging: thread -> rows (tid >> 2) and (tid >> 2) + 64, k chunk (tid & 3) * 4
   const int lrow = tid >> 2, lk = (tid & 3) * 4;
-  const int am = min(m0 + lrow, p.M - 1);
-  const int wn = min(n0 + lrow, p.N - 1);
-  for (int k0 = 0; k0 < p.K; k0 += TK) {
-    float4 a = make_float4(0, 0, 0, 0), w = make_float4(0, 0, 0, 0);
-    if (k0 + lk < p.K) {
-      a = *reinterpret_cast<const float4*>(p.A + (long)am * p.lda + k0 + lk);
-      w = *reinterpret_cast<const float4*>(p.W + (long)wn * p.ldw + k0 + lk);
+  const float* a0 = p.A + (long)min(m0 + lrow, p.M - 1) * p.lda + lk;
+  const float* a1 = p.A + (long)min(m0 + lrow + 64, p.M - 1) * p.lda + lk;
+  const float* w0 = p.W + (long)min(n0 + lrow, p.N - 1) * p.ldw + lk;
+  const float* w1 = p.W + (long)min(n0 + lrow + 64, p.N - 1) * p.ldw + lk;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ra0, ra1, rw0, rw1;
+  auto fetch = [&](int k0) {
+    const bool ok = k0 + lk < p.K;
+    ra0 = ok ? *reinterpret_cast<const float4*>(a0 + k0) : z4;
+    ra1 = ok ? *reinterpret_cast<const float4*>(a1 + k0) : z4;
+    rw0 = ok ? *reinterpret_cast<const float4*>(w0 + k0) : z4;
+    rw1 = ok ? *reinterpret_cast<const float4*>(w1 + k0) : z4;
+  };
+  auto stash = [&](int buf) {
+    *reinterpret_cast<float4*>(&sA[buf][lrow * RS + lk]) = ra0;
+    *reinterpret_cast<float4*>(&sA[buf][(lrow + 64) * RS + lk]) = ra1;
+    *reinterpret_cast<float4*>(&sW[buf][lrow * RS + lk]) = rw0;
+    *reinterpret_cast<float4*>(&sW[buf][(lrow + 64) * RS + lk]) = rw1;
+  };
+  const int nk = (p.K + TK - 1) / TK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) fetch((kt + 1) * TK);  // in flight under the MFMAs below
+    float4 wf[4], af[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wf[i] = *reinterpret_cast<const float4*>(&sW[buf][(wn * 64 + i * 16 + fr) * RS + fg * 4]);
+      af[i] = *reinterpret_cast<const float4*>(&sA[buf][(wm * 64 + i * 16 + fr) * RS + fg * 4]);
     }
-    __syncthreads();
-    sA[lk + 0][lrow] = a.x; sA[lk + 1][lrow] = a.y; sA[lk + 2][lrow] = a.z; sA[lk + 3][lrow] = a.w;
-    sW[lk + 0][lrow] = w.x; sW[lk + 1][lrow] = w.y; sW[lk + 2][lrow] = w.z; sW[lk + 3][lrow] = w.w;
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < TK; ++k) {
-      float av[4], wv[4];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { av[i] = sA[k][ty + 16 * i]; wv[i] = sW[k][tx + 16 * i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], wv[j], acc[i][j]);
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].x, af[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].y, af[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].z, af[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].w, af[j].w, acc[i][j], 0, 0, 0);
+      }
+    if (kt + 1 < nk) {
+      stash(buf ^ 1);  // the other buffer was last read in iteration kt-1, behind the barrier below
+      __syncthreads();
     }
   }
 
+  // epilogue: acc[i][j][r] = C[m0 + wm*64 + j*16 + fr][n0 + wn*64 + i*16 + fg*4 + r]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty + 16 * i;
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + fr;
     if (m >= p.M) continue;
     long orow = m;
     if (p.row_map) {
@@ -84,24 +117,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
     }
     if (!p.swiglu) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + tx + 16 * j;
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fg * 4;
         if (n >= p.N) continue;
-        float v = acc[i][j];
-        if (p.bias) v += p.bias[n];
-        v = apply_act(v, p.act);
-        if (p.resid) v += p.resid[orow * p.ldr + n];
-        p.C[orow * p.ldc + n] = v;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        float* cp = p.C + orow * p.ldc + n;
+        const float* rp = p.resid ? p.resid + orow * p.ldr + n : nullptr;
+        const bool vec = n + 3 < p.N && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0) &&
+                         (!rp || (reinterpret_cast<uintptr_t>(rp) & 15) == 0) &&
+                         (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+        if (vec) {
+          if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+          if (rp) {
+            const float4 q = *reinterpret_cast<const float4*>(rp);
+            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+          }
+          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) break;
+            float x = v[r];
+            if (p.bias) x += p.bias[n + r];
+            x = apply_act(x, p.act);
+            if (rp) x += rp[r];
+            cp[r] = x;
+          }
+        }
       }
     } else {
+      // W rows interleaved [gate x16 | up x16]: tile i even = gate, i odd = up, same lane
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int n_in = n0 + tx + 16 * j;  // gate column; up at n_in + 16
+      for (int i = 0; i < 4; i += 2) {
+        const int n_in = n0 + wn * 64 + i * 16 + fg * 4;  // gate rows; up at n_in + 16
         if (n_in >= p.N) continue;
-        float g = acc[i][j], u = acc[i][j + 1];
-        if (p.bias) { g += p.bias[n_in]; u += p.bias[n_in + 16]; }
-        const int n_out = (n0 >> 1) + (j >> 1) * 16 + tx;
-        p.C[orow * p.ldc + n_out] = (g / (1.0f + expf(-g))) * u;
+        const int n_out = (n0 >> 1) + wn * 32 + (i >> 1) * 16 + fg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float g = acc[i][j][r], u = acc[i + 1][j][r];
+          if (p.bias) { g += p.bias[n_in + r]; u += p.bias[n_in + 16 + r]; }
+          p.C[orow * p.ldc + n_out + r] = (g / (1.0f + expf(-g))) * u;
+        }
       }
     }
   }

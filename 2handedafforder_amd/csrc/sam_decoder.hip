@@ -113,6 +113,45 @@ __global__ void threshold_masks_kernel(const float* in, unsigned char* out, long
     out[i] = in[i] > logit_th ? 255 : 0;
 }
 
+struct GateArgs {
+  const float* in;
+  unsigned char* out;   // [n_th][plane_stride], the first `total` bytes of a plane are written
+  long total, plane_stride;
+  const float* taxonomy;  // device, 4 class probabilities of this prompt, or nullptr (gate always open)
+  int blank_class, n_th, on_value;
+  float th[8];
+};
+
+// planes[t][i] = (argmax(taxonomy) != blank_class && in[i] > th[t]) ? on_value : 0 — one read of the fp32 logits for all
+// thresholds; 4 pixels per thread (16-B load, 4-B store per plane). argmax ties resolve to the first maximum (torch).
+__global__ __launch_bounds__(256) void gate_threshold_kernel(GateArgs p) {
+  bool open = true;
+  if (p.taxonomy) {
+    int best = 0;
+    float bv = p.taxonomy[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+      const float v = p.taxonomy[c];
+      if (v > bv) { bv = v; best = c; }
+    }
+    open = best != p.blank_class;
+  }
+  const unsigned on = open ? (unsigned)p.on_value : 0u;
+  const long n4 = p.total >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(p.in)[i];
+    for (int t = 0; t < p.n_th; ++t) {
+      const float th = p.th[t];
+      const unsigned w = (v.x > th ? on : 0u) | (v.y > th ? on << 8 : 0u) | (v.z > th ? on << 16 : 0u) | (v.w > th ? on << 24 : 0u);
+      reinterpret_cast<unsigned*>(p.out + (long)t * p.plane_stride)[i] = w;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (p.total & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    for (int t = 0; t < p.n_th; ++t) p.out[(long)t * p.plane_stride + i] = p.in[i] > p.th[t] ? (unsigned char)on : 0;
+  }
+}
+
 }  // namespace
 
 // up1: [n_prompts*h*w][4*64] (dtype 0 bf16 / 1 f32), columns (dy*2+dx)*64+co, bias already added.
@@ -146,5 +185,25 @@ extern "C" int haff_threshold_masks(const float* in, void* out, long total, floa
   long g = (total + 255) / 256;
   if (g > 16384) g = 16384;
   hipLaunchKernelGGL(threshold_masks_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, (unsigned char*)out, total, logit_th);
+  return haff_check_launch();
+}
+
+// Output gating + thresholds of the CLIs in one pass (inference.py:276-334, chat.py:226-253): `logits` fp32 [total]
+// (one postprocessed mask), `planes` uint8 [n_th][plane_stride >= total, multiple of 4]; thresholds are LOGIT thresholds (host array of n_th <= 8
+// floats; the caller maps sigmoid(m) > th to m > x*(th), see postprocess.sigmoid_logit_threshold); taxonomy = device
+// pointer to the prompt's 4 class probabilities or NULL; a prompt whose argmax equals blank_class gets all-zero planes.
+extern "C" int haff_gate_threshold_masks(const float* logits, void* planes, long total, long plane_stride,
+                                         const float* thresholds_host, int n_th, int on_value, const float* taxonomy,
+                                         int blank_class, void* stream) {
+  if (total <= 0 || n_th <= 0 || n_th > 8 || on_value < 0 || on_value > 255 || !thresholds_host) return HAFF_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(logits) & 15) || (reinterpret_cast<uintptr_t>(planes) & 3) || plane_stride < total ||
+      (plane_stride & 3))
+    return HAFF_ERR_BAD_ARG;
+  GateArgs p{logits, (unsigned char*)planes, total, plane_stride, taxonomy, blank_class, n_th, on_value, {}};
+  for (int t = 0; t < n_th; ++t) p.th[t] = thresholds_host[t];
+  long g = ((total >> 2) + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(gate_threshold_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   return haff_check_launch();
 }

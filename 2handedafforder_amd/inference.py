@@ -18,10 +18,10 @@ import torch
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import haff  # noqa: F401
-    from haff import checkpoint, config as hcfg, preprocess, prompt as hprompt
+    from haff import checkpoint, config as hcfg, postprocess, preprocess, prompt as hprompt
     from haff.lisa import LisaMI355
 else:
-    from . import checkpoint, config as hcfg, preprocess, prompt as hprompt
+    from . import checkpoint, config as hcfg, postprocess, preprocess, prompt as hprompt
     from .lisa import LisaMI355
 
 
@@ -92,11 +92,32 @@ def prepare_frame(image_np, cfg, dtype, device):
     return image_clip, image, [resize], [original_size]
 
 
-def save_mask(path, mask_bool):
+def save_mask(path, plane_u8):
     from PIL import Image
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    Image.fromarray((mask_bool.astype(np.uint8) * 255)).save(path)
+    Image.fromarray(plane_u8).save(path)
     print(f"{path} has been saved.")
+
+
+def output_planes(masks_left, masks_right, taxonomies, thresholds=postprocess.THRESHOLDS):
+    """inference.py:276-334 on the device: {(side, th): uint8 [H0,W0] 0/255} — gating from taxonomies[0] (one host read of
+    its argmax decides which files exist), all five thresholds of a hand from ONE pass over its fp32 mask."""
+    out = {}
+    taxonomy = taxonomies[0]
+    if taxonomy.numel() == 0:
+        return out
+    tax = taxonomy.reshape(-1).float().contiguous()
+    t = int(torch.argmax(tax))
+    for side, masks, blank in (("left", masks_left, 1), ("right", masks_right, 0)):
+        if t == blank:
+            continue
+        for pred_mask in masks:
+            if pred_mask.shape[0] == 0:
+                continue
+            planes = postprocess.inference_planes(pred_mask[0], None, side, thresholds).cpu().numpy()
+            for k, th in enumerate(thresholds):
+                out[(side, th)] = planes[k]
+    return out
 
 
 def main(argv):
@@ -125,19 +146,8 @@ def main(argv):
             output_ids, masks_left, masks_right, taxonomies = model.evaluate(
                 image_clip, image, input_ids, resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
                 tokenizer=tokenizer)
-            taxonomy = taxonomies[0]
-            if taxonomy.numel() == 0:
-                continue
-            t = int(torch.argmax(taxonomy))
-            for side, masks, skip in (("left", masks_left, 1), ("right", masks_right, 0)):
-                if t == skip:
-                    continue
-                for pred_mask in masks:
-                    if pred_mask.shape[0] == 0:
-                        continue
-                    prob = torch.sigmoid(pred_mask[0]).cpu().numpy()
-                    for th in preprocess.THRESHOLDS:
-                        save_mask(os.path.join(args.vis_save_path + str(th), dir_name, folder_name, f"aff_{side}.png"), prob > th)
+            for (side, th), plane in output_planes(masks_left, masks_right, taxonomies).items():
+                save_mask(os.path.join(args.vis_save_path + str(th), dir_name, folder_name, f"aff_{side}.png"), plane)
 
 
 if __name__ == "__main__":

@@ -64,6 +64,7 @@ _PROTOS = {
                           c_float, c_int, c_void_p],
     "haff_resize_bilinear": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_threshold_masks": [c_void_p, c_void_p, c_long, c_float, c_void_p],
+    "haff_gate_threshold_masks": [c_void_p, c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     # ---- training path (csrc/train.hip + batched GEMMs) ----
     "haff_gemm_bf16_batched": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long,
                                c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -23,7 +23,7 @@ N_IMG_PAD = 255  # LISA.py:461
 
 
 class LisaMI355:
-    def __init__(self, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", sam_chunk=8):
+    def __init__(self, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", sam_chunk=8, fp32_tail=True):
         if not torch.cuda.is_available():
             raise RuntimeError("LisaMI355 needs an MI355X (HIP device); there is no CPU fallback for the hot path")
         from .lib import load_library
@@ -45,14 +45,22 @@ class LisaMI355:
         self._caches = {}
         sd, dev = state_dict, self.device
         assert cfg.clip.n_patches == N_IMG_PAD + 1, "the reference hard-codes 256 image tokens (LISA.py:461)"
+        # fp32 decoder tail (throughput mode): image embeddings leave the neck in fp32 and text_hidden_fcs, the prompt
+        # encoder, both two-way mask decoders, the hypernetwork / IoU / taxonomy MLPs and the upscaler run on the
+        # f32-input matrix cores (csrc/gemm_f32.hip) — 7 GFLOP of the 10 TFLOP per frame (hard part 3).
+        # The ViT-H / CLIP / Llama stacks stay bf16 MFMA. False = the all-bf16 path of round 1.
+        self.fp32_tail = fp32_tail and dtype == torch.bfloat16
+        tail = torch.float32 if self.fp32_tail else dtype
+        self.tail_dtype = tail
         self.sam_encoder = SamEncoderHip(sd, cfg.sam, dtype, dev)
-        self.sam_decoder = SamPromptDecoderHip(sd, cfg.sam, dtype, dev)
+        self.sam_encoder.emb_f32 = self.fp32_tail
+        self.sam_decoder = SamPromptDecoderHip(sd, cfg.sam, tail, dev)
         self.clip = ClipTowerHip(sd, cfg.clip, dtype, dev)
         self.llm = LlamaHip(sd, cfg.llm, dtype, dev)
         self.w_proj = sd["model.mm_projector.weight"].to(dev, dtype).contiguous()
         self.b_proj = _f32(sd["model.mm_projector.bias"], dev)
-        self.fc0 = (sd["model.text_hidden_fcs.0.0.weight"].to(dev, dtype).contiguous(), _f32(sd["model.text_hidden_fcs.0.0.bias"], dev))
-        self.fc2 = (sd["model.text_hidden_fcs.0.2.weight"].to(dev, dtype).contiguous(), _f32(sd["model.text_hidden_fcs.0.2.bias"], dev))
+        self.fc0 = (sd["model.text_hidden_fcs.0.0.weight"].to(dev, tail).contiguous(), _f32(sd["model.text_hidden_fcs.0.0.bias"], dev))
+        self.fc2 = (sd["model.text_hidden_fcs.0.2.weight"].to(dev, tail).contiguous(), _f32(sd["model.text_hidden_fcs.0.2.bias"], dev))
 
     # ---- a4/a5: CLIP tower + projector -------------------------------------------------------------------
     def encode_images(self, images_clip):
@@ -168,8 +176,8 @@ class LisaMI355:
         counts = mask.int().sum(-1)
         b_idx, t_idx = mask.nonzero(as_tuple=True)
         if b_idx.numel() == 0:
-            return torch.empty((0, self.cfg.out_dim), dtype=self.dtype, device=self.device), b_idx, counts
-        rows = hidden[b_idx, t_idx].contiguous()
+            return torch.empty((0, self.cfg.out_dim), dtype=self.tail_dtype, device=self.device), b_idx, counts
+        rows = hidden[b_idx, t_idx].to(self.tail_dtype).contiguous()
         h = ops.linear(rows, self.fc0[0], bias=self.fc0[1], act=ops.ACT_RELU)
         return ops.linear(h, self.fc2[0], bias=self.fc2[1]), b_idx, counts
 

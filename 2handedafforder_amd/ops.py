@@ -389,3 +389,22 @@ def threshold_masks(x, logit_th=0.0):
     rc = lib.haff_threshold_masks(x.data_ptr(), out.data_ptr(), x.numel(), float(logit_th), _stream())
     check(rc, "haff_threshold_masks")
     return out
+
+
+def gate_threshold_masks(x, logit_ths, on_value=255, taxonomy=None, blank_class=-1):
+    """x fp32 [...] mask logits of ONE prompt -> uint8 [n_th, ...]: (argmax(taxonomy) != blank_class and x > th) ? on_value : 0."""
+    import ctypes
+    lib = load_library()
+    _req(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    n_th = len(logit_ths)
+    total = x.numel()
+    stride = (total + 3) // 4 * 4
+    buf = torch.empty((n_th, stride), dtype=torch.uint8, device=x.device)
+    ths = (ctypes.c_float * n_th)(*[float(v) for v in logit_ths])
+    if taxonomy is not None:
+        assert taxonomy.dtype == torch.float32 and taxonomy.is_cuda and taxonomy.numel() == 4 and taxonomy.is_contiguous()
+    rc = lib.haff_gate_threshold_masks(x.data_ptr(), buf.data_ptr(), total, stride, ctypes.cast(ths, ctypes.c_void_p), n_th,
+                                       int(on_value), _p(taxonomy), int(blank_class), _stream())
+    check(rc, "haff_gate_threshold_masks")
+    return buf[:, :total].reshape((n_th,) + tuple(x.shape))

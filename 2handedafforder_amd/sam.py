@@ -70,6 +70,10 @@ class SamEncoderHip:
         # the LayerNorm kernels (already at the HBM roofline) stay the default.
         self.fold_norms = False
         self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
+        # fp32 image embeddings out of the neck (bf16 mode): the last 3x3-conv GEMM writes its fp32 accumulators and the
+        # final LayerNorm2d runs in fp32, so the decoder tail (LisaMI355.fp32_tail) starts from un-rounded embeddings.
+        # One bf16 rounding of the embedding ALONE costs 0.0005-0.0014 of mask IoU on random weights (tools/parity_sim.py).
+        self.emb_f32 = False
 
     @staticmethod
     def _fit_rel_pos(table, S):
@@ -188,7 +192,7 @@ class SamEncoderHip:
         y = ops.linear(x, self.w_neck0)
         y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
         cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
-        y = ops.linear(cols, self.w_neck2)
+        y = ops.linear(cols, self.w_neck2, out_dtype=torch.float32 if self.emb_f32 else None)
         y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6)
         return y.view(B, N, s.out_chans)
 
@@ -322,7 +326,7 @@ class SamPromptDecoderHip:
         """emb [Bf, N, C]; frame_idx int64 [P] (prompt -> frame); text [P, C]."""
         P = text.shape[0]
         N, C = emb.shape[1], emb.shape[2]
-        src = emb.index_select(0, frame_idx).reshape(P * N, C)
+        src = emb.index_select(0, frame_idx).reshape(P * N, C).to(self.dtype)
         src = ops.add_bcast(src, self.no_mask, mod=1).view(P, N, C)
         lo_l, iou_l, tax = self.left(src, self.key_pe, text, self.cfg.grid, taps)
         lo_r, iou_r, _ = self.right(src, self.key_pe, text, self.cfg.grid)

@@ -31,7 +31,7 @@ class LisaTrainable:
     def __init__(self, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", lora_r=8, lora_alpha=16, lora_dropout=0.05,
                  ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seed=0, lora_init_b_zero=True):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
-        self.base = LisaMI355(cfg, state_dict, dtype=dtype, device=device)
+        self.base = LisaMI355(cfg, state_dict, dtype=dtype, device=device, fp32_tail=False)  # training is bf16 end to end, as the reference's
         self.lora_r, self.lora_scale, self.lora_dropout = lora_r, lora_alpha / lora_r, lora_dropout
         self.w_ce, self.w_dice, self.w_bce = ce_loss_weight, dice_loss_weight, bce_loss_weight
         self.training = True

@@ -157,6 +157,15 @@ int haff_resize_bilinear(const float* in, float* out, int N, int Hs, int Ws, int
                          void* stream);
 /* mask > logit_th -> 0/255 bytes (inference.py:294-301 with logit_th = logit(th); chat.py:226 with 0) */
 int haff_threshold_masks(const float* in, void* out, long total, float logit_th, void* stream);
+/* a15 in one pass — the output gating + thresholds of 2Haff/inference.py:276-334 and chat.py:226-253:
+ * planes[t][i] = (argmax(taxonomy) != blank_class && logits[i] > thresholds_host[t]) ? on_value : 0.
+ * logits f32 [total] (16-B aligned), planes u8 [n_th][plane_stride] (plane_stride >= total, % 4 == 0), thresholds_host = HOST array of n_th <= 8 LOGIT thresholds
+ * (sigmoid(m) > th restated as m > x*(th), exact in f32: 2handedafforder_amd/postprocess.py), taxonomy = DEVICE pointer
+ * to the prompt's 4 class probabilities (argmax ties -> first, as torch.argmax) or NULL = gate open; blank_class 1 for the
+ * left hand, 0 for the right (inference.py:278,305; chat.py:233,243). on_value 255 (inference PNGs) / 100 (chat JPGs). */
+int haff_gate_threshold_masks(const float* logits, void* planes, long total, long plane_stride,
+                              const float* thresholds_host, int n_th, int on_value, const float* taxonomy, int blank_class,
+                              void* stream);
 
 
 /* ==== training path (LoRA fine-tune: train_ds.py:489-622 driving model_forward, LISA.py:175-430) ==================

@@ -424,6 +424,44 @@ def sam_preprocess(frame_u8_hwc, img_size):
     return F.pad(x, (0, img_size - w, 0, img_size - h))
 
 
+def inference_output_planes(pred_masks_left, pred_masks_right, taxonomies, th_list=(0.1, 0.2, 0.3, 0.5, 0.7)):
+    """Output gating + thresholds of inference.py:276-334: {(side, th): uint8 [H0,W0] of 0/255} = the arrays handed to
+    cv2.imwrite (a hand whose gate is closed writes nothing -> absent key). taxonomy = taxonomies[0] (:276), argmax over
+    the flattened tensor (:278,305); sigmoid in fp32 on the fp32 mask, numpy compare against the python float th
+    (float32 under both numpy casting regimes)."""
+    import numpy as np
+    out = {}
+    taxonomy = taxonomies[0]
+    if taxonomy.numel() == 0:
+        return out
+    t = int(torch.argmax(taxonomy))
+    for side, masks, blank in (("left", pred_masks_left, 1), ("right", pred_masks_right, 0)):
+        if t == blank:
+            continue
+        for pred_mask in masks:
+            if pred_mask.shape[0] == 0:
+                continue
+            prob = torch.sigmoid(pred_mask).detach().cpu().numpy()[0]
+            for th in th_list:
+                th_pred = np.zeros_like(prob)
+                th_pred[prob > th] = 255
+                out[(side, th)] = th_pred.astype(np.uint8)
+    return out
+
+
+def chat_output_planes(pred_mask_left, pred_mask_right, taxonomy):
+    """chat.py:226-253 for one prompt group: (mask_left * 100, mask_right * 100) as uint8; `mask > 0`, argmax == 1 blanks
+    the left hand, == 0 the right (both files are always written)."""
+    import numpy as np
+    left = pred_mask_left.detach().cpu().numpy()[0] > 0
+    if int(torch.argmax(taxonomy)) == 1:
+        left = np.zeros_like(left)
+    right = pred_mask_right.detach().cpu().numpy()[0] > 0
+    if int(torch.argmax(taxonomy)) == 0:
+        right = np.zeros_like(right)
+    return (left * 100).astype(np.uint8), (right * 100).astype(np.uint8)
+
+
 def mask_iou(a, b):
     """train_ds.py:761-776 == ActAffordance/scripts/evaluation/calculate_iou.py:26-41."""
     inter = (a & b).sum().item()

@@ -206,7 +206,8 @@ def test_gemm_swiglu(dev, dtype):
     _close(got, ref, 1.2e-2 if dtype == torch.bfloat16 else 2e-5, "swiglu")
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (130, 70, 36), (300, 1003, 256)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (130, 70, 36), (300, 1003, 256), (1, 256, 256), (6, 32, 2048), (4100, 128, 260),
+                                   (513, 262, 1284), (8192, 256, 256)])
 def test_gemm_f32(dev, M, N, K):
     ops = _ops()
     x = _rand((M, K), dev, torch.float32, 11)
@@ -216,6 +217,30 @@ def test_gemm_f32(dev, M, N, K):
     got = ops.linear(x, w, bias=bias, act=1, resid=resid)
     ref = F.gelu(x.double() @ w.double().T + bias.double()) + resid.double()
     _close(got, ref, 2e-5, "gemm_f32")
+
+
+def test_gemm_f32_rowmap_views_and_tails(dev):
+    """f32-input MFMA GEMM: scattered output rows (negative = dropped), strided A / C views whose rows are not 16-B
+    aligned (scalar epilogue path), K tail of the 16-deep tile, N tail of the 4-column lane group."""
+    ops = _ops()
+    M, N, K = 333, 203, 72
+    xb = _rand((M, K + 4), dev, torch.float32, 21)
+    x = xb[:, 4:]
+    w = _rand((N, K), dev, torch.float32, 22, K ** -0.5)
+    bias = _rand((N + 1,), dev, torch.float32, 23)[1:]          # 4-byte aligned only
+    g = torch.Generator().manual_seed(24)
+    perm = torch.randperm(M + 40, generator=g)[:M].to(torch.int32)
+    perm[::7] = -1
+    row_map = perm.to(dev)
+    out_b = torch.full((M + 40, N + 3), 7.0, device=dev)
+    out = out_b[:, 3:]                                           # rows start 12 B past a 16-B boundary
+    ops.linear(x, w, bias=bias, act=3, row_map=row_map, out=out)
+    ref = F.relu(x.double() @ w.double().T + bias.double())
+    exp = torch.full((M + 40, N), 7.0, device=dev, dtype=torch.float64)
+    keep = row_map >= 0
+    exp[row_map[keep].long()] = ref[keep]
+    _close(out, exp, 2e-5, "gemm_f32 row_map/views")
+    assert torch.equal(out_b[:, :3], torch.full((M + 40, 3), 7.0, device=dev))
 
 
 def _attn_ref(q, k, v, scale, causal=False, q_pos0=0, relh=None, relw=None, S=0):
