@@ -48,11 +48,11 @@ def main(argv, input_fn=input, max_turns=None):
             print("File not found in {}".format(image_path))
             continue
         image_np = load_rgb(image_path)
-        image_clip, image, resize_list, original_size_list = prepare_frame(image_np, cfg, dtype, model.device)
+        frames, resize_list, original_size_list = prepare_frame(image_np, cfg, dtype, model.device)
         input_ids = hprompt.tokenizer_image_token(prompt, tokenizer, return_tensors="pt").unsqueeze(0).to(model.device)
         output_ids, masks_left, masks_right, taxonomies = model.evaluate(
-            image_clip, image, input_ids, resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
-            tokenizer=tokenizer)
+            None, None, input_ids, resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
+            tokenizer=tokenizer, frames_u8=frames)
         ids = output_ids[0][output_ids[0] != IMAGE_TOKEN_INDEX]
         text_output = tokenizer.decode(ids, skip_special_tokens=False).replace("\n", "").replace("  ", " ")
         print("text_output: ", text_output)

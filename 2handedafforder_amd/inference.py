@@ -83,13 +83,14 @@ def load_rgb(path):
 
 
 def prepare_frame(image_np, cfg, dtype, device):
-    """inference.py:229-256: CLIP tensor, resized+normalised+padded SAM tensor, resize_list, original_size_list."""
+    """inference.py:229-256 with the host work moved to the device: the uint8 RGB frame is uploaded once; evaluate()
+    derives the CLIP tensor (CLIPImageProcessor.preprocess) and the resized SAM frame (ResizeLongestSide.apply_image,
+    then normalise + pad fused into the patch-embedding ingest) from it with the Pillow-exact HIP kernels.
+    Returns (frames_u8 [1,H0,W0,3] on the device, resize_list, original_size_list)."""
     original_size = tuple(image_np.shape[:2])
-    image_clip = preprocess.clip_preprocess(torch.from_numpy(image_np.copy()), cfg.clip.image).unsqueeze(0).to(device, dtype)
-    resized = preprocess.resize_longest_side(torch.from_numpy(image_np.copy()), cfg.sam.img_size)
-    resize = tuple(resized.shape[:2])
-    image = preprocess.sam_preprocess(resized, cfg.sam.img_size).unsqueeze(0).to(device, dtype)
-    return image_clip, image, [resize], [original_size]
+    frames = torch.from_numpy(np.array(image_np, copy=True)).unsqueeze(0).to(device)
+    resize = preprocess.get_preprocess_shape(original_size[0], original_size[1], cfg.sam.img_size)
+    return frames, [resize], [original_size]
 
 
 def save_mask(path, plane_u8):
@@ -141,11 +142,11 @@ def main(argv):
                 narration = json.load(f).get("narration", "")
             prompt = hprompt.build_inference_prompt(narration, args.use_mm_start_end)
             image_np = load_rgb(image_path)
-            image_clip, image, resize_list, original_size_list = prepare_frame(image_np, cfg, dtype, device)
+            frames, resize_list, original_size_list = prepare_frame(image_np, cfg, dtype, device)
             input_ids = hprompt.tokenizer_image_token(prompt, tokenizer, return_tensors="pt").unsqueeze(0).to(device)
             output_ids, masks_left, masks_right, taxonomies = model.evaluate(
-                image_clip, image, input_ids, resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
-                tokenizer=tokenizer)
+                None, None, input_ids, resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
+                tokenizer=tokenizer, frames_u8=frames)
             for (side, th), plane in output_planes(masks_left, masks_right, taxonomies).items():
                 save_mask(os.path.join(args.vis_save_path + str(th), dir_name, folder_name, f"aff_{side}.png"), plane)
 

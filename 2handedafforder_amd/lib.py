@@ -63,6 +63,8 @@ _PROTOS = {
     "haff_upscale_mask": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                           c_float, c_int, c_void_p],
     "haff_resize_bilinear": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "haff_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "haff_clip_normalize_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
     "haff_threshold_masks": [c_void_p, c_void_p, c_long, c_float, c_void_p],
     "haff_gate_threshold_masks": [c_void_p, c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     # ---- training path (csrc/train.hip + batched GEMMs) ----

@@ -40,6 +40,7 @@ class LisaMI355:
         # captured once per (batch, position) into a hipGraph and replayed. The KV cache is persistent per
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
         self.decode_graphs = True
+        self._ingest = None
         self._graphs = {}
         self._graph_pool = None   # one memory pool shared by every captured step (replays never overlap)
         self._caches = {}
@@ -181,6 +182,13 @@ class LisaMI355:
         h = ops.linear(rows, self.fc0[0], bias=self.fc0[1], act=ops.ACT_RELU)
         return ops.linear(h, self.fc2[0], bias=self.fc2[1]), b_idx, counts
 
+    def frame_ingest(self):
+        """Device-side host preprocessing (rows a1/a2): Pillow-exact resizes + CLIP normalisation on uint8 frames."""
+        if self._ingest is None:
+            from .preprocess import FrameIngest
+            self._ingest = FrameIngest(self.device)
+        return self._ingest
+
     # ---- the boundary --------------------------------------------------------------------------------------
     @torch.no_grad()
     def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, max_new_tokens=32,
@@ -190,11 +198,18 @@ class LisaMI355:
         # through on the caller's stream. Joined before the mask decoders.
         cur = torch.cuda.current_stream(self.device)
         side = self._sam_stream if self.overlap_streams else cur
+        if frames_u8 is not None:
+            frames_u8 = frames_u8.to(self.device)
+            if images_clip is None:   # a2 on the device: CLIPImageProcessor.preprocess of the same uint8 frames
+                images_clip = self.frame_ingest().clip_pixels(frames_u8, self.cfg.clip.image, self.dtype)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             if frames_u8 is not None:
                 from .preprocess import SAM_MEAN, SAM_STD
-                emb = self.get_visual_embs_u8(frames_u8.to(self.device), SAM_MEAN, SAM_STD)
+                # a1 on the device: ResizeLongestSide (identity when the long side is img_size), then the fused
+                # normalise + pad + patchify of haff_patchify_u8
+                sam_u8, _ = self.frame_ingest().sam_frames(frames_u8, self.cfg.sam.img_size)
+                emb = self.get_visual_embs_u8(sam_u8, SAM_MEAN, SAM_STD)
             else:
                 emb = self.get_visual_embs(images)
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer)

@@ -408,3 +408,34 @@ def gate_threshold_masks(x, logit_ths, on_value=255, taxonomy=None, blank_class=
                                        int(on_value), _p(taxonomy), int(blank_class), _stream())
     check(rc, "haff_gate_threshold_masks")
     return buf[:, :total].reshape((n_th,) + tuple(x.shape))
+
+
+def resample_u8(frames, out_hw, axis, bounds, coeffs):
+    """One axis of Pillow's antialiased resampling on uint8 NHWC frames [B,H,W,3]; bounds/coeffs = device int32 tables."""
+    lib = load_library()
+    _req(frames, "frames")
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4 and frames.shape[3] == 3
+    assert bounds.dtype == torch.int32 and coeffs.dtype == torch.int32 and bounds.is_cuda and coeffs.is_cuda
+    B, H, W, _ = frames.shape
+    oh, ow = out_hw
+    n_out = ow if axis == 0 else oh
+    assert bounds.shape == (n_out, 2) and coeffs.shape[0] == n_out and bounds.is_contiguous() and coeffs.is_contiguous()
+    out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=frames.device)
+    rc = lib.haff_resample_u8(frames.data_ptr(), out.data_ptr(), B, H, W, oh, ow, axis, bounds.data_ptr(), coeffs.data_ptr(),
+                              coeffs.shape[1], _stream())
+    check(rc, "haff_resample_u8")
+    return out
+
+
+def clip_normalize_u8(frames, top, left, size, lut, out_dtype):
+    """uint8 NHWC [B,H,W,3] window (top, left, size, size) -> [B,3,size,size] through the f32 [3,256] device LUT."""
+    lib = load_library()
+    _req(frames, "frames")
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.shape[3] == 3
+    assert lut.dtype == torch.float32 and lut.is_cuda and lut.shape == (3, 256) and lut.is_contiguous()
+    B, H, W, _ = frames.shape
+    out = torch.empty((B, 3, size, size), dtype=out_dtype, device=frames.device)
+    rc = lib.haff_clip_normalize_u8(frames.data_ptr(), out.data_ptr(), B, H, W, int(top), int(left), int(size), lut.data_ptr(),
+                                    _dt(out), _stream())
+    check(rc, "haff_clip_normalize_u8")
+    return out

@@ -155,6 +155,19 @@ int haff_upscale_mask(const void* up1, const float* ln_w, const float* ln_b, con
  * (both stages of Sam.postprocess_masks, sam.py:177-188) */
 int haff_resize_bilinear(const float* in, float* out, int N, int Hs, int Ws, int Hc, int Wc, int Ho, int Wo,
                          void* stream);
+/* ---- device-side frame ingest: the host resizes of the reference (Pillow, on uint8 RGB) and CLIP's normalisation ----
+ * One axis of Pillow's antialiased resampling, bit-exact with Image.resize(BILINEAR|BICUBIC): replaces
+ * ResizeLongestSide.apply_image (segment_anything/utils/transforms.py:27-34) and the resize inside
+ * CLIPImageProcessor.preprocess (third-party transformers; call sites inference.py:233-236, utils/aff_dataset.py:76,228).
+ * in u8 [B][Hin][Win][3] -> out u8 [B][Hout][Wout][3]; axis 0 resamples W (Hout == Hin), axis 1 resamples H (Wout == Win);
+ * bounds i32 [n_out][2] (first input index, tap count) and coeffs i32 [n_out][ksize] (22-bit fixed point) are DEVICE tables
+ * built by preprocess.pil_resample_tables. Horizontal pass first, then vertical. */
+int haff_resample_u8(const void* in, void* out, int B, int Hin, int Win, int Hout, int Wout, int axis, const int* bounds,
+                     const int* coeffs, int ksize, void* stream);
+/* centre crop + 1/255 + (x-mean)/std of CLIPImageProcessor as a f32 [3][256] DEVICE lut: u8 NHWC window (top,left,S,S)
+ * -> out [B][3][S][S], out_dtype 0 bf16 / 1 f32 (the images_clip argument of LISAForCausalLM.evaluate, LISA.py:432) */
+int haff_clip_normalize_u8(const void* in, void* out, int B, int Hin, int Win, int top, int left, int S, const float* lut,
+                           int out_dtype, void* stream);
 /* mask > logit_th -> 0/255 bytes (inference.py:294-301 with logit_th = logit(th); chat.py:226 with 0) */
 int haff_threshold_masks(const float* in, void* out, long total, float logit_th, void* stream);
 /* a15 in one pass — the output gating + thresholds of 2Haff/inference.py:276-334 and chat.py:226-253:

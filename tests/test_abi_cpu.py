@@ -82,11 +82,27 @@ def test_preprocess_contracts():
     assert torch.equal(x[:, :50], ref)
     assert preprocess.get_preprocess_shape(480, 640, 1024) == (768, 1024)
     assert preprocess.clip_preprocess(torch.from_numpy(fr)).shape == (3, 224, 224)
-    ml, mr = torch.tensor([[1.0, -1.0]]), torch.tensor([[-2.0, 3.0]])
-    l, r, t = preprocess.gate_and_threshold(ml, mr, torch.tensor([[0.1, 0.7, 0.1, 0.1]]))
-    assert t == 1 and not l.any() and r.tolist() == [[False, True]]
-    l, r, t = preprocess.gate_and_threshold(ml, mr, torch.tensor([[0.7, 0.1, 0.1, 0.1]]), mode="inference", threshold=0.5)
-    assert t == 0 and l.tolist() == [[True, False]] and not r.any()
+
+
+def test_sigmoid_thresholds_as_exact_fp32_logit_thresholds():
+    """a15: `sigmoid(mask) > th` (fp32 sigmoid, float32(th): inference.py:294-301) == `mask > x*(th)` for the ONE fp32
+    constant postprocess.py hard-codes per threshold. Re-derive each constant by bisection against torch.sigmoid, then
+    check the equivalence on every float within 64 ulps of x*, on a dense sweep and on random logits."""
+    from haff import postprocess as P
+    for th in P.THRESHOLDS:
+        xs = P.sigmoid_logit_threshold(th)
+        assert xs == P.derive_sigmoid_logit_threshold(th), th
+        th32 = torch.tensor(th, dtype=torch.float32)
+        near = [torch.tensor(xs, dtype=torch.float32)]
+        for _ in range(64):
+            near.append(torch.nextafter(near[-1], torch.tensor(float("inf"))))
+        lo = torch.tensor(xs, dtype=torch.float32)
+        for _ in range(64):
+            lo = torch.nextafter(lo, torch.tensor(float("-inf")))
+            near.append(lo)
+        x = torch.cat([torch.stack(near), torch.linspace(-30, 30, 200001), torch.randn(1 << 20, generator=torch.Generator().manual_seed(1)) * 3])
+        assert torch.equal(torch.sigmoid(x) > th32, x > xs), th
+    assert P.sigmoid_logit_threshold(0.5) > 0.0   # sigmoid_f32 rounds to exactly 0.5 just above zero: not the chat rule
 
 
 def test_sentencepiece_tokenizer_wrapper(tmp_path):

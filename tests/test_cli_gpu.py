@@ -67,3 +67,56 @@ def test_chat_cli_roundtrip(dev, tmp_path, monkeypatch, capsys):
     assert "text_output:" in text and "[SEG]" in text
     for name in ("mug_mask_left0.jpg", "mug_mask_right0.jpg", "mug_masked_img_0.jpg"):
         assert os.path.exists(tmp_path / "vis" / name)
+
+
+def test_output_gating_is_bit_exact(dev):
+    """a15 (byte work, bit-exact bar): the uint8 planes the CLIs write — inference.py:276-334 (five sigmoid thresholds,
+    0/255, a gated-out hand writes nothing) and chat.py:226-253 (mask > 0, *100, a gated-out hand is all zeros) — from
+    the HIP gating kernel equal the reference rule restated in the oracle, on real evaluate() logits of three shapes
+    (one with H0*W0 not a multiple of 4) with every taxonomy argmax, plus logits sitting on / one ulp around each
+    threshold."""
+    import torch
+    import haff  # noqa: F401
+    from haff import chat, config as hcfg, inference, postprocess as P, weights as hw
+    from haff.lisa import LisaMI355
+    from oracle import lisa_oracle as O
+    cfg = hcfg.tiny()
+    sd = hw.round_to_bf16_(hw.make_state_dict(cfg, 11))
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev)
+    rng = np.random.default_rng(5)
+    S = cfg.sam.img_size
+    ids = torch.tensor([[cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx, 9, 8, 7, 6]])
+    forced = torch.tensor([[5, cfg.seg_token_idx, cfg.eos_token_id]])
+    for orig in ((S, S), (150, 224), (111, 97)):
+        images = torch.from_numpy(rng.standard_normal((1, 3, S, S), dtype=np.float32))
+        clip = torch.from_numpy(rng.standard_normal((1, 3, 224, 224), dtype=np.float32))
+        _, left, right, tax = model.evaluate(clip.to(dev), images.to(dev), ids.to(dev), [(S, S)], [orig], max_new_tokens=3,
+                                             forced_answer=forced)
+        # scale the logits so every sigmoid threshold cuts through the mask, and plant boundary values
+        left = [left[0] * 8.0]
+        right = [right[0] * 8.0 + 0.3]
+        flat = left[0].view(-1)
+        k = 0
+        for th in P.THRESHOLDS + (0.5,):
+            xs = torch.tensor(P.sigmoid_logit_threshold(th), dtype=torch.float32)
+            for v in (xs, torch.nextafter(xs, torch.tensor(float("inf"))), torch.nextafter(xs, torch.tensor(float("-inf")))):
+                flat[k] = v.item()
+                k += 1
+        flat[k:k + 3] = torch.tensor([0.0, -0.0, 1e-45])
+        for t_class in range(4):
+            t = torch.full((1, 4), 0.1, device=dev)
+            t[0, t_class] = 0.7
+            got = inference.output_planes(left, right, [t])
+            ref = O.inference_output_planes([m.cpu() for m in left], [m.cpu() for m in right], [t.cpu()])
+            assert set(got) == set(ref), (orig, t_class)
+            for key in ref:
+                assert got[key].dtype == np.uint8 and np.array_equal(got[key], ref[key]), (orig, t_class, key)
+            gl, gr, _ = chat.render_outputs(np.zeros(orig + (3,), np.uint8), left[0][0], right[0][0], t)
+            rl, rr = O.chat_output_planes(left[0].cpu(), right[0].cpu(), t.cpu())
+            assert np.array_equal(gl, rl) and np.array_equal(gr, rr), (orig, t_class)
+    # device-side taxonomy gate of the kernel itself (ties -> first maximum, like torch.argmax)
+    x = torch.randn((64, 65), device=dev)
+    for tax, blank, open_ in (([0.4, 0.4, 0.1, 0.1], 0, False), ([0.4, 0.4, 0.1, 0.1], 1, True), ([0.1, 0.2, 0.35, 0.35], 2, False)):
+        planes = P.ops.gate_threshold_masks(x, [0.0, 0.5], 255, torch.tensor(tax, device=dev), blank)
+        exp = torch.stack([(x > 0), (x > 0.5)]).to(torch.uint8) * (255 if open_ else 0)
+        assert torch.equal(planes, exp)

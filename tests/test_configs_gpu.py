@@ -1,0 +1,252 @@
+"""BASELINE.json configs[2..4] at their REAL shapes, under -m gpu:
+
+  * every GEMM / attention launch shape that one bench step issues — configs[2] (7B, 64 frames, SAM blocks of 32 frames),
+    configs[4] (13B, batch 8) — against an fp32 reference on sampled rows / (batch, head) pairs;
+  * one full-width layer of each stack — Llama at 7B AND 13B width, CLIP-L — through the product modules against the CPU
+    oracle (both numeric modes);
+  * configs[3]: LisaTrainable forward + backward at 7B width (Llama 4096/32/11008 + vocab 32003, CLIP-L width, ViT-H width
+    at 1024^2), depth reduced to what the CPU oracle's autograd finishes in seconds — all 6 losses and every trainable
+    gradient.
+Tolerances as in test_ops_gpu.py / test_train_gpu.py (bf16: a few ulps of the output scale; fp32: 1e-5 relative)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_ops_gpu import ACT_REF, _attn_ref, _close, _ops, _rand
+
+pytestmark = pytest.mark.gpu
+
+# (M, N, K, epilogue) — epilogue: act code, "swiglu", "resid", "f32" (fp32 logits), "rowmap", "gather"
+BENCH_GEMMS = [
+    # configs[2]: SAM ViT-H, blocks of 32 frames (M = 32 * 4096)
+    (131072, 1280, 768, {"bias": True}),                              # patch embedding
+    (131072, 3840, 1280, {"bias": True}),                             # qkv, global blocks
+    (131072, 3840, 1280, {"bias": True, "rowmap": 156800}),           # qkv, windowed: scattered into the window-major layout
+    (131072, 1280, 1280, {"bias": True, "resid": True, "gather": 156800}),  # proj, windowed: gathered back
+    (131072, 5120, 1280, {"bias": True, "act": 1}),                   # lin1 + GELU
+    (131072, 1280, 5120, {"bias": True, "resid": True}),              # lin2 + residual
+    (131072, 256, 1280, {}),                                          # neck 1x1
+    (131072, 256, 2304, {"f32": True}),                               # neck 3x3 (fp32 embeddings for the decoder tail)
+    # configs[2]: CLIP-L, 64 frames (M = 64 * 257)
+    (16448, 3072, 1024, {"bias": True}),
+    (16448, 4096, 1024, {"bias": True, "act": 2}),
+    (16448, 1024, 4096, {"bias": True, "resid": True}),
+    (16448, 4096, 1024, {"bias": True}),                              # mm_projector (cls rows dropped by row_map in the model)
+    # configs[2]: Llama-7B prefill, 64 x 291 tokens
+    (18624, 12288, 4096, {}),
+    (18624, 4096, 4096, {"resid": True}),
+    (18624, 22016, 4096, {"swiglu": True}),
+    (18624, 4096, 11008, {"resid": True}),
+    # configs[2]: KV-cached decode steps, M = 64
+    (64, 12288, 4096, {}),
+    (64, 4096, 4096, {"resid": True}),
+    (64, 22016, 4096, {"swiglu": True}),
+    (64, 4096, 11008, {"resid": True}),
+    (64, 32003, 4096, {"f32": True}),                                 # lm_head
+    # configs[1]: batch 1
+    (1, 12288, 4096, {}),
+    (1, 22016, 4096, {"swiglu": True}),
+    (1, 32003, 4096, {"f32": True}),
+    # configs[4]: Llama-13B, batch 8 (M = 8 * 291) and its decode steps
+    (2328, 15360, 5120, {}),
+    (2328, 5120, 5120, {"resid": True}),
+    (2328, 27648, 5120, {"swiglu": True}),
+    (2328, 5120, 13824, {"resid": True}),
+    (8, 15360, 5120, {}),
+    (8, 27648, 5120, {"swiglu": True}),
+    (8, 5120, 13824, {"resid": True}),
+    (8, 32003, 5120, {"f32": True}),
+]
+
+
+@pytest.mark.parametrize("M,N,K,epi", BENCH_GEMMS, ids=lambda v: str(v) if not isinstance(v, dict) else "+".join(sorted(v)) or "plain")
+def test_gemm_at_bench_shapes(dev, M, N, K, epi):
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(M * 7 + N * 3 + K)
+    rows_in = epi.get("gather", M)
+    x = (torch.randn((rows_in, K), generator=g, device=dev)).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn((N,), generator=g, device=dev) if epi.get("bias") else None
+    swiglu = bool(epi.get("swiglu"))
+    n_out = N // 2 if swiglu else N
+    out_rows = epi.get("rowmap", M)
+    out_dtype = torch.float32 if epi.get("f32") else torch.bfloat16
+    resid = torch.randn((out_rows, n_out), generator=g, device=dev).to(out_dtype) if epi.get("resid") else None
+    row_map = a_map = None
+    if "rowmap" in epi:
+        row_map = torch.randperm(out_rows, generator=g, device=dev)[:M].to(torch.int32)
+    if "gather" in epi:
+        a_map = torch.randperm(rows_in, generator=g, device=dev)[:M].to(torch.int32)
+    out = torch.zeros((out_rows, n_out), dtype=out_dtype, device=dev) if row_map is not None else None
+    got = ops.linear(x, w, bias=bias, act=epi.get("act", 0), resid=resid, row_map=row_map, a_map=a_map, swiglu=swiglu,
+                     out=out, out_dtype=out_dtype)
+    assert got.shape == (out_rows, n_out) and bool(torch.isfinite(got.float()).all())
+    # fp32 reference on sampled logical rows (first / last tile rows always included)
+    ns = min(M, 192)
+    sel = torch.unique(torch.cat([torch.randint(0, M, (ns,), generator=g, device=dev), torch.tensor([0, M - 1], device=dev)]))
+    xs = x[a_map[sel].long()] if a_map is not None else x[sel]
+    y = xs.float() @ w.float().T
+    if bias is not None:
+        y = y + bias
+    if swiglu:
+        y5 = y.view(-1, N // 32, 2, 16)
+        y = (F.silu(y5[:, :, 0]) * y5[:, :, 1]).reshape(-1, n_out)
+    else:
+        y = ACT_REF[epi.get("act", 0)](y)
+    orow = row_map[sel].long() if row_map is not None else sel
+    if resid is not None:
+        y = y + resid[orow].float()
+    _close(got[orow], y, 2e-5 if False else (4e-3 if out_dtype == torch.float32 else 1.2e-2), f"gemm {M}x{N}x{K} {epi}")
+    if row_map is not None:   # rows nobody maps to stay untouched
+        untouched = torch.ones(out_rows, dtype=torch.bool, device=dev)
+        untouched[row_map.long()] = False
+        assert float(got[untouched].float().abs().max()) == 0.0
+
+
+BENCH_ATTN = [
+    # B, H, Nq, Nk, d, causal — configs[2] / configs[4] launch shapes
+    (64, 32, 291, 291, 128, True),     # Llama-7B prefill, 64 frames
+    (64, 32, 1, 299, 128, False),      # decode, 2048 (batch, head) pairs: one wave each
+    (8, 40, 291, 291, 128, True),      # Llama-13B prefill, batch 8
+    (8, 40, 1, 299, 128, False),       # 13B decode: 320 pairs, keys split over the four waves
+    (1, 32, 1, 299, 128, False),       # batch-1 decode
+    (64, 16, 257, 257, 64, False),     # CLIP-L, 64 frames
+    (128, 8, 6, 4096, 16, False),      # SAM decoder token -> image, 64 prompts x 2... per side (fp32 tail runs the f32 twin)
+    (64, 8, 4096, 6, 16, False),       # SAM decoder image -> token
+]
+
+
+@pytest.mark.parametrize("case", BENCH_ATTN, ids=str)
+def test_attention_at_bench_shapes(dev, case):
+    ops = _ops()
+    B, H, Nq, Nk, d, causal = case
+    g = torch.Generator(device=dev).manual_seed(B * 131 + Nk)
+    for dtype in ((torch.bfloat16, torch.float32) if d == 16 else (torch.bfloat16,)):
+        q = torch.randn((B, Nq, H, d), generator=g, device=dev).to(dtype).permute(0, 2, 1, 3)
+        k = torch.randn((B, Nk, H, d), generator=g, device=dev).to(dtype).permute(0, 2, 1, 3)
+        v = torch.randn((B, Nk, H, d), generator=g, device=dev).to(dtype).permute(0, 2, 1, 3)
+        got = ops.attention(q, k, v, d ** -0.5, causal=causal, q_pos0=Nk - Nq)
+        assert bool(torch.isfinite(got.float()).all())
+        bs = sorted({0, B - 1, B // 2, B // 3})
+        ref = _attn_ref(q[bs], k[bs], v[bs], d ** -0.5, causal=causal, q_pos0=Nk - Nq)
+        _close(got[bs], ref, 1.5e-2 if dtype == torch.bfloat16 else 2e-5, f"attention {case} {dtype}")
+
+
+def test_sam_attention_at_bench_shapes(dev):
+    """The two SAM encoder attention launches of a 32-frame block: 800 windows x 16 heads (fused window kernel) and
+    32 frames x 16 heads x 4096^2 (rel-pos tables + flash kernel), sampled (window | frame, head) pairs vs the formula
+    of image_encoder.py:235-260,354-392."""
+    ops = _ops()
+    H, d = 16, 80
+    g = torch.Generator(device=dev).manual_seed(5)
+    for n_b, S in ((800, 14), (32, 64)):
+        N = S * S
+        qkv = (torch.randn((n_b, N, 3, H, d), generator=g, device=dev) * 0.7).to(torch.bfloat16)
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        th = (torch.randn((2 * S - 1, d), generator=g, device=dev) * 0.3).to(torch.bfloat16).float()
+        tw = (torch.randn((2 * S - 1, d), generator=g, device=dev) * 0.3).to(torch.bfloat16).float()
+        if S == 14:
+            got = ops.window_attention(q, k, v, d ** -0.5, th, tw, S)
+        else:
+            relh, relw = ops.relpos_tables(q, th, tw, S)
+            got = ops.attention(q, k, v, d ** -0.5, relh=relh, relw=relw, S=S)
+        idx = torch.arange(S, device=dev)
+        Rh = th[(idx[:, None] - idx[None, :]) + S - 1]
+        Rw = tw[(idx[:, None] - idx[None, :]) + S - 1]
+        for b, h in ((0, 0), (n_b - 1, H - 1), (n_b // 2, 7)):
+            qq, kk, vv = q[b, h].double(), k[b, h].double(), v[b, h].double()
+            s = (qq * d ** -0.5) @ kk.T
+            r_q = qq.view(S, S, d)
+            rel_h = torch.einsum("hwc,hkc->hwk", r_q, Rh.double())
+            rel_w = torch.einsum("hwc,wkc->hwk", r_q, Rw.double())
+            s = (s.view(S, S, S, S) + rel_h[:, :, :, None] + rel_w[:, :, None, :]).view(N, N)
+            ref = torch.softmax(s, -1) @ vv
+            _close(got[b, :, h * d:(h + 1) * d], ref, 2e-2, f"sam attention S={S} ({b},{h})")
+
+
+# ---- one full-width layer of each stack against the CPU oracle --------------------------------------------------------
+def _llm_cfg(width):
+    from haff import config as hcfg
+    cfg = hcfg.haff_7b() if width == "7b" else hcfg.haff_13b()
+    cfg.llm.layers = 1
+    return cfg
+
+
+@pytest.mark.parametrize("width", ["7b", "13b"])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_width_llama_layer_matches_oracle(dev, width, mode):
+    """transformers LlamaDecoderLayer + final norm at H = 4096 / 32 heads / ffn 11008 and H = 5120 / 40 / 13824: prefill of
+    T = 291 positions (2 rows), then two KV-cached steps, vs the oracle's llama_forward on the same weights."""
+    import haff  # noqa: F401
+    from haff import weights as hw
+    from haff.llava import LlamaHip
+    from oracle import lisa_oracle as O
+    cfg = _llm_cfg(width)
+    shapes = {k: v for k, v in hw.llm_shapes(cfg).items() if k.startswith("model.layers.") or k == "model.norm.weight"}
+    shapes["model.embed_tokens.weight"] = (8, cfg.llm.hidden)   # unused rows: the test feeds embeddings directly
+    shapes["lm_head.weight"] = (8, cfg.llm.hidden)
+    sd = hw.make_state_dict(cfg, 31, shapes)
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)
+    B, T, Hd = 2, 291, cfg.llm.hidden
+    x = torch.randn((B, T + 2, Hd), generator=torch.Generator().manual_seed(2))
+    if mode == "bf16":
+        x = x.to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = O.llama_forward(sd, x, cfg.llm)                      # no-cache recompute over T + 2 positions
+    llm = LlamaHip(sd, cfg.llm, dtype, dev)
+    cache = llm.new_cache(B, T + 2)
+    xd = x.to(dev, dtype)
+    got = [llm.forward(xd[:, :T].contiguous(), cache)]
+    for s in range(2):
+        got.append(llm.forward(xd[:, T + s:T + s + 1].contiguous(), cache))
+    got = torch.cat(got, 1).float().cpu()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"llama {width} {mode}: hidden rel err {err:.3e}")
+    assert err <= (2e-4 if mode == "f32" else 2.5e-2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_width_clip_layer_and_projector_match_oracle(dev, mode):
+    """CLIP-L/14 width (1024 / 16 heads / mlp 4096, 257 tokens): embeddings + pre-LN + the encoder layers that
+    select_layer = -2 keeps of a 3-layer stack + the 7B mm_projector, vs the oracle's encode_images."""
+    import haff  # noqa: F401
+    from haff import config as hcfg, weights as hw
+    from haff.llava import ClipTowerHip
+    from oracle import lisa_oracle as O
+    cfg = hcfg.haff_7b()
+    cfg.clip.layers = 3
+    shapes = hw.clip_shapes(cfg.clip)
+    shapes["model.mm_projector.weight"] = (cfg.llm.hidden, cfg.clip.hidden)
+    shapes["model.mm_projector.bias"] = (cfg.llm.hidden,)
+    sd = hw.make_state_dict(cfg, 32, shapes)
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    x = torch.randn((2, 3, 224, 224), generator=torch.Generator().manual_seed(3))
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)
+        x = x.to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = O.encode_images(sd, cfg, x)
+    tower = ClipTowerHip(sd, cfg.clip, dtype, dev)
+    h = tower.hidden(x.to(dev))
+    got = tower.project(h, 2, sd["model.mm_projector.weight"].to(dev, dtype).contiguous(),
+                        sd["model.mm_projector.bias"].to(dev, torch.float32)).float().cpu()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"clip-L {mode}: projected features rel err {err:.3e}")
+    assert got.shape == ref.shape == (2, 256, cfg.llm.hidden) and err <= (2e-4 if mode == "f32" else 2.5e-2)
+
+
+# ---- configs[3]: fine-tune step at 7B width ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_finetune_forward_backward_at_7b_width(dev, mode):
+    from haff import config as hcfg
+    from test_train_gpu import check_forward_backward, make_batch
+    cfg = hcfg.LisaCfg(name="7B-width, reduced depth",
+                       sam=hcfg.SamCfg(depth=2, global_idx=(1,)),      # ViT-H width at 1024^2: one windowed + one global block
+                       clip=hcfg.ClipCfg(layers=2),                    # CLIP-L width; select_layer = -2 runs one layer
+                       llm=hcfg.LlamaCfg(layers=1))                    # 4096 / 32 heads / 11008, vocab 32003
+    check_forward_backward(dev, cfg, mode, make_batch(cfg, hw=(100, 90)), min_tensors=140)

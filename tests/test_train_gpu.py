@@ -29,13 +29,19 @@ def make_batch(cfg, b=2, L=14, seed=0, hw=(100, 90)):
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_model_forward_loss_and_grads_match_oracle(dev, mode):
     import haff  # noqa: F401
-    from haff import config as hcfg, weights as hw
+    from haff import config as hcfg
+    cfg = hcfg.tiny()
+    check_forward_backward(dev, cfg, mode, make_batch(cfg), min_tensors=150)
+
+
+def check_forward_backward(dev, cfg, mode, batch, min_tensors):
+    """All 6 losses and every trainable gradient of LisaTrainable (HIP forward + backward) vs the oracle under autograd."""
+    import haff  # noqa: F401
+    from haff import weights as hw
     from haff.train_model import LisaTrainable
     from oracle import lisa_oracle as O
-    cfg = hcfg.tiny()
     sd = hw.make_state_dict(cfg, 21)
     dtype = torch.float32 if mode == "f32" else torch.bfloat16
-    batch = make_batch(cfg)
     if mode == "bf16":
         hw.round_to_bf16_(sd)
         batch["images"] = batch["images"].to(torch.bfloat16).float()
@@ -87,7 +93,7 @@ def test_model_forward_loss_and_grads_match_oracle(dev, mode):
         flat_r.append(r.reshape(-1))
         assert scale == 0 or rel <= gtol, f"{k}: grad rel err {rel:.3g} (scale {scale:.3g})"
     print(f"{mode}: {n_checked} gradient tensors checked, worst {worst}")
-    assert n_checked > 150
+    assert n_checked > min_tensors
     cos = torch.nn.functional.cosine_similarity(torch.cat(flat_g), torch.cat(flat_r), dim=0).item()
     print(f"{mode}: global gradient cosine {cos:.6f}")
     assert cos >= (0.99999 if mode == "f32" else 0.995)
