@@ -94,7 +94,7 @@ def check_forward_backward(dev, cfg, mode, batch, min_tensors):
         assert scale == 0 or rel <= gtol, f"{k}: grad rel err {rel:.3g} (scale {scale:.3g})"
     print(f"{mode}: {n_checked} gradient tensors checked, worst {worst}")
     assert n_checked > min_tensors
-    cos = torch.nn.functional.cosine_similarity(torch.cat(flat_g), torch.cat(flat_r), dim=0).item()
+    cos = torch.nn.functional.cosine_similarity(torch.cat(flat_g).double(), torch.cat(flat_r).double(), dim=0).item()
     print(f"{mode}: global gradient cosine {cos:.6f}")
     assert cos >= (0.99999 if mode == "f32" else 0.995)
 
