@@ -37,7 +37,6 @@ struct AttnArgs {
   int q_pos0;  // causal: key j visible to query i iff j <= i + q_pos0
   const float *relh, *relw;  // [B*H][Nq][S]
   int S;
-  const bf16_t *tab_h, *tab_w;  // BIAS == 4: rel-pos tables [2S-1][d] (the terms are computed in the kernel)
 };
 
 constexpr int QB = 128;   // queries per workgroup
@@ -66,7 +65,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int STAGE_BYTES = KT * KSTRIDE + KT * VSTRIDE;  // one K tile + one V tile
   unsigned char* sKV = smem_raw;                             // two stages (double buffer: one barrier per tile)
   float* sRel = reinterpret_cast<float*>(smem_raw + 2 * STAGE_BYTES);  // [QB][2*SMAX+1] when BIAS==1
-  unsigned short* sRelh = reinterpret_cast<unsigned short*>(smem_raw + 2 * STAGE_BYTES);  // [QB][64] bf16 when BIAS==4
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,89 +141,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       }
     }
   }
-  // BIAS == 4 (SAM global blocks, S == 64): same layout of terms as BIAS == 2, but computed here from q and the
-  // rel-pos tables (image_encoder.py:354-392) instead of read from 2 x [B*H][N][64] fp32 tensors a separate kernel
-  // wrote (1 GB per 32-frame block each way). A q-tile is 16 consecutive tokens of one grid row (qh uniform):
-  //   rel_w: T^T[r][q] = Rw[r].q for all 127 table rows (8 MFMA m-tiles) -> wave-private scratch -> the lane keeps
-  //          its 16 terms r = qw - kw + 63 in registers;
-  //   rel_h: rows qh .. qh+63 only (4 m-tiles), row m is kh = 63 - m -> bf16 table [query][kh] in LDS, one read per KV tile.
-  // The scratch aliases the K/V stages (not yet in use); a barrier separates the two uses.
-  if (BIAS == 4) {
-    constexpr int SR = 132;
-    float* scr = reinterpret_cast<float*>(smem_raw) + wave * (16 * SR);
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int qtok = q0 + wave * 32 + qt * 16;          // first token of the q-tile (multiple of 16)
-      const int qh = min(qtok, p.Nq - 1) >> 6, qw = (qtok & 63) + fr;
-      const int qc = min(qrow[qt], p.Nq - 1);
-      bf16x8 qraw[NKD];
-#pragma unroll
-      for (int kd = 0; kd < NKD; ++kd) {
-        const int col = kd * 32 + fh * 8;
-        uint4 r = make_uint4(0, 0, 0, 0);
-        if (col < p.d) r = *reinterpret_cast<const uint4*>(qb + (long)qc * p.q_st + col);
-        qraw[kd] = __builtin_bit_cast(bf16x8, r);
-      }
-      // table fragments are fetched four m-tiles at a time (12 independent 16-B loads in flight), then multiplied
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        uint4 a[4][NKD];
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {
-          const int row = min(16 * (4 * g + m4) + fr, 126);
-#pragma unroll
-          for (int kd = 0; kd < NKD; ++kd) {
-            const int col = kd * 32 + fh * 8;
-            a[m4][kd] = make_uint4(0, 0, 0, 0);
-            if (col < p.d) a[m4][kd] = *reinterpret_cast<const uint4*>(p.tab_w + row * p.d + col);
-          }
-        }
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kd = 0; kd < NKD; ++kd)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m4][kd]), qraw[kd], acc, 0, 0, 0);
-          float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-          store4(scr + fr * SR + 16 * (4 * g + m4) + 4 * fh, v);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = min(max(qw - (16 * t + 4 * fh + j) + 63, 0), 126);
-          relw_r[qt][t][j] = scr[fr * SR + r] * LOG2E;
-          asm volatile("" : "+v"(relw_r[qt][t][j]));   // scale here, not in the tile loop (see the note at the entry point)
-        }
-      __builtin_amdgcn_wave_barrier();
-      {
-        uint4 a[4][NKD];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int row = min(qh + 16 * mt + fr, 126);
-#pragma unroll
-          for (int kd = 0; kd < NKD; ++kd) {
-            const int col = kd * 32 + fh * 8;
-            a[mt][kd] = make_uint4(0, 0, 0, 0);
-            if (col < p.d) a[mt][kd] = *reinterpret_cast<const uint4*>(p.tab_h + row * p.d + col);
-          }
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kd = 0; kd < NKD; ++kd)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt][kd]), qraw[kd], acc, 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            sRelh[(wave * 32 + qt * 16 + fr) * 64 + (63 - (16 * mt + 4 * fh + j))] = f32_to_bf16(acc[j] * LOG2E);
-        }
-      }
-    }
-    __syncthreads();   // scratch -> K/V stages; sRelh complete
-  }
   // BIAS == 3 (S <= 16, SAM windows): keys are visited as a grid with rows padded to 16 (virtual key v -> kh = v>>4,
   // kw = v&15, real key kh*S+kw, kw >= S masked). A 64-key tile is then 4 whole grid rows, so the lane's 4 relw terms
   // are tile-invariant and the 4 relh terms of a tile are picked from 16 registers: no LDS lookups, no index math.
@@ -257,14 +172,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     }
   }
 
-  float relh_next[2] = {0.f, 0.f};   // BIAS 2: natural-log domain (scaled at use); BIAS 4: already log2 domain
+  float relh_next[2] = {0.f, 0.f};   // BIAS 2: natural-log domain (scaled at use)
   if (BIAS == 2) {
     relh_next[0] = relh_row[0][0];
     relh_next[1] = relh_row[1][0];
-  }
-  if (BIAS == 4) {
-    relh_next[0] = bf16_to_f32(sRelh[(wave * 32 + fr) * 64]);
-    relh_next[1] = bf16_to_f32(sRelh[(wave * 32 + 16 + fr) * 64]);
   }
 
   // ---- K/V staging coordinates ----
@@ -374,10 +285,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       // The running max is folded into the accumulator's initial value too: the MFMA then delivers s - m_run and
       // the exponentials need no subtraction unless this tile raises the max (first tile: no max yet, plain s).
       const float msub = m_run[qt];
-      const float rhv = (BIAS == 4 ? relh_next[qt] : relh_next[qt] * LOG2E) - msub;
+      const float rhv = relh_next[qt] * LOG2E - msub;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        if (BIAS == 2 || BIAS == 4) sacc[t][qt] = f32x4{relw_r[qt][t][0] + rhv, relw_r[qt][t][1] + rhv, relw_r[qt][t][2] + rhv, relw_r[qt][t][3] + rhv};
+        if (BIAS == 2) sacc[t][qt] = f32x4{relw_r[qt][t][0] + rhv, relw_r[qt][t][1] + rhv, relw_r[qt][t][2] + rhv, relw_r[qt][t][3] + rhv};
         else if (BIAS == 3) {
           const float rb = rh3[t] - msub;
           sacc[t][qt] = f32x4{relw3[qt][0] + rb, relw3[qt][1] + rb, relw3[qt][2] + rb, relw3[qt][3] + rb};
@@ -385,7 +296,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         else sacc[t][qt] = f32x4{-msub, -msub, -msub, -msub};
       }
       if (BIAS == 2 && kt + 1 < nkt) relh_next[qt] = relh_row[qt][kt + 1];  // one tile ahead: latency hidden
-      if (BIAS == 4 && kt + 1 < nkt) relh_next[qt] = bf16_to_f32(sRelh[(wave * 32 + qt * 16 + fr) * 64 + kt + 1]);
     }
 #pragma unroll
     for (int kd = 0; kd < NKD; ++kd) {
@@ -543,7 +453,6 @@ int launch_attn(const AttnArgs& p, hipStream_t s) {
   constexpr int KSTRIDE = DP * 2 + 16, VSTRIDE = DP * 2 + 32;
   size_t lds = 2 * ((size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE);
   if (BIAS == 1) lds += (size_t)QB * (2 * 32 + 1) * sizeof(float);
-  if (BIAS == 4) lds += (size_t)QB * 64 * sizeof(unsigned short);
   dim3 grid(((p.Nq + QB - 1) / QB) * p.H * p.B), block(256);
   hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL, NDT, LSUM>), grid, block, lds, s, p);
   return haff_check_launch();
@@ -689,7 +598,7 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   if (rel && (causal || S <= 0 || (Nk % S) != 0)) return HAFF_ERR_BAD_ARG;
   AttnArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
              reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
-             B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S, nullptr, nullptr};
+             B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
@@ -719,43 +628,6 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   if (dp == 64) return launch_attn<64, 0, false>(p, s);
   if (dp == 96) return launch_attn<96, 0, false>(p, s);
   return launch_attn<128, 0, false>(p, s);
-}
-
-// EXPERIMENTAL, not on the default path (sam.py: fused_global_attention = False). Inside the full ViT-H encoder, at two
-// workgroups per CU, this kernel intermittently produced wrong rel-pos terms for whole 16-query tiles of first-wave
-// workgroups (tests/test_fullsize_gpu.py caught it as run-to-run differences); the same launch replayed with warm
-// caches, the kernel at one workgroup per CU, and the generic BIAS == 2 kernel at the same LDS size and occupancy were
-// all stable. The cause was not found; pinning the rel_w terms in registers as soon as they are read
-// made every observed run stable, which is kept, but the generic path stays the default until the cause is known.
-// SAM GLOBAL attention (64 x 64 tokens) with the decomposed rel-pos terms computed in the kernel from the bf16 tables:
-// replaces haff_relpos_tables_bf16 + haff_attention_bf16(relh, relw) for the 4 global ViT-H blocks. q/k/v/o as in
-// haff_attention_bf16 with Nq == Nk == S*S; tab_h/tab_w: bf16 [2S-1][d] contiguous. Supported: S == 64, d == 80.
-extern "C" int haff_global_attention_bf16(const void* q, long q_sb, long q_sh, long q_st,
-                                          const void* k, long k_sb, long k_sh, long k_st,
-                                          const void* v, long v_sb, long v_sh, long v_st,
-                                          void* o, long o_sb, long o_sh, long o_st,
-                                          int B, int H, int S, int d, float scale,
-                                          const void* tab_h, const void* tab_w, void* stream) {
-  if (B <= 0 || H <= 0 || S <= 0 || d <= 0 || !tab_h || !tab_w) return HAFF_ERR_BAD_ARG;
-  if ((q_st & 7) || (k_st & 7) || (v_st & 7) || (o_st & 3) || (q_sh & 7) || (k_sh & 7) || (v_sh & 7) || (o_sh & 3) ||
-      (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (o_sb & 3) || (reinterpret_cast<uintptr_t>(tab_h) & 15) ||
-      (reinterpret_cast<uintptr_t>(tab_w) & 15))
-    return HAFF_ERR_BAD_ARG;
-  if (S != 64 || d != 80) return HAFF_ERR_UNSUPPORTED;
-  const int N = S * S;
-  AttnArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
-             reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
-             B, H, N, N, d, scale, 0, nullptr, nullptr, S, reinterpret_cast<const bf16_t*>(tab_h),
-             reinterpret_cast<const bf16_t*>(tab_w)};
-  static bool attr_set = false;
-  if (!attr_set) {
-    const size_t lds = 2 * ((size_t)KT * (96 * 2 + 16) + (size_t)KT * (96 * 2 + 32)) + (size_t)QB * 64 * 2;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<96, 4, false, 6, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return HAFF_ERR_LAUNCH;
-    attr_set = true;
-  }
-  return launch_attn<96, 4, false, 6, true>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---------------------------------------------------------------------------------------------------

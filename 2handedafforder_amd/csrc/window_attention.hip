@@ -479,18 +479,17 @@ extern "C" int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, l
             grid_h, grid_w, grid_h > 0 ? (grid_h + S - 1) / S : 0, pad_token};
   if (grid_h > 0) {
     // padded windows: square window grid, whole images, pad row addressable with the 32-bit staging offsets
+    // ... and at or after every window's base: the kernel reaches the pad row through an UNSIGNED 32-bit byte offset from
+    // that base ((pad_token * k_st - win * k_sb) * 2), which would wrap for a pad row placed before a window
     if (grid_w != grid_h || (n_windows % (p.wps * p.wps)) != 0 || pad_token < 0 || q_st != k_st ||
-        (pad_token + 1) * k_st * 2 >= (1L << 32))
+        (pad_token + 1) * k_st * 2 >= (1L << 32) || pad_token * k_st < (long)(n_windows - 1) * k_sb)
       return HAFF_ERR_BAD_ARG;
   }
   using C = WinCfg<80, 14>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_kernel<80, 14>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return HAFF_ERR_LAUNCH;
-    attr_set = true;
-  }
+  // the attribute is per device and this entry point keeps no state: set it on every call (a host-side table write)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_kernel<80, 14>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+    return HAFF_ERR_LAUNCH;
   // persistent: one 7-wave workgroup per CU (150 KB LDS); a multiple of 8 workgroups keeps the item -> XCD mapping
   const int n_items = n_windows * H;
   dim3 grid(n_items < 256 ? n_items : 256), block(C::NTHREADS);

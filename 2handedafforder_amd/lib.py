@@ -38,9 +38,6 @@ _PROTOS = {
                            c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_relpos_tables_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_int, c_int, c_void_p],
-    "haff_global_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
-                                   c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
-                                   c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "haff_window_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                    c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                    c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_long,

@@ -60,10 +60,6 @@ class SamEncoderHip:
         self.w_neck2 = sd[E + ".neck.2.weight"].permute(0, 2, 3, 1).reshape(s.out_chans, -1).to(dev, dtype).contiguous()
         self.neck3 = (_f32(sd[E + ".neck.3.weight"], dev), _f32(sd[E + ".neck.3.bias"], dev))
         self._maps = {}
-        # Global blocks: rel-pos terms computed inside the attention kernel (haff_global_attention_bf16). Worth +0.7 % of
-        # the frame rate, but OFF: in the full encoder it was not run-to-run stable (attention.hip, note at the entry
-        # point); the default is haff_relpos_tables_bf16 + the generic flash kernel, which is.
-        self.fused_global_attention = False
         # Optional: norm1 -> qkv and norm2 -> lin1 folded into the products (gamma into the weights, beta into the bias,
         # per-row {mean, rstd} from haff_row_stats applied in the GEMM epilogue, haff_gemm_bf16_ln). Measured neutral
         # (95.0 vs 95.2-96.5 frames/s): the statistics pass still reads x once and the epilogue pays for the fold, so
@@ -172,8 +168,6 @@ class SamEncoderHip:
                 v = q5[:, :, 2].permute(0, 2, 1, 3)
                 if not blk["global"] and ops.window_attention_supported(q, S):
                     a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
-                elif blk["global"] and self.fused_global_attention and ops.global_attention_supported(q, S):
-                    a = ops.global_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
                 else:
                     relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
                     a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)

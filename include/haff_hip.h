@@ -81,17 +81,6 @@ int haff_relpos_tables(const void* q, long q_sb, long q_sh, long q_st, const flo
 int haff_relpos_tables_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* tab_h, const void* tab_w,
                             float* relh, float* relw, int B, int H, int S, int d, void* stream);
 
-/* SAM GLOBAL attention (S x S = 64 x 64 tokens) with the decomposed rel-pos terms computed in the kernel from the
- * bf16 tables (image_encoder.py:235-260,354-392): replaces haff_relpos_tables_bf16 + haff_attention_bf16(relh, relw)
- * for the 4 global ViT-H blocks — no [B*H][N][S] fp32 term tensors. q/k/v/o as haff_attention_bf16, Nq == Nk == S*S;
- * tab_*: bf16 [2S-1][d]. Supported: S == 64, d == 80; otherwise HAFF_ERR_UNSUPPORTED (-2).
- * EXPERIMENTAL: not used by the default path (sam.py: fused_global_attention = False). Inside the full encoder it was
- * not run-to-run stable on MI355X; the generic pair above is. */
-int haff_global_attention_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* k, long k_sb, long k_sh,
-                               long k_st, const void* v, long v_sb, long v_sh, long v_st, void* o, long o_sb,
-                               long o_sh, long o_st, int B, int H, int S, int d, float scale, const void* tab_h,
-                               const void* tab_w, void* stream);
-
 /* fused SAM WINDOW attention with the decomposed rel-pos bias computed in the kernel (one pass over HBM; replaces
  * haff_relpos_tables_bf16 + haff_attention_bf16 for the 28 windowed ViT-H blocks): Attention.forward
  * (image_encoder.py:235-260) + add_decomposed_rel_pos (:354-392) + get_rel_pos with q_size == k_size (:322-351).

@@ -363,29 +363,6 @@ def test_linear_gather_rows(dev, M, N, K):
     _close(xr, ref, 2e-2, "gather linear in place")
 
 
-def test_global_attention_fused(dev):
-    """haff_global_attention_bf16 (S = 64, d = 80; rel-pos terms computed in the kernel) vs the reference formula and vs
-    the table kernel + generic attention pair it replaces."""
-    ops = _ops()
-    S, d, H, B = 64, 80, 2, 2
-    N = S * S
-    qkv = _rand((B, N, 3, H, d), dev, torch.bfloat16, 49, 1.5)
-    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    th = _rand((2 * S - 1, d), dev, torch.float32, 46, 0.5).to(torch.bfloat16).float()
-    tw = _rand((2 * S - 1, d), dev, torch.float32, 47, 0.5).to(torch.bfloat16).float()
-    assert ops.global_attention_supported(q, S)
-    scale = d ** -0.5
-    got = ops.global_attention(q, k, v, scale, th, tw, S)
-    rh, rw = ops.relpos_tables(q, th, tw, S)
-    old = ops.attention(q, k, v, scale, relh=rh, relw=rw, S=S)
-    _close(got, old.float(), 2e-2, "fused vs generic global attention")
-    idx = torch.arange(S, device=dev)[:, None] - torch.arange(S, device=dev)[None, :] + (S - 1)
-    rq = q.float().reshape(B * H, S, S, d)
-    relh = torch.einsum("bhwc,hkc->bhwk", rq, th[idx]).reshape(B * H, N, S)
-    relw = torch.einsum("bhwc,wkc->bhwk", rq, tw[idx]).reshape(B * H, N, S)
-    _close(got, _attn_ref(q, k, v, scale, False, 0, relh, relw, S), 2e-2, "fused global attention")
-
-
 def test_window_attention_pad_token(dev):
     """Padded windows: rows of padded tokens are never written (filled with NaN here); the kernel must take the pad
     token row instead. 2 images of 20x20 tokens -> 2x2 windows of 14x14, windows on the right/bottom edge padded."""

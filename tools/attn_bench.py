@@ -44,11 +44,6 @@ def main():
             v = torch.randn((B, Nk, H, d), device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
         relh = relw = None
         line = f"{name:16s}"
-        if S == 64 and d == 80:
-            th0 = torch.randn((2 * S - 1, d), device=dev)
-            tw0 = torch.randn((2 * S - 1, d), device=dev)
-            t_f = timeit(lambda: ops.global_attention(q, k, v, d ** -0.5, th0, tw0, S))
-            line += f" fused(in-kernel rel-pos) {t_f:8.1f} us |"
         if S:
             th = torch.randn((2 * S - 1, d), device=dev)
             tw = torch.randn((2 * S - 1, d), device=dev)
