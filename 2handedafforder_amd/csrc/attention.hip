@@ -37,6 +37,7 @@ struct AttnArgs {
   int q_pos0;  // causal: key j visible to query i iff j <= i + q_pos0
   const float *relh, *relw;  // [B*H][Nq][S]
   int S;
+  const int* nk_rows;  // optional, device int32 [B]: batch b sees only its first nk_rows[b] (<= Nk) keys (ragged KV caches)
 };
 
 constexpr int QB = 128;   // queries per workgroup
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
   const int b = bh_id / p.H, h = bh_id - b * p.H;
   const int q0 = qblk * QB;
+  const int Nk = p.nk_rows ? min(p.nk_rows[b], p.Nk) : p.Nk;   // keys visible to this batch entry
 
   const bf16_t* qb = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
   const bf16_t* kb = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
   const long k_step = (long)KT * p.k_st, v_step = (long)KT * p.v_st;
   auto load_tile = [&](int kt) {
-    const bool plain = (BIAS != 3) && (kt * KT + KT <= p.Nk);  // wave-uniform: whole tile in range, no remap
+    const bool plain = (BIAS != 3) && (kt * KT + KT <= Nk);  // wave-uniform: whole tile in range, no remap
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       if (col_ok[i]) {   // chunks past d are never loaded nor written: their LDS slots are set once (below)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         } else {
           int key = kt * KT + st_row[i];
           if (BIAS == 3) key = min(key >> 4, p.S - 1) * p.S + min(key & 15, p.S - 1);
-          key = min(key, p.Nk - 1);
+          key = min(key, Nk - 1);
           kreg[i] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st + st_c[i] * 8);
           vreg[i] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st + st_c[i] * 8);
         }
@@ -254,11 +256,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   float m_run[2] = {0.f, 0.f};   // reference max the accumulators are expressed against (set by the first tile)
   float l_run[2] = {0.f, 0.f};
 
-  int nkt = (p.Nk + KT - 1) / KT;
+  int nkt = (Nk + KT - 1) / KT;
   if (BIAS == 3) nkt = (16 * p.S + KT - 1) / KT;
   if (CAUSAL) {
     const int last_q = min(q0 + QB - 1, p.Nq - 1);
-    const int last_key = min(last_q + p.q_pos0, p.Nk - 1);
+    const int last_key = min(last_q + p.q_pos0, Nk - 1);
     nkt = min(nkt, last_key / KT + 1);
   }
 
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     // ---- scale, bias, mask, online softmax in the log2 domain (lane owns query column fr of each q-tile) ----
     // wave-uniform: does any element of this tile need masking?
-    bool need_mask = (kt * KT + KT > p.Nk);
+    bool need_mask = (kt * KT + KT > Nk);
     if (CAUSAL) need_mask = need_mask || (kt * KT + KT - 1 > q0 + wave * 32 + p.q_pos0);
     int off_h[4][4], off_w[4][4];
     if (BIAS == 1) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int kc = min(kt * KT + 16 * t + 4 * fh + r, p.Nk - 1);
+          const int kc = min(kt * KT + 16 * t + 4 * fh + r, Nk - 1);
           const int kh = (int)(((float)kc + 0.5f) * inv_S);  // exact for kc < 2^20
           off_h[t][r] = kh;
           off_w[t][r] = p.S + kc - kh * p.S;
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kt * KT + 16 * t + 4 * fh + r;
-            bool ok = key < p.Nk;
+            bool ok = key < Nk;
             if (CAUSAL) ok = ok && (key <= qrow[qt] + p.q_pos0);
             sacc[t][qt][r] = ok ? sacc[t][qt][r] : -INFINITY;
           }
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   const int bh = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
   if (bh >= p.B * p.H) return;
   const int b = bh / p.H, h = bh - b * p.H;
+  const int Nk = p.nk_rows ? min(p.nk_rows[b], p.Nk) : p.Nk;
   const int g = lane >> 4, c = lane & 15;
   const bf16_t* qb = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
   const bf16_t* kb = p.k + (long)b * p.k_sb + (long)h * p.k_sh + c * 8;
@@ -502,12 +505,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 
   float m_run = -1e30f, l_run = 0.f;
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int n_it = (p.Nk + 3) / 4;
+  const int n_it = (Nk + 3) / 4;
   for (int it0 = SPLIT ? wave * DEC_UNROLL : 0; it0 < n_it; it0 += (SPLIT ? 4 : 1) * DEC_UNROLL) {
     uint4 kr[DEC_UNROLL], vr[DEC_UNROLL];
 #pragma unroll
     for (int u = 0; u < DEC_UNROLL; ++u) {
-      const int key = min((it0 + u) * 4 + g, p.Nk - 1);
+      const int key = min((it0 + u) * 4 + g, Nk - 1);
       kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st);
       vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st);
     }
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
         s += qv[2 * j + 1] * __builtin_bit_cast(float, kw[j] & 0xffff0000u);
       }
       s = row16_sum(s);
-      s = key < p.Nk ? s : -INFINITY;
+      s = key < Nk ? s : -INFINITY;
       const float m_new = fmaxf(m_run, s);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       const float pr = __builtin_amdgcn_exp2f(s - m_new);
@@ -583,13 +586,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 // q/k/v/o: bf16; strides in elements (batch, head, token). d % 8 == 0, d <= 128.
 // causal != 0: key j visible to query i iff j <= i + q_pos0.
 // relh/relw (may be null): fp32 [B*H][Nq][S] decomposed rel-pos terms; key index -> (kh, kw) = (j / S, j % S).
-extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_st,
-                                   const void* k, long k_sb, long k_sh, long k_st,
-                                   const void* v, long v_sb, long v_sh, long v_st,
-                                   void* o, long o_sb, long o_sh, long o_st,
-                                   int B, int H, int Nq, int Nk, int d, float scale,
-                                   int causal, int q_pos0,
-                                   const float* relh, const float* relw, int S, void* stream) {
+static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
+                               const void* k, long k_sb, long k_sh, long k_st,
+                               const void* v, long v_sb, long v_sh, long v_st,
+                               void* o, long o_sb, long o_sh, long o_st,
+                               int B, int H, int Nq, int Nk, int d, float scale,
+                               int causal, int q_pos0,
+                               const float* relh, const float* relw, int S, const int* nk_rows, void* stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d > 128 || (d & 7)) return HAFF_ERR_BAD_ARG;
   if ((q_st & 7) || (k_st & 7) || (v_st & 7) || (o_st & 3) || (q_sh & 7) || (k_sh & 7) || (v_sh & 7) || (o_sh & 3) ||
       (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (o_sb & 3))
@@ -598,7 +601,7 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   if (rel && (causal || S <= 0 || (Nk % S) != 0)) return HAFF_ERR_BAD_ARG;
   AttnArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
              reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
-             B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S};
+             B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S, nk_rows};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
@@ -628,6 +631,30 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
   if (dp == 64) return launch_attn<64, 0, false>(p, s);
   if (dp == 96) return launch_attn<96, 0, false>(p, s);
   return launch_attn<128, 0, false>(p, s);
+}
+
+extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_st,
+                                   const void* k, long k_sb, long k_sh, long k_st,
+                                   const void* v, long v_sb, long v_sh, long v_st,
+                                   void* o, long o_sb, long o_sh, long o_st,
+                                   int B, int H, int Nq, int Nk, int d, float scale,
+                                   int causal, int q_pos0,
+                                   const float* relh, const float* relw, int S, void* stream) {
+  return attention_bf16_impl(q, q_sb, q_sh, q_st, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, o_st, B, H, Nq, Nk, d,
+                             scale, causal, q_pos0, relh, relw, S, nullptr, stream);
+}
+
+// KV-cached decode over RAGGED caches (batched prompts of different lengths): one query per (batch, head), batch b
+// attends its first nk_rows[b] cached keys (device int32 [B], each in 1..Nk; Nk = the cache view's extent). No mask, no
+// bias: the query is the newest position, every cached key is visible (transformers LlamaAttention with a KV cache).
+extern "C" int haff_attention_decode_rows_bf16(const void* q, long q_sb, long q_sh,
+                                               const void* k, long k_sb, long k_sh, long k_st,
+                                               const void* v, long v_sb, long v_sh, long v_st,
+                                               void* o, long o_sb, long o_sh,
+                                               int B, int H, int Nk, int d, float scale, const int* nk_rows, void* stream) {
+  if (!nk_rows) return HAFF_ERR_BAD_ARG;
+  return attention_bf16_impl(q, q_sb, q_sh, (long)H * d, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, (long)H * d, B, H, 1,
+                             Nk, d, scale, 0, 0, nullptr, nullptr, 0, nk_rows, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

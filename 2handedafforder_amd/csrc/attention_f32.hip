@@ -18,6 +18,7 @@ struct AttnF32Args {
   int causal, q_pos0;
   const float *relh, *relw;
   int S;
+  const int* nk_rows;   // optional device int32 [B]: batch b sees only its first nk_rows[b] keys
 };
 
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
   float* sRed = sQ + QPB * p.d;                              // [256][4] reduction scratch (reused)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QPB;
+  const int Nk = p.nk_rows ? min(p.nk_rows[b], p.Nk) : p.Nk;
   const float* qb = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
   const float* kb = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
   const float* vb = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
   __syncthreads();
 
   // pass 1: scores
-  for (int j = tid; j < p.Nk; j += 256) {
+  for (int j = tid; j < Nk; j += 256) {
     float acc[QPB] = {0.f, 0.f, 0.f, 0.f};
     const float* kr = kb + (long)j * p.k_st;
     for (int c = 0; c < p.d; c += 4) {
@@ -62,26 +64,26 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
         s += p.relh[(bh * p.Nq + qrow) * p.S + kh] + p.relw[(bh * p.Nq + qrow) * p.S + kw];
       }
       if (p.causal && j > qrow + p.q_pos0) s = -INFINITY;
-      sS[(long)qi * p.Nk + j] = s;
+      sS[(long)qi * Nk + j] = s;
     }
   }
   __syncthreads();
 
   // softmax: wave w owns query w
   {
-    float* row = sS + (long)wave * p.Nk;
+    float* row = sS + (long)wave * Nk;
     float m = -INFINITY;
-    for (int j = lane; j < p.Nk; j += 64) m = fmaxf(m, row[j]);
+    for (int j = lane; j < Nk; j += 64) m = fmaxf(m, row[j]);
     m = wave_max(m);
     float sum = 0.f;
-    for (int j = lane; j < p.Nk; j += 64) {
+    for (int j = lane; j < Nk; j += 64) {
       const float e = expf(row[j] - m);
       row[j] = e;
       sum += e;
     }
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
-    for (int j = lane; j < p.Nk; j += 64) row[j] *= inv;
+    for (int j = lane; j < Nk; j += 64) row[j] *= inv;
   }
   __syncthreads();
 
@@ -93,11 +95,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
 #pragma unroll
   for (int qi = 0; qi < QPB; ++qi) acc[qi] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g < G) {
-    for (int j = g; j < p.Nk; j += G) {
+    for (int j = g; j < Nk; j += G) {
       const float4 vv = *reinterpret_cast<const float4*>(vb + (long)j * p.v_st + c4 * 4);
 #pragma unroll
       for (int qi = 0; qi < QPB; ++qi) {
-        const float pj = sS[(long)qi * p.Nk + j];
+        const float pj = sS[(long)qi * Nk + j];
         acc[qi].x = fmaf(pj, vv.x, acc[qi].x);
         acc[qi].y = fmaf(pj, vv.y, acc[qi].y);
         acc[qi].z = fmaf(pj, vv.z, acc[qi].z);
@@ -124,12 +126,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
 
 }  // namespace
 
-extern "C" int haff_attention_f32(const float* q, long q_sb, long q_sh, long q_st,
-                                  const float* k, long k_sb, long k_sh, long k_st,
-                                  const float* v, long v_sb, long v_sh, long v_st,
-                                  float* o, long o_sb, long o_sh, long o_st,
-                                  int B, int H, int Nq, int Nk, int d, float scale, int causal, int q_pos0,
-                                  const float* relh, const float* relw, int S, void* stream) {
+static int attention_f32_impl(const float* q, long q_sb, long q_sh, long q_st,
+                              const float* k, long k_sb, long k_sh, long k_st,
+                              const float* v, long v_sb, long v_sh, long v_st,
+                              float* o, long o_sb, long o_sh, long o_st,
+                              int B, int H, int Nq, int Nk, int d, float scale, int causal, int q_pos0,
+                              const float* relh, const float* relw, int S, const int* nk_rows, void* stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d > 256 || (d & 3)) return HAFF_ERR_BAD_ARG;
   if ((q_st & 3) || (k_st & 3) || (v_st & 3) || (o_st & 3) || (q_sh & 3) || (k_sh & 3) || (v_sh & 3) || (o_sh & 3) ||
       (q_sb & 3) || (k_sb & 3) || (v_sb & 3) || (o_sb & 3))
@@ -139,11 +141,32 @@ extern "C" int haff_attention_f32(const float* q, long q_sb, long q_sh, long q_s
   size_t lds = ((size_t)QPB * Nk + (size_t)QPB * d + 256 * 4) * sizeof(float);
   if (lds > 150 * 1024) return HAFF_ERR_UNSUPPORTED;
   AttnF32Args p{q, k, v, o, q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
-                B, H, Nq, Nk, d, scale, causal, q_pos0, rel ? relh : nullptr, rel ? relw : nullptr, S};
+                B, H, Nq, Nk, d, scale, causal, q_pos0, rel ? relh : nullptr, rel ? relw : nullptr, S, nk_rows};
   dim3 grid((Nq + QPB - 1) / QPB, H, B), block(256);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)e;
   hipLaunchKernelGGL(attn_f32_kernel, grid, block, lds, reinterpret_cast<hipStream_t>(stream), p);
   return haff_check_launch();
+}
+
+extern "C" int haff_attention_f32(const float* q, long q_sb, long q_sh, long q_st,
+                                  const float* k, long k_sb, long k_sh, long k_st,
+                                  const float* v, long v_sb, long v_sh, long v_st,
+                                  float* o, long o_sb, long o_sh, long o_st,
+                                  int B, int H, int Nq, int Nk, int d, float scale, int causal, int q_pos0,
+                                  const float* relh, const float* relw, int S, void* stream) {
+  return attention_f32_impl(q, q_sb, q_sh, q_st, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, o_st, B, H, Nq, Nk, d,
+                            scale, causal, q_pos0, relh, relw, S, nullptr, stream);
+}
+
+// fp32 twin of haff_attention_decode_rows_bf16
+extern "C" int haff_attention_decode_rows_f32(const float* q, long q_sb, long q_sh,
+                                              const float* k, long k_sb, long k_sh, long k_st,
+                                              const float* v, long v_sb, long v_sh, long v_st,
+                                              float* o, long o_sb, long o_sh,
+                                              int B, int H, int Nk, int d, float scale, const int* nk_rows, void* stream) {
+  if (!nk_rows) return HAFF_ERR_BAD_ARG;
+  return attention_f32_impl(q, q_sb, q_sh, (long)H * d, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, (long)H * d, B, H, 1, Nk,
+                            d, scale, 0, 0, nullptr, nullptr, 0, nk_rows, stream);
 }

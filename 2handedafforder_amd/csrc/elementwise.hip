@@ -97,7 +97,7 @@ __global__ void embed_splice_kernel(const long* ids, const int* img_pos, const T
 // the caches [B][Tmax][Hkv*d] at positions pos0+t. cs: fp32 [Tmax][d] = cos(0..d/2) | sin(0..d/2).
 template <typename T>
 __global__ void rope_cache_kernel(T* qkv, long ld, T* kcache, T* vcache, const float* cs, int B, int Tq, int Hq,
-                                  int Hkv, int d, int pos0, int Tmax) {
+                                  int Hkv, int d, int pos0, int Tmax, const int* pos0_rows) {
   const int half = d / 2, hc = half / 8;
   const int per_row = (Hq + 2 * Hkv) * hc;
   const long total = (long)B * Tq * per_row;
@@ -106,7 +106,7 @@ __global__ void rope_cache_kernel(T* qkv, long ld, T* kcache, T* vcache, const f
     const long row = i / per_row;
     const int t = (int)(row % Tq), b = (int)(row / Tq);
     const int head = w / hc, ch = w % hc;
-    const int pos = pos0 + t;
+    const int pos = (pos0_rows ? pos0_rows[b] : pos0) + t;
     T* base = qkv + row * ld + (long)head * d + ch * 8;
     float x1[8], x2[8];
     load8(base, x1);
@@ -253,8 +253,20 @@ extern "C" int haff_rope_cache(void* qkv, long ld, void* kcache, void* vcache, c
   if (B <= 0 || Tq <= 0 || (d & 15) || (ld & 7) || pos0 < 0 || pos0 + Tq > Tmax) return HAFF_ERR_BAD_ARG;
   const long total = (long)B * Tq * (Hq + 2 * Hkv) * (d / 16);
   dim3 g(grid_for(total, 256)), b(256);
-  if (dtype == 0) hipLaunchKernelGGL((rope_cache_kernel<bf16_t>), g, b, 0, HAFF_STREAM(stream), (bf16_t*)qkv, ld, (bf16_t*)kcache, (bf16_t*)vcache, cos_sin, B, Tq, Hq, Hkv, d, pos0, Tmax);
-  else hipLaunchKernelGGL((rope_cache_kernel<float>), g, b, 0, HAFF_STREAM(stream), (float*)qkv, ld, (float*)kcache, (float*)vcache, cos_sin, B, Tq, Hq, Hkv, d, pos0, Tmax);
+  if (dtype == 0) hipLaunchKernelGGL((rope_cache_kernel<bf16_t>), g, b, 0, HAFF_STREAM(stream), (bf16_t*)qkv, ld, (bf16_t*)kcache, (bf16_t*)vcache, cos_sin, B, Tq, Hq, Hkv, d, pos0, Tmax, nullptr);
+  else hipLaunchKernelGGL((rope_cache_kernel<float>), g, b, 0, HAFF_STREAM(stream), (float*)qkv, ld, (float*)kcache, (float*)vcache, cos_sin, B, Tq, Hq, Hkv, d, pos0, Tmax, nullptr);
+  return haff_check_launch();
+}
+
+// Ragged batches: row b's Tq new positions start at pos0_rows[b] (device int32 [B], each with pos0_rows[b] + Tq <= Tmax —
+// the caller's contract: the kernel cannot report a device-side violation) instead of one shared pos0.
+extern "C" int haff_rope_cache_rows(void* qkv, long ld, void* kcache, void* vcache, const float* cos_sin, int B, int Tq,
+                                    int Hq, int Hkv, int d, const int* pos0_rows, int Tmax, int dtype, void* stream) {
+  if (B <= 0 || Tq <= 0 || (d & 15) || (ld & 7) || !pos0_rows || Tq > Tmax) return HAFF_ERR_BAD_ARG;
+  const long total = (long)B * Tq * (Hq + 2 * Hkv) * (d / 16);
+  dim3 g(grid_for(total, 256)), b(256);
+  if (dtype == 0) hipLaunchKernelGGL((rope_cache_kernel<bf16_t>), g, b, 0, HAFF_STREAM(stream), (bf16_t*)qkv, ld, (bf16_t*)kcache, (bf16_t*)vcache, cos_sin, B, Tq, Hq, Hkv, d, 0, Tmax, pos0_rows);
+  else hipLaunchKernelGGL((rope_cache_kernel<float>), g, b, 0, HAFF_STREAM(stream), (float*)qkv, ld, (float*)kcache, (float*)vcache, cos_sin, B, Tq, Hq, Hkv, d, 0, Tmax, pos0_rows);
   return haff_check_launch();
 }
 

@@ -59,6 +59,7 @@ struct GemmArgs {
   // batched launches (blockIdx.y = z): operand z lives at base + (z / nb_inner) * s?o + (z % nb_inner) * s?i elements
   int nb_inner;
   long sAo, sAi, sWo, sWi, sCo, sCi;
+  int nt_out;         // non-temporal output stores (large outputs; chosen by the launcher)
 };
 
 // Epilogue activations of the throughput (bf16) path. GELU matters for the K=1280 SAM MLP GEMM, whose epilogue touches
@@ -100,6 +101,30 @@ __device__ unsigned long long haff_gemm_trace_buf[8192 * 8];
 #else
 #define HAFF_TRACE(i) do {} while (0)
 #endif
+
+// Output stores of the tile kernel. nt: non-temporal — a C tile of a LARGE output is written once and next read by
+// another kernel after hundreds of MB of other traffic; keeping it out of the XCD's L2 leaves the A/W panels resident
+// (+3 % on 131072x5120x1280, +6 % with a residual epilogue; neutral on the K >= 4096 shapes; tools/gemm_variant.py).
+// The launcher sets it for outputs of 64 MB and more (decode-sized outputs are re-read from L2 by the next kernel).
+typedef unsigned int haff_u32x4 __attribute__((ext_vector_type(4)));
+typedef float haff_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store8_c(bf16_t* p, const float (&v)[8], bool nt) {
+  if (nt) {
+    haff_u32x4 r = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    __builtin_nontemporal_store(r, reinterpret_cast<haff_u32x4*>(p));
+  } else {
+    store8(p, v);
+  }
+}
+__device__ __forceinline__ void store8_c(float* p, const float (&v)[8], bool nt) {
+  if (nt) {
+    haff_f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    __builtin_nontemporal_store(a, reinterpret_cast<haff_f32x4*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<haff_f32x4*>(p + 4));
+  } else {
+    store8(p, v);
+  }
+}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -398,6 +423,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const bool c_vec = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((p.ldc & 7) == 0);
   const bool r_vec = p.resid && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) && ((p.ldr & 7) == 0);
   const bool fast = c_vec && (!p.resid || r_vec) && (n_wave_out + WCOLS <= n_total_out);
+  const bool nt_out = p.nt_out != 0;
 
   float bias_r[TN][4];
   if (p.bias && n_wave_in + WNC <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
@@ -452,7 +478,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       const int wr = mi * 16 + st * RPS + rb_r;
       const int orow = __shfl(orow_l[(mi * 16) >> 6], wr & 63);
       rres[st] = uint4{0u, 0u, 0u, 0u};
-      if (orow >= 0)
+      if (orow >= 0)   // (non-temporal residual loads measured neutral)
         rres[st] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)orow * p.ldr + n_out);
     }
   };
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] += rr[j];
             }
-            store8(reinterpret_cast<float*>(p.C) + (long)orow * p.ldc + n_out, v);
+            store8_c(reinterpret_cast<float*>(p.C) + (long)orow * p.ldc + n_out, v, nt_out);
           } else {
             if (p.resid) {
               const unsigned int w[4] = {rcur[st].x, rcur[st].y, rcur[st].z, rcur[st].w};
@@ -535,7 +561,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
                 v[2 * j + 1] += __builtin_bit_cast(float, w[j] & 0xffff0000u);
               }
             }
-            store8(reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n_out, v);
+            store8_c(reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n_out, v, nt_out);
           }
         }
       }
@@ -820,6 +846,9 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   // the concurrently running tiles drift apart and a 2-deep group keeps more of the sweep in the 4 MiB L2
   // (measured +5 % on 131072x1280x5120 and 18624x4096x11008, tools/gemm_variant.py).
   if (big && K >= 5120 && (N + 255) / 256 <= 32) p.group_m = 2;
+#ifndef HAFF_GEMM_NO_NT
+  p.nt_out = (long)M * (swiglu ? N / 2 : N) * (out_f32 ? 4 : 2) >= (64L << 20);
+#endif
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
 

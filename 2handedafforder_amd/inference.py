@@ -44,6 +44,8 @@ def parse_args(args):
     parser.add_argument("--synthetic", default=None, choices=["tiny", "mid", "7b", "13b"], help="random-init model of this geometry")
     parser.add_argument("--sam-checkpoint", default=None, type=str)
     parser.add_argument("--max-new-tokens", default=512, type=int)
+    parser.add_argument("--batch-size", default=1, type=int,
+                        help="frames per evaluate() call (the reference runs 1; prompts of different lengths are right-padded)")
     return parser.parse_args(args)
 
 
@@ -121,12 +123,21 @@ def output_planes(masks_left, masks_right, taxonomies, thresholds=postprocess.TH
     return out
 
 
-def main(argv):
-    args = parse_args(argv)
-    model, tokenizer, cfg, dtype = build_model_and_tokenizer(args)
-    device = model.device
-    for dir_name in sorted(os.listdir(args.benchmark_dir)):
-        dir_path = os.path.join(args.benchmark_dir, dir_name)
+def pad_prompts(id_rows, pad_token_id):
+    """collate_fn's rule (utils/dataset.py:90-93,144-150): right-pad with pad_token_id, mask = real positions."""
+    L = max(r.numel() for r in id_rows)
+    ids = torch.full((len(id_rows), L), pad_token_id, dtype=torch.long)
+    mask = torch.zeros((len(id_rows), L), dtype=torch.bool)
+    for b, r in enumerate(id_rows):
+        ids[b, :r.numel()] = r
+        mask[b, :r.numel()] = True
+    return ids, mask
+
+
+def iter_examples(benchmark_dir):
+    """The directory walk of inference.py:199-219: <dir>/<folder>/{inpainting.png, annotation.json}, sorted."""
+    for dir_name in sorted(os.listdir(benchmark_dir)):
+        dir_path = os.path.join(benchmark_dir, dir_name)
         if not os.path.isdir(dir_path):
             continue
         for folder_name in sorted(os.listdir(dir_path)):
@@ -140,14 +151,30 @@ def main(argv):
                 continue
             with open(annotation_path) as f:
                 narration = json.load(f).get("narration", "")
+            yield dir_name, folder_name, image_path, narration
+
+
+def main(argv):
+    args = parse_args(argv)
+    model, tokenizer, cfg, dtype = build_model_and_tokenizer(args)
+    device = model.device
+    examples = list(iter_examples(args.benchmark_dir))
+    for i in range(0, len(examples), max(args.batch_size, 1)):
+        chunk = examples[i:i + max(args.batch_size, 1)]
+        frames, resize_list, original_size_list, id_rows = [], [], [], []
+        for _, _, image_path, narration in chunk:
+            fr, rs, osz = prepare_frame(load_rgb(image_path), cfg, dtype, device)
+            frames.append(fr[0])
+            resize_list += rs
+            original_size_list += osz
             prompt = hprompt.build_inference_prompt(narration, args.use_mm_start_end)
-            image_np = load_rgb(image_path)
-            frames, resize_list, original_size_list = prepare_frame(image_np, cfg, dtype, device)
-            input_ids = hprompt.tokenizer_image_token(prompt, tokenizer, return_tensors="pt").unsqueeze(0).to(device)
-            output_ids, masks_left, masks_right, taxonomies = model.evaluate(
-                None, None, input_ids, resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
-                tokenizer=tokenizer, frames_u8=frames)
-            for (side, th), plane in output_planes(masks_left, masks_right, taxonomies).items():
+            id_rows.append(hprompt.tokenizer_image_token(prompt, tokenizer, return_tensors="pt"))
+        input_ids, mask = pad_prompts(id_rows, cfg.pad_token_id)
+        output_ids, masks_left, masks_right, taxonomies = model.evaluate(
+            None, None, input_ids.to(device), resize_list, original_size_list, max_new_tokens=args.max_new_tokens,
+            tokenizer=tokenizer, frames_u8=frames, attention_mask=mask)
+        for b, (dir_name, folder_name, _, _) in enumerate(chunk):   # per frame, exactly the reference's B = 1 rule
+            for (side, th), plane in output_planes(masks_left[b:b + 1], masks_right[b:b + 1], taxonomies[b:b + 1]).items():
                 save_mask(os.path.join(args.vis_save_path + str(th), dir_name, folder_name, f"aff_{side}.png"), plane)
 
 

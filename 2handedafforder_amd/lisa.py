@@ -71,37 +71,61 @@ class LisaMI355:
 
     # ---- a6-a8: splice + greedy generate -----------------------------------------------------------------
     @torch.no_grad()
-    def generate(self, images_clip, input_ids, max_new_tokens=32, forced_answer=None):
+    def generate(self, images_clip, input_ids, max_new_tokens=32, forced_answer=None, attention_mask=None):
+        """Greedy KV-cached decode (LISA.py:443-450). Rows may have different prompt lengths: input_ids is right-padded
+        (utils/dataset.py:90-93) and attention_mask [B, L] (bool, True on real tokens; None = every row is full length)
+        marks the real prefix of each row, as collate_fn builds it (:144-150). Row b's generated tokens are appended right
+        after ITS last real token, so output_ids [B, L + N] is left-aligned per row (pad_token_id behind the end) and the
+        hidden states [B, T + N - 1, H] line up with it position by position — the [SEG] rule of LISA.py:457-465 then
+        applies per row unchanged. Equal to B independent batch-1 runs."""
         cfg = self.cfg
         input_ids = input_ids.to(self.device)
         B, L = input_ids.shape
         is_img = input_ids == IMAGE_TOKEN_INDEX
         assert bool((is_img.sum(1) == 1).all()), "exactly one <image> sentinel per row (LISA.py:458 hack)"
         img_pos = is_img.int().argmax(1).to(torch.int32)
+        if attention_mask is None:
+            lens = torch.full((B,), L, dtype=torch.int64, device=self.device)
+        else:
+            am = attention_mask.to(self.device).bool()
+            lens = am.sum(1)
+            assert bool((am == (torch.arange(L, device=self.device)[None, :] < lens[:, None])).all()), "right padding only"
+            assert bool((img_pos.long() < lens).all())
         img = self.encode_images(images_clip)
         n_img = img.shape[1]
         # the sentinel slot itself is never dereferenced by the splice kernel
-        x = ops.embed_splice(input_ids.contiguous(), img_pos, self.llm.embed, img.contiguous())
+        x = ops.embed_splice(input_ids.clamp_min(IMAGE_TOKEN_INDEX).contiguous(), img_pos, self.llm.embed, img.contiguous())
         T = L + n_img - 1
+        t_rows = lens + (n_img - 1)                      # real positions per row after the splice
         cache = self._persistent_cache(B, T + max_new_tokens)
-        hidden = [self.llm.forward(x, cache)]
-        out_ids = input_ids
+        prefill = self.llm.forward(x, cache)             # causal: a row's real positions never see its padding
+        H = prefill.shape[2]
+        hidden = torch.zeros((B, T + max(max_new_tokens - 1, 0), H), dtype=prefill.dtype, device=self.device)
+        hidden[:, :T] = prefill
+        rows = torch.arange(B, device=self.device)
+        cache["pos"].copy_(t_rows.to(torch.int32))
+        cache["nk"].copy_((t_rows + 1).to(torch.int32))
+        out_ids = torch.full((B, L + max_new_tokens), cfg.pad_token_id, dtype=input_ids.dtype, device=self.device)
+        out_ids[:, :L] = torch.where(torch.arange(L, device=self.device)[None, :] < lens[:, None], input_ids,
+                                     torch.full_like(input_ids, cfg.pad_token_id))
         finished = torch.zeros(B, dtype=torch.bool, device=self.device)
         if forced_answer is not None:
             forced_answer = forced_answer.to(self.device)
-        logits = self.llm.next_token_logits(hidden[-1][:, -1])
+        logits = self.llm.next_token_logits(prefill[rows, t_rows - 1].contiguous())
         nxt = ops.argmax_rows(logits)
+        n_done = 0
         for step in range(max_new_tokens):
             if forced_answer is not None:
                 nxt = forced_answer[:, step].clone()
             nxt = torch.where(finished, torch.full_like(nxt, cfg.pad_token_id), nxt)
-            out_ids = torch.cat([out_ids, nxt[:, None]], dim=1)
+            out_ids[rows, lens + step] = nxt
+            n_done = step + 1
             finished = finished | (nxt == cfg.eos_token_id)
             if step == max_new_tokens - 1 or bool(finished.all()):
                 break
             h1, nxt = self._decode_step(nxt, cache)
-            hidden.append(h1)
-        return out_ids, torch.cat(hidden, dim=1) if len(hidden) > 1 else hidden[0]
+            hidden[rows, t_rows + step] = h1[:, 0]
+        return out_ids[:, :L + n_done], hidden[:, :T + n_done - 1]
 
     def _persistent_cache(self, B, tmax):
         key = (B, tmax)
@@ -118,39 +142,41 @@ class LisaMI355:
     def _decode_step_eager(self, nxt, cache):
         B = nxt.shape[0]
         x1 = self.llm.embed.index_select(0, nxt).view(B, 1, -1)
-        h1 = self.llm.forward(x1, cache)
+        h1 = self.llm.decode_rows(x1, cache)
         logits = self.llm.next_token_logits(h1[:, -1])
         return h1, ops.argmax_rows(logits)
 
     def _decode_step(self, nxt, cache):
-        """One greedy step: embed(nxt) -> 32 layers against the KV cache -> logits -> argmax. Returns (hidden [B,1,H],
-        next ids [B]). Replays a hipGraph captured for this (batch, cache capacity, position) when enabled."""
+        """One greedy step: embed(nxt) -> the layers against the KV cache at each row's own position -> logits -> argmax,
+        then every row's position advances by one. Returns (hidden [B,1,H], next ids [B]). The per-row positions live in
+        device memory (cache["pos"], cache["nk"]), so ONE hipGraph per (batch, cache capacity) serves every step."""
         if not self.decode_graphs:
-            return self._decode_step_eager(nxt, cache)
-        B, pos = nxt.shape[0], cache["len"]
-        key = (B, cache["tmax"], pos)
-        ent = self._graphs.get(key)
-        if ent is None:
-            if len(self._graphs) >= 256:
-                self._graphs.clear()
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
-            static_in = nxt.clone()
-            # warm-up outside the capture (lazy one-time work inside the ops), then rewind the cache length
-            self._decode_step_eager(static_in, cache)
-            cache["len"] = pos
-            torch.cuda.current_stream(self.device).synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
-                h1, out = self._decode_step_eager(static_in, cache)
-            ent = self._graphs[key] = (g, static_in, h1, out)
-            cache["len"] = pos
-        g, static_in, h1, out = ent
-        static_in.copy_(nxt)
-        g.replay()
-        cache["len"] = pos + 1
-        # outputs are the graph's static tensors: hand out copies so the next replay cannot overwrite them
-        return h1.clone(), out.clone()
+            out = self._decode_step_eager(nxt, cache)
+        else:
+            B = nxt.shape[0]
+            key = (B, cache["tmax"])
+            ent = self._graphs.get(key)
+            if ent is None:
+                if len(self._graphs) >= 16:
+                    self._graphs.clear()
+                if self._graph_pool is None:
+                    self._graph_pool = torch.cuda.graph_pool_handle()
+                static_in = nxt.clone()
+                # warm-up outside the capture (lazy one-time work inside the ops); it rewrites this step's K/V slots only
+                self._decode_step_eager(static_in, cache)
+                torch.cuda.current_stream(self.device).synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+                    h1, out = self._decode_step_eager(static_in, cache)
+                ent = self._graphs[key] = (g, static_in, h1, out)
+            g, static_in, h1, out = ent
+            static_in.copy_(nxt)
+            g.replay()
+            # outputs are the graph's static tensors: hand out copies so the next replay cannot overwrite them
+            out = (h1.clone(), out.clone())
+        cache["pos"].add_(1)
+        cache["nk"].add_(1)
+        return out
 
     # ---- a10: SAM image encoder --------------------------------------------------------------------------
     @torch.no_grad()
@@ -167,6 +193,20 @@ class LisaMI355:
         for i in range(0, frames.shape[0], self.sam_chunk):
             fr = frames[i:i + self.sam_chunk]
             outs.append(self.sam_encoder.forward_rows(self.sam_encoder.patch_rows_from_u8(fr, mean, std), fr.shape[0]))
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+    @torch.no_grad()
+    def get_visual_embs_frames(self, frames, mean, std):
+        """A list of uint8 HWC frames of DIFFERENT sizes (a directory of images): each goes through its own Pillow-exact
+        resize + fused normalise/pad/patchify (cheap, HBM-bound), the patch rows are concatenated and the ViT runs batched."""
+        ing, enc = self.frame_ingest(), self.sam_encoder
+        outs = []
+        for i in range(0, len(frames), self.sam_chunk):
+            rows = []
+            for fr in frames[i:i + self.sam_chunk]:
+                u8, _ = ing.sam_frames(fr.to(self.device)[None], self.cfg.sam.img_size)
+                rows.append(enc.patch_rows_from_u8(u8, mean, std))
+            outs.append(enc.forward_rows(torch.cat(rows, 0) if len(rows) > 1 else rows[0], len(rows)))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
     # ---- a9: [SEG] gather + text_hidden_fcs ---------------------------------------------------------------
@@ -192,27 +232,37 @@ class LisaMI355:
     # ---- the boundary --------------------------------------------------------------------------------------
     @torch.no_grad()
     def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, max_new_tokens=32,
-                 tokenizer=None, forced_answer=None, frames_u8=None):
+                 tokenizer=None, forced_answer=None, frames_u8=None, attention_mask=None):
         # The SAM encoder (MFMA-bound, ~60 % of the FLOPs) does not depend on the language model: it runs on its own
         # HIP stream so its big GEMMs fill the CUs while the HBM/latency-bound greedy decode steps of the LLM trickle
         # through on the caller's stream. Joined before the mask decoders.
         cur = torch.cuda.current_stream(self.device)
         side = self._sam_stream if self.overlap_streams else cur
+        frame_list = isinstance(frames_u8, (list, tuple))   # frames of different sizes: one [H,W,3] uint8 tensor each
         if frames_u8 is not None:
-            frames_u8 = frames_u8.to(self.device)
+            if not frame_list:
+                frames_u8 = frames_u8.to(self.device)
             if images_clip is None:   # a2 on the device: CLIPImageProcessor.preprocess of the same uint8 frames
-                images_clip = self.frame_ingest().clip_pixels(frames_u8, self.cfg.clip.image, self.dtype)
+                ing = self.frame_ingest()
+                if frame_list:
+                    images_clip = torch.cat([ing.clip_pixels(f.to(self.device)[None], self.cfg.clip.image, self.dtype)
+                                             for f in frames_u8], 0)
+                else:
+                    images_clip = ing.clip_pixels(frames_u8, self.cfg.clip.image, self.dtype)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             if frames_u8 is not None:
                 from .preprocess import SAM_MEAN, SAM_STD
                 # a1 on the device: ResizeLongestSide (identity when the long side is img_size), then the fused
                 # normalise + pad + patchify of haff_patchify_u8
-                sam_u8, _ = self.frame_ingest().sam_frames(frames_u8, self.cfg.sam.img_size)
-                emb = self.get_visual_embs_u8(sam_u8, SAM_MEAN, SAM_STD)
+                if frame_list:
+                    emb = self.get_visual_embs_frames(frames_u8, SAM_MEAN, SAM_STD)
+                else:
+                    sam_u8, _ = self.frame_ingest().sam_frames(frames_u8, self.cfg.sam.img_size)
+                    emb = self.get_visual_embs_u8(sam_u8, SAM_MEAN, SAM_STD)
             else:
                 emb = self.get_visual_embs(images)
-        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer)
+        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask)
         pred, frame_idx, counts = self.seg_embeddings(output_ids, hidden)
         cur.wait_stream(side)
         emb.record_stream(cur)

@@ -136,7 +136,10 @@ class LlamaHip:
         H = self.cfg.hidden
         return {"k": [torch.empty((B, tmax, H), dtype=self.dtype, device=self.device) for _ in self.layers],
                 "v": [torch.empty((B, tmax, H), dtype=self.dtype, device=self.device) for _ in self.layers],
-                "len": 0, "tmax": tmax}
+                "len": 0, "tmax": tmax,
+                # per-row decode state (ragged batches): next position and visible key count of every row
+                "pos": torch.zeros((B,), dtype=torch.int32, device=self.device),
+                "nk": torch.ones((B,), dtype=torch.int32, device=self.device)}
 
     def forward(self, x, cache):
         """x [B,T,H] embeddings of the next T positions; appends to the cache; returns post-norm hidden [B,T,H]."""
@@ -163,6 +166,33 @@ class LlamaHip:
             x = ops.linear(g, L["wd"], resid=x, out=x)
         cache["len"] = pos0 + T
         return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, T, H)
+
+    def decode_rows(self, x1, cache):
+        """One KV-cached position per row at PER-ROW positions: x1 [B,1,H] is the embedding of row b's next token, which
+        sits at position cache["pos"][b] (device int32 [B]) and attends that row's first pos+1 cached keys — greedy decode
+        of right-padded prompts of different lengths (padding rule of utils/dataset.py:90-93). The caller advances
+        cache["pos"] / cache["nk"] (nk = pos + 1). Returns post-norm hidden [B,1,H]."""
+        l = self.cfg
+        B, T, H = x1.shape
+        assert T == 1
+        nh, hd = l.heads, self.hd
+        cs = self._cos_sin(cache["tmax"])
+        pos, nk = cache["pos"], cache["nk"]
+        x = x1.reshape(B, H).clone() if not x1.is_contiguous() else x1.reshape(B, H)
+        for li, L in enumerate(self.layers):
+            h = ops.rmsnorm(x, L["n1"], l.rms_eps)
+            qkv = ops.linear(h, L["wqkv"])
+            kc, vc = cache["k"][li], cache["v"][li]
+            ops.rope_cache_rows(qkv, kc, vc, cs, B, 1, nh, nh, hd, pos)
+            q = qkv.view(B, 1, 3, nh, hd)[:, :, 0].permute(0, 2, 1, 3)
+            k = kc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)
+            v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)
+            a = ops.attention_decode_rows(q, k, v, hd ** -0.5, nk)
+            x = ops.linear(a.view(B, H), L["wo"], resid=x, out=x)
+            h = ops.rmsnorm(x, L["n2"], l.rms_eps)
+            g = ops.linear(h, L["wgu"], swiglu=True)
+            x = ops.linear(g, L["wd"], resid=x, out=x)
+        return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, 1, H)
 
     def next_token_logits(self, hidden_last):
         """hidden_last [B,H] -> fp32 logits [B,V] (lm_head, no bias; llava_llama.py:105)."""

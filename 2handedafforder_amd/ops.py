@@ -296,6 +296,36 @@ def rope_cache(qkv, kcache, vcache, cos_sin, B, Tq, Hq, Hkv, d, pos0):
     check(rc, "haff_rope_cache")
 
 
+def rope_cache_rows(qkv, kcache, vcache, cos_sin, B, Tq, Hq, Hkv, d, pos0_rows):
+    """rope_cache with a per-row start position (int32 [B] on the device): ragged right-padded batches."""
+    lib = load_library()
+    _req(qkv, "qkv")
+    Tmax = kcache.shape[1]
+    assert kcache.is_contiguous() and vcache.is_contiguous() and cos_sin.dtype == torch.float32
+    assert pos0_rows.dtype == torch.int32 and pos0_rows.is_cuda and pos0_rows.numel() == B
+    rc = lib.haff_rope_cache_rows(qkv.data_ptr(), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(), cos_sin.data_ptr(),
+                                  B, Tq, Hq, Hkv, d, pos0_rows.data_ptr(), Tmax, _dt(qkv), _stream())
+    check(rc, "haff_rope_cache_rows")
+
+
+def attention_decode_rows(q, k, v, scale, nk_rows, out=None):
+    """One query per (batch, head) against ragged KV caches: q [B,H,1,d] view, k/v [B,H,Nk,d] views of the whole cache,
+    nk_rows int32 [B] on the device (keys visible per batch entry). Returns [B,1,H*d]."""
+    lib = load_library()
+    _req(q, "q")
+    B, H, Nq, d = q.shape
+    assert Nq == 1 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    assert nk_rows.dtype == torch.int32 and nk_rows.is_cuda and nk_rows.numel() == B
+    if out is None:
+        out = torch.empty((B, 1, H * d), dtype=q.dtype, device=q.device)
+    fn = lib.haff_attention_decode_rows_bf16 if q.dtype == torch.bfloat16 else lib.haff_attention_decode_rows_f32
+    rc = fn(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+            v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), out.data_ptr(), H * d, d, B, H, k.shape[2], d, float(scale),
+            nk_rows.data_ptr(), _stream())
+    check(rc, "haff_attention_decode_rows")
+    return out
+
+
 def argmax_rows(logits):
     lib = load_library()
     _req(logits, "logits")

@@ -330,7 +330,7 @@ def main():
             tok = torch.zeros((1,), dtype=torch.long, device=device)
 
             def one_step():
-                cache["len"] = T0
+                cache["pos"].fill_(T0); cache["nk"].fill_(T0 + 1)
                 return model._decode_step(tok, cache)
             for _ in range(3):
                 one_step()

@@ -73,6 +73,15 @@ int haff_attention_f32(const float* q, long q_sb, long q_sh, long q_st, const fl
                        int B, int H, int Nq, int Nk, int d, float scale, int causal, int q_pos0,
                        const float* relh, const float* relw, int S, void* stream);
 
+/* KV-cached decode over RAGGED caches (batched prompts of different lengths; reference padding rules:
+ * 2Haff/utils/dataset.py:90-93,144-150): one query per (batch, head); batch b attends its first nk_rows[b] cached keys
+ * (DEVICE int32 [B], 1 <= nk_rows[b] <= Nk). q/o: [B][H][d] with (batch, head) strides; k/v as haff_attention_bf16. */
+int haff_attention_decode_rows_bf16(const void* q, long q_sb, long q_sh, const void* k, long k_sb, long k_sh, long k_st,
+                                    const void* v, long v_sb, long v_sh, long v_st, void* o, long o_sb, long o_sh, int B,
+                                    int H, int Nk, int d, float scale, const int* nk_rows, void* stream);
+int haff_attention_decode_rows_f32(const float* q, long q_sb, long q_sh, const float* k, long k_sb, long k_sh, long k_st,
+                                   const float* v, long v_sb, long v_sh, long v_st, float* o, long o_sb, long o_sh, int B,
+                                   int H, int Nk, int d, float scale, const int* nk_rows, void* stream);
 /* decomposed rel-pos terms (image_encoder.py:376-384, from the UNSCALED q, :244-248):
  * relh[bh][q][kh] = q . Rh[qh - kh + S - 1], relw[bh][q][kw] = q . Rw[qw - kw + S - 1]; N = S*S queries.
  * tab_*: [2S-1][d] (f32 for the generic entry, bf16 for the MFMA entry). */
@@ -126,6 +135,10 @@ int haff_embed_splice(const long* ids, const int* img_pos, const void* embed, co
  * (caches [B][Tmax][Hkv*d]); cos_sin f32 [Tmax][d] = cos(d/2) | sin(d/2). d % 16 == 0. */
 int haff_rope_cache(void* qkv, long ld, void* kcache, void* vcache, const float* cos_sin, int B, int Tq, int Hq, int Hkv,
                     int d, int pos0, int Tmax, int dtype, void* stream);
+/* same with a per-row start position: row b's Tq new positions begin at pos0_rows[b] (DEVICE int32 [B];
+ * pos0_rows[b] + Tq <= Tmax is the caller's contract) — greedy decode of right-padded prompts of different lengths */
+int haff_rope_cache_rows(void* qkv, long ld, void* kcache, void* vcache, const float* cos_sin, int B, int Tq, int Hq,
+                         int Hkv, int d, const int* pos0_rows, int Tmax, int dtype, void* stream);
 /* greedy token: first index of the row maximum (generate(num_beams=1), LISA.py:443-450) */
 int haff_argmax_rows(const float* x, long ld, long* out, int rows, int V, void* stream);
 /* out[r] = a[r] + b[r % mod]  (PE adds, transformer.py:166-178; src + dense prompt, mask_decoder.py:141) */

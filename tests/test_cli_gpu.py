@@ -120,3 +120,41 @@ def test_output_gating_is_bit_exact(dev):
         planes = P.ops.gate_threshold_masks(x, [0.0, 0.5], 255, torch.tensor(tax, device=dev), blank)
         exp = torch.stack([(x > 0), (x > 0.5)]).to(torch.uint8) * (255 if open_ else 0)
         assert torch.equal(planes, exp)
+
+
+def test_inference_cli_batches_a_directory(dev, tmp_path, monkeypatch):
+    """inference.py over a benchmark directory with frames of different sizes and narrations of different lengths:
+    --batch-size 3 (one ragged evaluate() call) writes the same PNG bytes as the reference's frame-by-frame loop
+    (--batch-size 1). fp32 mode: every output element is accumulated in a fixed k order, so batching is bit-invariant."""
+    import torch
+    import haff  # noqa: F401
+    from haff import inference, lisa
+    for i, (hw, text) in enumerate((((150, 224), "open drawer"), ((224, 224), "pour water from the kettle into the cup"),
+                                    ((200, 120), "cut"))):
+        d = tmp_path / "bench" / "kitchen" / f"clip{i}"
+        d.mkdir(parents=True)
+        _png(d / "inpainting.png", hw[0], hw[1], i)
+        (d / "annotation.json").write_text(json.dumps({"narration": text}))
+    orig = lisa.LisaMI355.evaluate
+
+    def forced(self, *a, **kw):
+        B = a[2].shape[0]
+        kw["forced_answer"] = torch.tensor([[5, self.cfg.seg_token_idx, self.cfg.eos_token_id]]).expand(B, -1)
+        kw["max_new_tokens"] = 3
+        return orig(self, *a, **kw)
+    monkeypatch.setattr(lisa.LisaMI355, "evaluate", forced)
+    outs = {}
+    for bs in (1, 3):
+        out = tmp_path / f"vis_b{bs}_"
+        inference.main(["--synthetic", "tiny", "--benchmark-dir", str(tmp_path / "bench"), "--vis_save_path", str(out),
+                        "--image_size", "224", "--precision", "fp32", "--batch-size", str(bs)])
+        files = {}
+        for th in (0.1, 0.2, 0.3, 0.5, 0.7):
+            for i in range(3):
+                for side in ("left", "right"):
+                    p = f"{out}{th}/kitchen/clip{i}/aff_{side}.png"
+                    if os.path.exists(p):
+                        files[(th, i, side)] = open(p, "rb").read()
+        outs[bs] = files
+    assert len(outs[1]) >= 15 and set(outs[1]) == set(outs[3])
+    assert all(outs[1][k] == outs[3][k] for k in outs[1])

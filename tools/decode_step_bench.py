@@ -24,7 +24,7 @@ def main():
         cache = model._persistent_cache(B, T0 + 8)
         tok = torch.zeros((B,), dtype=torch.long, device=dev)
         def one_step():
-            cache["len"] = T0
+            cache["pos"].fill_(T0); cache["nk"].fill_(T0 + 1)
             return model._decode_step(tok, cache)
         for _ in range(3):
             one_step()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time haff_gemm_bf16_cfg from an explicitly named build of gemm_bf16.hip (experiment variants compiled with -D flags
 into 2handedafforder_amd/lib/libhaff_gemm_<name>.so). usage: [ACT=1] [CFG=2] gemm_variant.py name [name ...]
-(ACT: epilogue activation code of haff_hip.h, with a bias vector; default 0 = plain product. CFG: tile_cfg, 1 = 128x128,
+(RESID=1: residual epilogue. ACT: epilogue activation code of haff_hip.h, with a bias vector; default 0 = plain product. CFG: tile_cfg, 1 = 128x128,
 2 = 256x256 8-wave (default), 3 = 256x256 4-wave)"""
 import ctypes
 import os
@@ -31,6 +31,7 @@ def main():
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         act = int(os.environ.get("ACT", "0"))
         bias = torch.randn((N,), device=dev) if act else None
+        resid = torch.randn((M, N), device=dev).to(torch.bfloat16) if os.environ.get("RESID") else None
         res = {n: [] for n in names}
         for r in range(4):
             for n in names:
@@ -38,7 +39,8 @@ def main():
                 e0.record()
                 for _ in range(3):
                     rc = libs[n].haff_gemm_bf16_cfg(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N,
-                                                    bias.data_ptr() if act else None, None, 0,
+                                                    bias.data_ptr() if act else None,
+                                                    resid.data_ptr() if resid is not None else None, N if resid is not None else 0,
                                                     None, M, N, K, act, 0, 0, int(os.environ.get("CFG", "2")), None)
                     assert rc == 0
                 e1.record()

@@ -36,12 +36,12 @@ def main():
     ms_gen, (out_ids, hidden) = t(lambda: model.generate(clip, ids, 8, forced))
     print(f"generate eager {ms_gen_eager:.1f} ms | with decode graphs {ms_gen:.1f} ms")
     cache = model._persistent_cache(1, 291 + 8)
-    cache["len"] = 291
+    cache["pos"].fill_(291); cache["nk"].fill_(291 + 1)
     nxt = torch.zeros((1,), dtype=torch.long, device=dev)
 
     def one_step(graph):
         model.decode_graphs = graph
-        cache["len"] = 291
+        cache["pos"].fill_(291); cache["nk"].fill_(291 + 1)
         return model._decode_step(nxt, cache)
     ms_e, _ = t(lambda: one_step(False), 10)
     ms_g, _ = t(lambda: one_step(True), 10)

@@ -23,7 +23,7 @@ def main():
     tok = torch.arange(B, device=dev) % 1000 + 5
     def decode_chain():
         outs = []
-        cache["len"] = T0
+        cache["pos"].fill_(T0); cache["nk"].fill_(T0 + 1)
         t = tok
         for _ in range(8):
             h, t = model._decode_step(t, cache)
