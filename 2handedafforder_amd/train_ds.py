@@ -269,6 +269,7 @@ def main(argv):
         print(f"trainable params: {n_train:,d} (LoRA {n_lora:,d}) | world_size {world} | micro-batch {args.batch_size} "
               f"x accum {args.grad_accumulation_steps}")
     states = {k: T.AdamWState(p) for k, p in model.named_parameters()}
+    reducer = T.GradBucketReducer(model.named_parameters())   # p.grad become views into flat per-dtype buckets
     ckpt_dir = os.path.join(args.log_base_dir, args.exp_name, "ckpt_model")
     global_step, best_score, start_epoch = 0, 0.0, args.start_epoch
     resume = args.resume or (ckpt_dir if args.auto_resume and os.path.exists(os.path.join(ckpt_dir, "latest.pt")) else "")
@@ -297,18 +298,23 @@ def main(argv):
         keys = [None, "loss", "ce_loss", "mask_loss", "mask_bce_loss", "mask_dice_loss", "taxonomy_ce_loss"]
         model.train()
         end = time.time()
+        loss_acc = torch.zeros((len(keys) - 1,), dtype=torch.float32, device=device)   # meters stay on the device
+        n_acc = 0
         for step in range(args.steps_per_epoch):
-            model.zero_grad()
-            for _ in range(args.grad_accumulation_steps):
+            reducer.zero()
+            for micro in range(args.grad_accumulation_steps):
                 batch = collate_fn([train_ds[sample_idx + j] for j in range(args.batch_size)], tokenizer, args.model_max_length)
                 sample_idx += args.batch_size
                 batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 out = model(**batch)
-                out["loss"].backward()      # gradients accumulate in .grad across the micro-steps
-                for m, k in zip(meters[1:], keys[1:]):
-                    m.update(float(out[k].detach()), args.batch_size)
-            grads = [p.grad for p in model.parameters() if p.grad is not None]
-            T.allreduce_mean_(grads)        # ONE bucketed RCCL all-reduce of the trainable set per optimizer step
+                # gradients accumulate into the bucket views across the micro-steps; on the last one each bucket's
+                # all-reduce (RCCL) is issued as soon as its last gradient lands, under the rest of backward
+                reducer.begin(sync=micro == args.grad_accumulation_steps - 1)
+                out["loss"].backward()
+                loss_acc += torch.stack([out[k].detach().float().reshape(()) for k in keys[1:]])   # no host sync
+                n_acc += 1
+            reducer.finish()
+            grads = reducer.grads()
             gscale = 1.0 / args.grad_accumulation_steps
             norm = float(T.grad_norm(grads)) * gscale
             gscale *= min(1.0, 1.0 / (norm + 1e-6))                                  # gradient_clipping: 1.0
@@ -321,6 +327,10 @@ def main(argv):
             meters[0].update(time.time() - end)
             end = time.time()
             if global_step % args.print_freq == 0:
+                for m, v in zip(meters[1:], (loss_acc / max(n_acc, 1)).tolist()):   # ONE device->host read per log line
+                    m.update(v, n_acc * args.batch_size)
+                loss_acc.zero_()
+                n_acc = 0
                 all_reduce_meters(meters, device)
                 if rank == 0:
                     print(progress_line(epoch, step + 1, args.steps_per_epoch, meters[:6]), flush=True)

@@ -80,3 +80,101 @@ def allreduce_mean_(tensors, bucket_bytes=64 << 20):
         if size >= bucket_bytes:
             flush()
     flush()
+
+
+def _ready_rank(name):
+    """Order in which the trainable tensors' gradients become final during backward (output side first):
+    lm_head, then text_hidden_fcs and the mask decoders, then the LoRA pairs from the LAST Llama layer down to the first,
+    embed_tokens last (its gradient is only complete once the whole backward has reached the input embeddings)."""
+    import re
+    if name.startswith("lm_head"):
+        return (0, 0)
+    if "embed_tokens" in name:
+        return (3, 0)
+    m = re.search(r"layers\.(\d+)\.", name)
+    if m and "lora_" in name:
+        return (2, -int(m.group(1)))
+    return (1, 0)
+
+
+class GradBucketReducer:
+    """Gradient all-reduce of the trainable set, overlapped with backward (the reference's engine does
+    the same with overlap_comm / reduce_scatter per micro-step, train_ds.py:372-379 — here ONCE per optimizer step).
+
+    * parameters are assigned to buckets of ~bucket_bytes in the order their gradients become ready (_ready_rank), per
+      dtype; every bucket owns ONE flat buffer in the gradients' own dtype and each p.grad is a VIEW into it: backward
+      accumulates straight into the bucket (no cat, no up-cast, no copy back);
+    * post-accumulate hooks count a bucket's arrivals; on the LAST micro-step of an accumulation window (begin(sync=True))
+      the bucket's async all-reduce (RCCL over xGMI on the GPU node, gloo in the CPU tests) is launched the moment its
+      last gradient lands, while backward continues into the earlier layers;
+    * finish() launches whatever never fired (tensors the loss does not reach), waits, and turns sums into means.
+    """
+
+    def __init__(self, named_params, bucket_bytes=64 << 20):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        items = sorted(named_params, key=lambda kv: _ready_rank(kv[0]))
+        self.buckets = []          # each: {"flat", "names", "pending", "n", "work"}
+        self.bucket_of = {}
+        cur = None
+        for name, p in items:
+            nbytes = p.numel() * p.element_size()
+            if cur is None or cur["dtype"] != p.dtype or cur["bytes"] + nbytes > bucket_bytes and cur["bytes"] > 0:
+                cur = {"dtype": p.dtype, "bytes": 0, "params": [], "names": []}
+                self.buckets.append(cur)
+            cur["params"].append(p)
+            cur["names"].append(name)
+            cur["bytes"] += nbytes
+        for bi, b in enumerate(self.buckets):
+            n = sum(p.numel() for p in b["params"])
+            b["flat"] = torch.zeros((n,), dtype=b["dtype"], device=b["params"][0].device)
+            off = 0
+            for p in b["params"]:
+                p.grad = b["flat"][off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self.bucket_of[id(p)] = bi
+                p.register_post_accumulate_grad_hook(self._on_grad)
+            b["n"], b["pending"], b["work"] = len(b["params"]), len(b["params"]), None
+        self.sync = False
+        self.launch_order = []     # bucket indices in the order their all-reduce was issued (tests / tracing)
+
+    def zero(self):
+        for b in self.buckets:
+            b["flat"].zero_()
+
+    def begin(self, sync):
+        """Call before each backward: sync=True on the micro-step whose gradients complete the accumulation window."""
+        self.sync = bool(sync) and self.world > 1
+        self.launch_order = []
+        for b in self.buckets:
+            b["pending"], b["work"] = b["n"], None
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        b["work"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+        self.launch_order.append(bi)
+
+    def _on_grad(self, p):
+        if not self.sync:
+            return
+        bi = self.bucket_of[id(p)]
+        b = self.buckets[bi]
+        b["pending"] -= 1
+        if b["pending"] == 0 and b["work"] is None:
+            self._launch(bi)
+
+    def finish(self):
+        """After the last backward of the window: every bucket reduced and averaged in place (p.grad views see it)."""
+        if self.world == 1:
+            return
+        for bi, b in enumerate(self.buckets):
+            if b["work"] is None:
+                self._launch(bi)
+        for b in self.buckets:
+            b["work"].wait()
+            b["flat"].div_(self.world)
+        self.sync = False
+
+    def grads(self):
+        return [b["flat"] for b in self.buckets]

@@ -86,7 +86,7 @@ def _grad_worker(rank, world, port, q):
     meters[1].update(0.5, 1)
     all_reduce_meters(meters, "cpu")
     if rank == 0:
-        q.put(([t.float() for t in grads], [(m.sum, m.count) for m in meters]))
+        q.put(([t.float().numpy().copy() for t in grads], [(m.sum, m.count) for m in meters]))  # numpy: no fd passing
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -110,7 +110,159 @@ def test_two_rank_gradient_allreduce_equals_mean_of_rank_gradients():
         per_rank.append([torch.randn((257, 3), generator=g), torch.randn((1000,), generator=g).to(torch.bfloat16).float(),
                          torch.randn((5,), generator=g)])
     for i, got in enumerate(grads):
+        got = torch.from_numpy(got)
         ref = (per_rank[0][i] + per_rank[1][i]) / 2
         tol = 1e-6 if i != 1 else 2e-2
         assert (got - ref).abs().max().item() <= tol
     assert meters[0] == (2.0 + 4.0, 4.0) and meters[1] == (1.0, 2.0)
+
+
+# ---- DDP semantics on the MODEL's gradients: two ranks on half-batches + overlapped bucketed ----
+# ---- all-reduce == one process on the concatenated batch. CPU stand-in for the HIP model: the oracle under autograd.   ----
+def _trainable_leaves(cfg, sd, seed=3, r=4):
+    """The reference's trainable set (train_ds.py:192-244) as fp32 leaves: LoRA A/B on q_proj / v_proj of every Llama layer,
+    embed_tokens, lm_head, text_hidden_fcs, both mask decoders."""
+    g = torch.Generator().manual_seed(seed)
+    osd = {k: v.clone() for k, v in sd.items()}
+    named, lora = [], {}
+    for k in sorted(sd):
+        if k in ("lm_head.weight", "model.embed_tokens.weight") or "text_hidden_fcs" in k or "mask_decoder_" in k:
+            osd[k] = osd[k].clone().requires_grad_(True)
+            named.append((k, osd[k]))
+    H = cfg.llm.hidden
+    for i in range(cfg.llm.layers):
+        for n in ("q_proj", "v_proj"):
+            base = f"model.layers.{i}.self_attn.{n}"
+            lora[base + ".lora_A"] = (torch.randn((r, H), generator=g) * 0.05).requires_grad_(True)
+            lora[base + ".lora_B"] = (torch.randn((H, r), generator=g) * 0.05).requires_grad_(True)
+            named += [(base + ".lora_A", lora[base + ".lora_A"]), (base + ".lora_B", lora[base + ".lora_B"])]
+    return osd, lora, named
+
+
+def _half(batch, lo, hi):
+    out = {}
+    for k, v in batch.items():
+        if k == "offset":
+            out[k] = torch.arange(hi - lo + 1)
+        elif torch.is_tensor(v):
+            out[k] = v[lo:hi]
+        elif isinstance(v, list):
+            out[k] = v[lo:hi]
+        else:
+            out[k] = v
+    return out
+
+
+def _model_grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from haff import config as hcfg, train_ops as T, weights as hw
+    from oracle import lisa_oracle as O
+    from test_train_gpu import make_batch
+    hdist.init_from_env("gloo")
+    cfg = hcfg.tiny()
+    sd = hw.make_state_dict(cfg, 21)
+    osd, lora, named = _trainable_leaves(cfg, sd)
+    reducer = T.GradBucketReducer(named, bucket_bytes=64 << 10)
+    fired_in_backward = []
+    launch = reducer._launch
+    reducer._launch = lambda bi: (fired_in_backward.append(bi), launch(bi))[1]
+    batch = make_batch(cfg, b=2, hw=(40, 36))
+    reducer.zero()
+    # two micro-steps (gradient accumulation): only the second one may talk to the other rank
+    for micro in range(2):
+        reducer.begin(sync=micro == 1)
+        out = O.lisa_model_forward(osd, cfg, _half(batch, rank, rank + 1), lora=lora, lora_alpha=8.0)
+        (out["loss"] * 0.5).backward()
+        if micro == 0:
+            assert fired_in_backward == []
+    n_hook = len(fired_in_backward)
+    reducer.finish()
+    if rank == 0:
+        names = [b["names"] for b in reducer.buckets]
+        q.put(({k: p.grad.detach().numpy().copy() for k, p in named}, n_hook, list(reducer.launch_order), names))  # numpy: no fd passing
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_model_gradients_equal_single_process_on_the_concatenated_batch():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from haff import config as hcfg, weights as hw
+    from oracle import lisa_oracle as O
+    from test_train_gpu import make_batch
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, n_hook, order, names = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single process, whole batch, the same two accumulation micro-steps
+    cfg = hcfg.tiny()
+    sd = hw.make_state_dict(cfg, 21)
+    osd, lora, named = _trainable_leaves(cfg, sd)
+    batch = make_batch(cfg, b=2, hw=(40, 36))
+    for _ in range(2):
+        out = O.lisa_model_forward(osd, cfg, batch, lora=lora, lora_alpha=8.0)
+        (out["loss"] * 0.5).backward()
+    worst = 0.0
+    for k, p in named:
+        gk = torch.from_numpy(got[k])
+        if p.grad is None:
+            assert float(gk.abs().max()) == 0.0, k
+            continue
+        scale = p.grad.abs().max().item()
+        err = (gk - p.grad).abs().max().item()
+        worst = max(worst, err / (scale + 1e-12) if scale > 1e-7 else 0.0)
+        assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
+    # overlap: buckets were launched from inside backward, output side before input side
+    assert n_hook >= 2 and len(order) == len(names)
+    flat_names = [n for bi in order for n in names[bi]]
+    assert flat_names.index("lm_head.weight") < flat_names.index("model.layers.0.self_attn.q_proj.lora_A")
+    assert flat_names.index("model.layers.1.self_attn.q_proj.lora_A") < flat_names.index("model.layers.0.self_attn.q_proj.lora_A")
+
+
+def _bench_stub_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import contextlib
+    import io
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--stub-step-ms", str(20 + 30 * rank), "--batch", "5"])
+    q.put((rank, buf.getvalue()))
+
+
+def test_bench_multi_rank_path_dry_run_with_stub_model():
+    """bench.py --gpus 2 (rendezvous from the torchrun environment, fence, EXACTLY K timed steps, max over ranks, one JSON
+    line on rank 0, barrier + teardown) with the model replaced by a sleep: rank 1 is the slow rank (50 ms vs 20 ms per
+    step), so value must be whole-job frames / the SLOW rank's time."""
+    import json
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_stub_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[1].strip() == ""                       # only rank 0 prints
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["ms_per_step"] >= 50.0 and line["ms_per_step"] < 120.0
+    assert abs(line["value"] - 2 * 5 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    assert line["cpu_baseline"] is None and line["config"]["stub"] is True

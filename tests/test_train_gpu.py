@@ -171,3 +171,74 @@ def test_merged_checkpoint_reproduces_lora_model(dev):
     with torch.no_grad():
         plain = base.forward(x.view(B, T, H).clone(), base.new_cache(B, T)).float().cpu().view(B * T, H)
     assert (plain - ref).abs().max().item() / ref.abs().max().item() > 5 * err
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import haff  # noqa: F401
+    from haff import config as hcfg, dist as hdist, train_ops as T, weights as hw
+    from haff.train_model import LisaTrainable
+    hdist.init_from_env("gloo")   # both ranks share the one GPU of the box: gloo carries the HBM-resident buckets
+    dev = torch.device("cuda:0")
+    cfg = hcfg.tiny()
+    model = LisaTrainable(cfg, hw.make_state_dict(cfg, 21), dtype=torch.float32, device=dev, lora_dropout=0.0,
+                          lora_init_b_zero=False, seed=3)
+    reducer = T.GradBucketReducer(model.named_parameters(), bucket_bytes=64 << 10)
+    in_backward = []
+    launch = reducer._launch
+    reducer._launch = lambda bi: (in_backward.append(bi), launch(bi))[1]
+    full = make_batch(cfg, b=2)
+    half = {k: (v[rank:rank + 1] if torch.is_tensor(v) and k != "offset" else (v[rank:rank + 1] if isinstance(v, list) else v))
+            for k, v in full.items()}
+    half["offset"] = torch.arange(2)
+    half = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in half.items()}
+    reducer.zero()
+    reducer.begin(sync=True)
+    model(**half)["loss"].backward()
+    n_hook = len(in_backward)
+    reducer.finish()
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(({k: p.grad.float().cpu().numpy().copy() for k, p in model.named_parameters()}, n_hook, len(reducer.buckets)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_finetune_gradients_equal_single_process(dev):
+    """configs[3]'s data-parallel rule on the real HIP model: LisaTrainable on two half-batches in two processes +
+    GradBucketReducer (buckets all-reduced from backward hooks) == one process on the concatenated batch (fp32, 1e-4)."""
+    import socket
+    import torch.multiprocessing as mp
+    import haff  # noqa: F401
+    from haff import config as hcfg, weights as hw
+    from haff.train_model import LisaTrainable
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, n_hook, n_buckets = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = hcfg.tiny()
+    model = LisaTrainable(cfg, hw.make_state_dict(cfg, 21), dtype=torch.float32, device=dev, lora_dropout=0.0,
+                          lora_init_b_zero=False, seed=3)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(cfg, b=2).items()}
+    model(**batch)["loss"].backward()
+    checked = 0
+    for k, p in model.named_parameters():
+        g = torch.from_numpy(got[k])
+        if p.grad is None:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        ref = p.grad.float().cpu()
+        scale = ref.abs().max().item()
+        assert (g - ref).abs().max().item() <= 1e-4 * scale + 1e-7, k
+        checked += 1
+    print(f"{checked} gradient tensors equal; {n_hook} of {n_buckets} buckets were all-reduced from inside backward")
+    assert checked > 150 and n_hook >= 2
