@@ -15,13 +15,35 @@ from . import weights as hw
 
 
 def config_from_dir(path):
-    """7B vs 13B geometry from the checkpoint's config.json (hidden_size / num_hidden_layers)."""
+    """Model geometry from the checkpoint's config.json: the Llama fields HF writes (hidden_size, num_hidden_layers,
+    num_attention_heads, intermediate_size, vocab_size, rms_norm_eps, rope_theta), LLaVA's mm_vision_select_layer and
+    LISA's out_dim. SAM ViT-H and CLIP-L/14 are what the reference hard-wires (build_sam.py:15-23, inference.py:34-36);
+    a non-default vision geometry (this repo's reduced test models) travels in the optional "haff_geometry" key."""
     with open(os.path.join(path, "config.json")) as f:
         c = json.load(f)
     cfg = hcfg.haff_13b() if int(c.get("hidden_size", 4096)) == 5120 else hcfg.haff_7b()
-    cfg.llm.vocab = int(c.get("vocab_size", cfg.llm.vocab))
-    cfg.llm.rms_eps = float(c.get("rms_norm_eps", cfg.llm.rms_eps))
+    l = cfg.llm
+    l.hidden = int(c.get("hidden_size", l.hidden))
+    l.layers = int(c.get("num_hidden_layers", l.layers))
+    l.heads = int(c.get("num_attention_heads", l.heads))
+    l.ffn = int(c.get("intermediate_size", l.ffn))
+    l.rope_theta = float(c.get("rope_theta", l.rope_theta))
+    l.rms_eps = float(c.get("rms_norm_eps", l.rms_eps))
+    # a plain LLaVA base says 32000; the fine-tune adds [SEG], <im_start>, <im_end> (train_ds.py:142-149) -> +3
+    n_base = int(c.get("vocab_size", l.vocab))
+    l.vocab = n_base if c.get("haff_vocab_includes_added_tokens", n_base % 1000 == 3) else n_base + 3
+    cfg.seg_token_idx, cfg.im_start_idx, cfg.im_end_idx = l.vocab - 3, l.vocab - 2, l.vocab - 1
+    cfg.out_dim = int(c.get("out_dim", cfg.out_dim))
     cfg.clip.select_layer = int(c.get("mm_vision_select_layer", cfg.clip.select_layer))
+    for k in ("bos_token_id", "eos_token_id", "pad_token_id"):
+        if c.get(k) is not None:
+            setattr(cfg, k, int(c[k]))
+    geo = c.get("haff_geometry") or {}
+    for name, sub in (("sam", cfg.sam), ("clip", cfg.clip)):
+        for k, v in (geo.get(name) or {}).items():
+            setattr(sub, k, tuple(v) if isinstance(v, list) else v)
+    if "name" in geo:
+        cfg.name = geo["name"]
     return cfg
 
 
@@ -43,8 +65,9 @@ def load_hf_dir(path):
     return sd
 
 
-def load_state_dict(version_dir, clip_dir=None, sam_ckpt=None):
-    """Reference-keyed state dict for LisaMI355 from on-disk checkpoints."""
+def load_state_dict(version_dir, clip_dir=None, sam_ckpt=None, for_training=False, seed=0):
+    """Reference-keyed state dict for LisaMI355 from on-disk checkpoints. for_training: a plain LLaVA base is completed
+    the way the reference's fine-tune entrypoint does it (complete_for_training)."""
     sd = load_hf_dir(version_dir)
     if clip_dir is not None:
         for k, v in load_hf_dir(clip_dir).items():
@@ -57,10 +80,42 @@ def load_state_dict(version_dir, clip_dir=None, sam_ckpt=None):
                 sd["model.visual_model." + k.replace("mask_decoder", "mask_decoder_right", 1)] = v
             else:
                 sd.setdefault("model.visual_model." + k, v)
+    if for_training:
+        complete_for_training(sd, config_from_dir(version_dir), seed)
     missing = [k for k in hw.all_shapes(config_from_dir(version_dir)) if k not in sd and "post_layernorm" not in k]
     if missing:
         raise KeyError(f"{len(missing)} tensors missing from the checkpoint, e.g. {missing[:4]}")
     return sd
+
+
+def complete_for_training(sd, cfg, seed=0):
+    """What the reference builds on top of a plain LLaVA base before fine-tuning (train_ds.py:167-244,
+    LISA.py:79-104): `resize_token_embeddings(len(tokenizer))` — embed_tokens / lm_head grow to the vocabulary with the
+    added [SEG], <im_start>, <im_end> rows (new rows ~ N(0, initializer_range = 0.02), the HF _init_weights rule);
+    `initialize_lisa_modules` — text_hidden_fcs freshly initialised (nn.Linear default: U(-1/sqrt(in), 1/sqrt(in)) for
+    weight and bias) and SAM built from --vision_pretrained with mask_decoder.* duplicated left/right
+    (build_sam.py:125-136; done by load_state_dict) plus the taxonomy head, which no SAM checkpoint has (nn.Linear default).
+    Only tensors ABSENT from `sd` are created (a merged 2HAff checkpoint passes through unchanged). Seeded: every rank builds
+    identical tensors."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = hw.all_shapes(cfg)
+
+    created = []
+    for k in ("model.embed_tokens.weight", "lm_head.weight"):
+        have, want = sd[k].shape[0], shapes[k][0]
+        if have < want:
+            extra = torch.randn((want - have, sd[k].shape[1]), generator=g) * 0.02
+            sd[k] = torch.cat([sd[k].float(), extra], 0).to(sd[k].dtype)
+            created.append(f"{k}[{have}:{want}]")
+    for k, shape in shapes.items():
+        if k in sd:
+            continue
+        if "text_hidden_fcs" in k or "taxonomy_embed" in k:
+            fan_in = shapes[k.replace(".bias", ".weight")][1]
+            bound = 1.0 / fan_in ** 0.5
+            sd[k] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            created.append(k)
+    return created
 
 
 def synthetic_state_dict(cfg, seed, device=None, dtype=torch.bfloat16):

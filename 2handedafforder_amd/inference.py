@@ -60,21 +60,19 @@ def build_model_and_tokenizer(args):
         sd = checkpoint.synthetic_state_dict(cfg, 1234, device, dtype)
         tokenizer = checkpoint.ByteTokenizer(cfg)
     else:
-        cfg = checkpoint.config_from_dir(args.version)
+        # inference.py:115-127,158-168: slow (sentencepiece) Llama tokenizer of the checkpoint + [SEG]; the model from
+        # LISAForCausalLM.from_pretrained(version, vision_tower=, seg_token_idx=) — local directories (no hub here)
         sp_file = os.path.join(args.version, "tokenizer.model")
-        try:
-            from transformers import AutoTokenizer
-            tokenizer = AutoTokenizer.from_pretrained(args.version, cache_dir=None, model_max_length=args.model_max_length,
-                                                      padding_side="right", use_fast=False)
-            tokenizer.pad_token = tokenizer.unk_token
-        except Exception:  # transformers without the slow (sentencepiece) Llama tokenizer: use the model file directly
-            if not os.path.isfile(sp_file):
-                raise
-            tokenizer = checkpoint.SentencePieceTokenizer(sp_file)
-        cfg.seg_token_idx = tokenizer("[SEG]", add_special_tokens=False).input_ids[0]
+        if not os.path.isfile(sp_file):
+            raise SystemExit(f"{sp_file} not found: --version must be a local merged-checkpoint directory")
+        tokenizer = checkpoint.SentencePieceTokenizer(sp_file)
+        seg = tokenizer("[SEG]", add_special_tokens=False).input_ids[0]
+        clip_dir = args.vision_tower if os.path.isdir(args.vision_tower) else None
+        model = LisaMI355.from_pretrained(args.version, vision_tower=clip_dir, seg_token_idx=seg, torch_dtype=dtype,
+                                          sam_checkpoint=args.sam_checkpoint, device=device).eval()
+        cfg = model.cfg
         cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
-        sd = checkpoint.load_state_dict(args.version, args.vision_tower if os.path.isdir(args.vision_tower) else None,
-                                        args.sam_checkpoint)
+        return model, tokenizer, cfg, dtype
     model = LisaMI355(cfg, sd, dtype=dtype, device=device).eval()
     return model, tokenizer, cfg, dtype
 

@@ -292,3 +292,18 @@ class LisaMI355:
     @classmethod
     def from_state_dict(cls, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", **kw):
         return cls(cfg, state_dict, dtype=dtype, device=device, **kw)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, vision_tower=None, seg_token_idx=None,
+                        torch_dtype=torch.bfloat16, sam_checkpoint=None, device="cuda:0", **kw):
+        """The constructor the reference's CLIs use (inference.py:158-168, chat.py:104-114):
+        `LISAForCausalLM.from_pretrained(version, vision_tower=, seg_token_idx=, torch_dtype=)` followed by
+        `initialize_vision_modules` — a merged checkpoint directory (merge_lora_weights_and_save_hf_model.py:149-155 layout:
+        sharded weights + index + config.json, `vision_tower` keys excluded) plus the CLIP tower from its own directory
+        (clip_encoder.py:21-29). Local directories only: there is no hub access in this setting."""
+        from . import checkpoint
+        cfg = checkpoint.config_from_dir(pretrained_model_name_or_path)
+        if seg_token_idx is not None:
+            cfg.seg_token_idx = int(seg_token_idx)
+        sd = checkpoint.load_state_dict(pretrained_model_name_or_path, vision_tower, sam_checkpoint)
+        return cls(cfg, sd, dtype=torch_dtype, device=device, **kw)

@@ -30,8 +30,8 @@ def merge_state_dict(base_sd, trained, lora_r, lora_alpha, dtype=torch.bfloat16)
     for k, v in trained.items():
         if k.endswith(".lora_A") or k.endswith(".lora_B"):
             continue
-        if k not in out:
-            raise KeyError(f"trained tensor {k} has no counterpart in the base checkpoint")
+        # tensors the fine-tune CREATED on top of a plain LLaVA base (text_hidden_fcs, the mask decoders with their taxonomy
+        # head, the resized embed_tokens / lm_head) have no counterpart, or a smaller one, in the base: the trained one wins
         out[k] = v.detach().to("cpu")
     for k in [k for k in trained if k.endswith(".lora_A")]:
         mod = k[: -len(".lora_A")]
@@ -79,6 +79,9 @@ def hf_config(cfg, dtype):
             "num_hidden_layers": l.layers, "num_attention_heads": l.heads, "intermediate_size": l.ffn,
             "vocab_size": l.vocab, "rms_norm_eps": l.rms_eps, "rope_theta": l.rope_theta,
             "mm_vision_select_layer": cfg.clip.select_layer, "mm_use_im_start_end": True,
+            # the two keys LISAForCausalLM.__init__ branches on when the merged checkpoint is loaded again (LISA.py:129-141)
+            "train_mask_decoder": True, "out_dim": cfg.out_dim, "haff_vocab_includes_added_tokens": True,
+            "haff_geometry": {"name": cfg.name, "sam": dict(vars(cfg.sam)), "clip": dict(vars(cfg.clip))},
             "bos_token_id": cfg.bos_token_id, "eos_token_id": cfg.eos_token_id, "pad_token_id": cfg.pad_token_id,
             "torch_dtype": {torch.bfloat16: "bfloat16", torch.float32: "float32", torch.float16: "float16"}[dtype]}
 
@@ -91,6 +94,7 @@ def parse_args(argv=None):
     p.add_argument("--precision", default="bf16", choices=["fp32", "bf16", "fp16"])
     p.add_argument("--lora_r", default=8, type=int)
     p.add_argument("--lora_alpha", default=16, type=int)
+    p.add_argument("--vision_pretrained", default="", type=str, help="SAM checkpoint (sam_vit_h_4b8939.pth) when the base has no visual_model")
     return p.parse_args(argv)
 
 
@@ -102,6 +106,10 @@ def main(argv=None):
     base = checkpoint.load_hf_dir(args.version)
     blob = torch.load(args.weight, map_location="cpu", weights_only=False)
     trained = blob["params"] if isinstance(blob, dict) and "params" in blob else blob
+    if args.vision_pretrained:   # frozen SAM encoder / prompt encoder of the fine-tune run (the decoders come from `trained`)
+        for k, v in checkpoint._load_file(args.vision_pretrained).items():
+            if not k.startswith("mask_decoder."):
+                base.setdefault("model.visual_model." + k, v)
     merged = merge_state_dict(base, trained, args.lora_r, args.lora_alpha, dtype)
     files = save_pretrained(merged, args.save_path, hf_config(cfg, dtype))
     tok = os.path.join(args.version, "tokenizer.model")

@@ -26,9 +26,11 @@ if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import haff  # noqa: F401
     from haff import checkpoint, config as hcfg, dist as hdist, prompt as hprompt, train_ops as T
+    from haff.aff_dataset import AffRecordsDataset
     from haff.train_model import LisaTrainable
 else:
     from . import checkpoint, config as hcfg, dist as hdist, prompt as hprompt, train_ops as T
+    from .aff_dataset import AffRecordsDataset
     from .train_model import LisaTrainable
 
 
@@ -72,7 +74,12 @@ def parse_args(args):
     p.add_argument("--auto_resume", action="store_true", default=True)
     p.add_argument("--conv_type", default="llava_v1", type=str, choices=["llava_v1", "llava_llama_2"])
     # MI355X / offline extras
-    p.add_argument("--synthetic", default="tiny", choices=["tiny", "mid", "7b", "13b"])
+    p.add_argument("--synthetic", default=None, choices=["tiny", "mid", "7b", "13b"],
+                   help="random-init model of this geometry + byte tokenizer + synthetic samples (no checkpoints needed); "
+                        "without it --version / --vision-tower / --vision_pretrained / --dataset_dir are REAL local paths")
+    p.add_argument("--sam_records", default=None, type=str,
+                   help="a torch-saved list of 2HANDS records (narration, inpainted/image, taxonomy, masks) when the HF "
+                        "`datasets` hub / the h5 layout under --dataset_dir is not available")
     p.add_argument("--val_samples", default=4, type=int)
     p.add_argument("--mask_hw", default=None, type=int, nargs=2, help="ground-truth mask size (default: image size)")
     p.add_argument("--seed", default=0, type=int)
@@ -255,10 +262,31 @@ def main(argv):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
-    cfg = {"tiny": hcfg.tiny, "mid": hcfg.mid, "7b": hcfg.haff_7b, "13b": hcfg.haff_13b}[args.synthetic]()
-    tokenizer = checkpoint.ByteTokenizer(cfg)
-    tokenizer.model_max_length = args.model_max_length
-    sd = checkpoint.synthetic_state_dict(cfg, 1234, device, dtype)   # identical on every rank (same seed)
+    if args.synthetic:
+        cfg = {"tiny": hcfg.tiny, "mid": hcfg.mid, "7b": hcfg.haff_7b, "13b": hcfg.haff_13b}[args.synthetic]()
+        tokenizer = checkpoint.ByteTokenizer(cfg)
+        tokenizer.model_max_length = args.model_max_length
+        sd = checkpoint.synthetic_state_dict(cfg, 1234, device, dtype)   # identical on every rank (same seed)
+    else:
+        # the reference's model construction (train_ds.py:135-181): tokenizer + added tokens from --version, the base
+        # checkpoint, the CLIP tower from --vision-tower, SAM from --vision_pretrained, text_hidden_fcs / taxonomy head /
+        # the three new vocabulary rows freshly initialised (checkpoint.complete_for_training, same seed on every rank)
+        for flag, path in (("--version", args.version), ("--vision-tower", args.vision_tower),
+                           ("--vision_pretrained", args.vision_pretrained)):
+            if not os.path.exists(path):
+                raise SystemExit(f"{flag} {path!r} is not a local path (no hub access here); pass a directory/file, "
+                                 f"or --synthetic <geometry> for a random-init plumbing run")
+        cfg = checkpoint.config_from_dir(args.version)
+        cfg.out_dim = args.out_dim
+        tokenizer = checkpoint.SentencePieceTokenizer(os.path.join(args.version, "tokenizer.model"))
+        tokenizer.model_max_length = args.model_max_length
+        cfg.seg_token_idx = tokenizer("[SEG]", add_special_tokens=False).input_ids[0]
+        cfg.im_start_idx = tokenizer("<im_start>", add_special_tokens=False).input_ids[0]
+        cfg.im_end_idx = tokenizer("<im_end>", add_special_tokens=False).input_ids[0]
+        cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
+        cfg.llm.vocab = max(cfg.llm.vocab, len(tokenizer))
+        sd = checkpoint.load_state_dict(args.version, args.vision_tower, args.vision_pretrained, for_training=True,
+                                        seed=args.seed)
     model = LisaTrainable(cfg, sd, dtype=dtype, device=device, lora_r=args.lora_r, lora_alpha=args.lora_alpha,
                           lora_dropout=args.lora_dropout, ce_loss_weight=args.ce_loss_weight,
                           dice_loss_weight=args.dice_loss_weight, bce_loss_weight=args.bce_loss_weight, seed=args.seed)
@@ -282,8 +310,21 @@ def main(argv):
         start_epoch = global_step // args.steps_per_epoch
         if rank == 0:
             print(f"resume training from {resume}, start from epoch {start_epoch}")
-    train_ds = SyntheticAffDataset(cfg, 10 ** 9, args.seed + 1000 * rank, args.mask_hw)
-    val_ds = SyntheticAffDataset(cfg, args.val_samples, 777, args.mask_hw, inference=True)
+    if args.synthetic:
+        train_ds = SyntheticAffDataset(cfg, 10 ** 9, args.seed + 1000 * rank, args.mask_hw)
+        val_ds = SyntheticAffDataset(cfg, args.val_samples, 777, args.mask_hw, inference=True)
+    else:
+        # AffRecordsDataset = utils/aff_dataset.py:48-346 on the records' HF layout
+        if args.sam_records:
+            records = torch.load(args.sam_records, weights_only=False)
+            train_ds = AffRecordsDataset(records, cfg, seed=args.seed + 1000 * rank)
+            val_ds = AffRecordsDataset(records[:max(args.val_samples, 1)], cfg, samples_per_epoch=args.val_samples, inference=True, seed=777)
+        elif os.path.isdir(args.dataset_dir):
+            train_ds = AffRecordsDataset.from_local(args.dataset_dir, cfg, seed=args.seed + 1000 * rank)
+            val_ds = AffRecordsDataset.from_local(args.dataset_dir, cfg, samples_per_epoch=args.val_samples, inference=True, seed=777)
+        else:
+            train_ds = AffRecordsDataset.from_hf(args.dataset_dir, cfg, seed=args.seed + 1000 * rank)
+            val_ds = AffRecordsDataset.from_hf(args.dataset_dir, cfg, samples_per_epoch=args.val_samples, inference=True, seed=777)
     total_steps = args.epochs * args.steps_per_epoch
     if args.eval_only:
         iou, iocm = validate(model, val_ds, tokenizer, args, rank, world, device)
