@@ -26,11 +26,14 @@ def _write_inputs(tmp_path, cfg, sd):
     n_base = cfg.llm.vocab - 3
     corpus = tmp_path / "corpus.txt"
     words = ("where would someone grasp the cup to pour water cut bread with knife open drawer bottle hold pan stir pot "
-             "please segment region perform action image can you show me interact objects following task sure it is result")
-    corpus.write_text("\n".join(" ".join(np.random.default_rng(i).permutation(words.split())) for i in range(200)))
+             "please segment region perform action image can you show me interact objects following task sure it is result").split()
+    rng = np.random.default_rng(0)
+    filler = ["".join(rng.choice(list("abcdefghijklmnopqrstuvwxyz"), size=rng.integers(3, 9))) for _ in range(400)]
+    corpus.write_text("\n".join(" ".join(rng.choice(words + filler, size=12)) for _ in range(600)))
     spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(base / "tokenizer"), vocab_size=n_base,
                                    model_type="bpe", bos_id=1, eos_id=2, unk_id=0, pad_id=-1, character_coverage=1.0,
-                                   hard_vocab_limit=False)
+                                   minloglevel=2)
+    assert spm.SentencePieceProcessor(model_file=str(base / "tokenizer.model")).get_piece_size() == n_base
     llm = {k: v.clone() for k, v in sd.items() if k.startswith("model.layers.") or k in ("model.norm.weight",) or "mm_projector" in k}
     llm["model.embed_tokens.weight"] = sd["model.embed_tokens.weight"][:n_base].clone()
     llm["lm_head.weight"] = sd["lm_head.weight"][:n_base].clone()
@@ -78,7 +81,7 @@ def test_train_merge_serve_on_checkpoint_files(dev, tmp_path, capsys, monkeypatc
     argv = ["--version", str(base), "--vision-tower", str(clip), "--vision_pretrained", str(sam), "--sam_records", str(records),
             "--epochs", "1", "--steps_per_epoch", "2", "--grad_accumulation_steps", "2", "--batch_size", "2", "--precision", "bf16",
             "--log_base_dir", str(tmp_path / "runs"), "--exp_name", "t", "--val_samples", "2", "--lr", "0.0003",
-            "--image_size", str(cfg.sam.img_size), "--model_max_length", "400", "--lora_r", "4", "--lora_alpha", "8"]
+            "--image_size", str(cfg.sam.img_size), "--model_max_length", "3000", "--lora_r", "8", "--lora_alpha", "16"]
     train_ds.main(argv)
     out = capsys.readouterr().out
     assert "Epoch: [0][2/2]" in out and "IoU:" in out and "saved checkpoint" in out
@@ -86,7 +89,7 @@ def test_train_merge_serve_on_checkpoint_files(dev, tmp_path, capsys, monkeypatc
         train_ds.main(["--version", "liuhaotian/llava-v1.5-13b"])
     merged = tmp_path / "merged"
     merge_lora.main(["--version", str(base), "--weight", str(tmp_path / "runs" / "t" / "ckpt_model" / "latest.pt"),
-                     "--save_path", str(merged), "--precision", "bf16", "--lora_r", "4", "--lora_alpha", "8",
+                     "--save_path", str(merged), "--precision", "bf16", "--lora_r", "8", "--lora_alpha", "16",
                      "--vision_pretrained", str(sam)])
     mcfg = json.load(open(merged / "config.json"))
     assert mcfg["train_mask_decoder"] is True and mcfg["out_dim"] == 256 and mcfg["vocab_size"] == cfg.llm.vocab
