@@ -46,13 +46,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((address_space(3))) bf16x4* lds_v4_ptr;
 
+
 // NDT: output d-tiles actually computed (d <= 16*NDT <= DP): SAM's d = 80 lives in DP = 96 for the QK k-steps but
 // needs only 5 of the 6 P.V output tiles.
 // LSUM (needs d % 16 == 0 and d < DP): column d of the staged V tile is a constant 1, so the softmax denominator falls
 // out of the P.V MFMA as output row d (one extra d-tile of MFMAs instead of 16 VALU adds per q-tile per KV tile, and it
 // sums exactly the bf16-rounded probabilities the numerator uses).
-template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false>
+// FULL: Nq % 128 == 0 and Nk % 64 == 0 (and no causal mask, no grid remap): every tile is whole, so the clamped /
+// remapped load path, the key masks and the row guards are compiled out (the SAM global blocks: 4096 x 4096).
+template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false, bool FULL = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  static_assert(!FULL || (!CAUSAL && BIAS != 3), "FULL tiles only");
   constexpr int KSTRIDE = DP * 2 + 16;  // bytes
   constexpr int VSTRIDE = DP * 2 + 32;
   constexpr int NCH = DP / 32;          // 16-B chunks per thread per operand per tile
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
   const long k_step = (long)KT * p.k_st, v_step = (long)KT * p.v_st;
   auto load_tile = [&](int kt) {
-    const bool plain = (BIAS != 3) && (kt * KT + KT <= Nk);  // wave-uniform: whole tile in range, no remap
+    const bool plain = FULL || ((BIAS != 3) && (kt * KT + KT <= Nk));  // wave-uniform: whole tile in range, no remap
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       if (col_ok[i]) {   // chunks past d are never loaded nor written: their LDS slots are set once (below)
@@ -270,6 +274,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   for (int kt = 0; kt < nkt; ++kt) {
     const unsigned char* sK = sKV + (kt & 1) * STAGE_BYTES;
     const unsigned char* sV = sK + KT * KSTRIDE;
+    // BIAS 2: this tile's rel_h scalars were loaded one iteration ago. Materialise them BEFORE the next tile's K/V loads
+    // are issued: hipcc otherwise places their wait at the first use, behind those loads, as a full vmcnt(0) — every
+    // iteration then stalled for the whole K/V round trip before its first MFMA (51 % of the wave cycles parked).
+    float rh_cur[2] = {relh_next[0], relh_next[1]};
+    if (BIAS == 2) asm volatile("" : "+v"(rh_cur[0]), "+v"(rh_cur[1]));
     if (kt + 1 < nkt) load_tile(kt + 1);  // HBM -> registers, in flight during the MFMAs below
 
     // ---- S^T = K . Q^T, accumulators start at the (log2-domain) bias ----
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       // The running max is folded into the accumulator's initial value too: the MFMA then delivers s - m_run and
       // the exponentials need no subtraction unless this tile raises the max (first tile: no max yet, plain s).
       const float msub = m_run[qt];
-      const float rhv = relh_next[qt] * LOG2E - msub;
+      const float rhv = rh_cur[qt] * LOG2E - msub;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (BIAS == 2) sacc[t][qt] = f32x4{relw_r[qt][t][0] + rhv, relw_r[qt][t][1] + rhv, relw_r[qt][t][2] + rhv, relw_r[qt][t][3] + rhv};
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     // ---- scale, bias, mask, online softmax in the log2 domain (lane owns query column fr of each q-tile) ----
     // wave-uniform: does any element of this tile need masking?
-    bool need_mask = (kt * KT + KT > Nk);
+    bool need_mask = !FULL && (kt * KT + KT > Nk);
     if (CAUSAL) need_mask = need_mask || (kt * KT + KT - 1 > q0 + wave * 32 + p.q_pos0);
     int off_h[4][4], off_w[4][4];
     if (BIAS == 1) {
@@ -355,9 +364,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             sacc[t][qt][r] = ok ? sacc[t][qt][r] : -INFINITY;
           }
       }
+      // (this file is compiled with -fno-honor-nans: fmaxf() on MFMA results otherwise gets a canonicalising
+      // v_max_f32 x, x in front of every maximum — 32 extra VALU instructions per KV tile; the chain below then folds to
+      // v_max3_f32. An inline-asm v_max3 is not an option: hipcc pads no MFMA -> VALU wait states around asm operands.)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        mx = fmaxf(mx, fmaxf(fmaxf(sacc[t][qt][0], sacc[t][qt][1]), fmaxf(sacc[t][qt][2], sacc[t][qt][3])));
+      for (int t = 0; t < 4; ++t) {
+        mx = fmaxf(fmaxf(mx, sacc[t][qt][0]), sacc[t][qt][1]);
+        mx = fmaxf(fmaxf(mx, sacc[t][qt][2]), sacc[t][qt][3]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // s holds scores relative to m_run (or absolute before the first max is known). Exact lazy rescale: only a tile
@@ -450,13 +464,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
-template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false>
+template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false, bool FULL = false>
 int launch_attn(const AttnArgs& p, hipStream_t s) {
   constexpr int KSTRIDE = DP * 2 + 16, VSTRIDE = DP * 2 + 32;
   size_t lds = 2 * ((size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE);
   if (BIAS == 1) lds += (size_t)QB * (2 * 32 + 1) * sizeof(float);
   dim3 grid(((p.Nq + QB - 1) / QB) * p.H * p.B), block(256);
-  hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL, NDT, LSUM>), grid, block, lds, s, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<DP, BIAS, CAUSAL, NDT, LSUM, FULL>), grid, block, lds, s, p);
   return haff_check_launch();
 }
 
@@ -619,7 +633,10 @@ static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
       return launch_attn<128, 3, false>(p, s);
     }
     if (dp == 64) return mode == 2 ? launch_attn<64, 2, false>(p, s) : launch_attn<64, 1, false>(p, s);
-    if (dp == 96 && mode == 2 && d == 80) return launch_attn<96, 2, false, 6, true>(p, s);   // SAM global blocks
+    if (dp == 96 && mode == 2 && d == 80) {   // SAM global blocks
+      if ((Nq % 128) == 0 && (Nk % KT) == 0 && !nk_rows) return launch_attn<96, 2, false, 6, true, true>(p, s);
+      return launch_attn<96, 2, false, 6, true>(p, s);
+    }
     if (dp == 96) return mode == 2 ? launch_attn<96, 2, false>(p, s) : launch_attn<96, 1, false>(p, s);
     return mode == 2 ? launch_attn<128, 2, false>(p, s) : launch_attn<128, 1, false>(p, s);
   }

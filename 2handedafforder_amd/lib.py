@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhaff_hip.so")
+LIB_PATH = os.environ.get("HAFF_LIB_PATH") or os.path.join(_HERE, "lib", "libhaff_hip.so")   # override: A/B builds in tools/
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 c_void_p, c_long, c_int, c_float = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float

@@ -12,6 +12,7 @@ from haff import ops
 CASES = [  # name, B, H, Nq, Nk, d, causal, S
     ("sam window  B8", 8 * 25, 16, 196, 196, 80, False, 14),
     ("sam global  B8", 8, 16, 4096, 4096, 80, False, 64),
+    ("sam global  B32", 32, 16, 4096, 4096, 80, False, 64),
     ("clip        B64", 64, 16, 257, 257, 64, False, 0),
     ("llama pre   B64", 64, 32, 291, 291, 128, True, 0),
     ("llama dec   B64", 64, 32, 1, 298, 128, False, 0),

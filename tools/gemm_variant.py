@@ -10,7 +10,7 @@ import sys
 import torch
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(131072, 5120, 1280), (131072, 1280, 5120), (18624, 4096, 4096), (18624, 4096, 11008), (16448, 1024, 4096), (16448, 4096, 1024), (65536, 1280, 5120)]
+SHAPES = [(131072, 3840, 1280), (131072, 1280, 1280), (131072, 5120, 1280), (131072, 1280, 5120), (18624, 4096, 4096), (18624, 4096, 11008), (16448, 1024, 4096), (16448, 4096, 1024), (65536, 1280, 5120)]
 
 
 def load(name):
@@ -32,23 +32,25 @@ def main():
         act = int(os.environ.get("ACT", "0"))
         bias = torch.randn((N,), device=dev) if act else None
         resid = torch.randn((M, N), device=dev).to(torch.bfloat16) if os.environ.get("RESID") else None
-        res = {n: [] for n in names}
+        cfgs = [int(c) for c in os.environ.get("CFG", "2").split(",")]
+        cols = [(n, c) for n in names for c in cfgs]
+        res = {k: [] for k in cols}
         for r in range(4):
-            for n in names:
+            for n, cfg_id in cols:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
                     rc = libs[n].haff_gemm_bf16_cfg(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N,
                                                     bias.data_ptr() if act else None,
                                                     resid.data_ptr() if resid is not None else None, N if resid is not None else 0,
-                                                    None, M, N, K, act, 0, 0, int(os.environ.get("CFG", "2")), None)
+                                                    None, M, N, K, act, 0, 0, cfg_id, None)
                     assert rc == 0
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
-                    res[n].append(e0.elapsed_time(e1) / 3 * 1e3)
+                    res[(n, cfg_id)].append(e0.elapsed_time(e1) / 3 * 1e3)
         fl = 2.0 * M * N * K
-        print(f"{M:6d} {N:6d} {K:6d} | " + " | ".join(f"{n}: {sorted(v)[1]:8.1f} us {fl / sorted(v)[1] / 1e6:5.0f}" for n, v in res.items()), flush=True)
+        print(f"{M:6d} {N:6d} {K:6d} | " + " | ".join(f"{n}/cfg{c}: {sorted(v)[1]:8.1f} us {fl / sorted(v)[1] / 1e6:5.0f}" for (n, c), v in res.items()), flush=True)
 
 
 if __name__ == "__main__":
