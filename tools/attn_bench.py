@@ -18,6 +18,9 @@ CASES = [  # name, B, H, Nq, Nk, d, causal, S
     ("llama dec   B64", 64, 32, 1, 298, 128, False, 0),
     ("dec t2i     P64", 64, 8, 6, 4096, 16, False, 0),
     ("dec i2t     P64", 64, 8, 4096, 6, 16, False, 0),
+    ("dec t2i f32 P64", 64, 8, 6, 4096, 16, False, -1),
+    ("dec i2t f32 P64", 64, 8, 4096, 6, 16, False, -1),
+    ("dec self f32 P64", 64, 8, 6, 6, 32, False, -1),
 ]
 
 
@@ -36,13 +39,16 @@ def timeit(fn, reps=5):
 def main():
     dev = torch.device("cuda:0")
     for name, B, H, Nq, Nk, d, causal, S in CASES:
+        dt = torch.bfloat16
+        if S < 0:
+            dt, S = torch.float32, 0
         if Nq == Nk:
-            qkv = torch.randn((B, Nq, 3, H, d), device=dev).to(torch.bfloat16)
+            qkv = torch.randn((B, Nq, 3, H, d), device=dev).to(dt)
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         else:
-            q = torch.randn((B, Nq, H, d), device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
-            k = torch.randn((B, Nk, H, d), device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
-            v = torch.randn((B, Nk, H, d), device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
+            q = torch.randn((B, Nq, H, d), device=dev).to(dt).permute(0, 2, 1, 3)
+            k = torch.randn((B, Nk, H, d), device=dev).to(dt).permute(0, 2, 1, 3)
+            v = torch.randn((B, Nk, H, d), device=dev).to(dt).permute(0, 2, 1, 3)
         relh = relw = None
         line = f"{name:16s}"
         if S:
