@@ -38,6 +38,11 @@ struct AttnArgs {
   const float *relh, *relw;  // [B*H][Nq][S]
   int S;
   const int* nk_rows;  // optional, device int32 [B]: batch b sees only its first nk_rows[b] (<= Nk) keys (ragged KV caches)
+  // decode kernel with RoPE + cache append fused in (attn_decode_kernel<.., true>): q/k/v above are the RAW q row and the
+  // K/V caches; the newest position (nk_rows[b] - 1) comes from knew/vnew (raw, same (batch, head) strides as q), is
+  // rotated here and appended to the caches by this kernel
+  const bf16_t *knew, *vnew;
+  const float* cos_sin;   // [Tmax][d] = cos(0..d/2) | sin(0..d/2)
 };
 
 constexpr int QB = 128;   // queries per workgroup
@@ -496,7 +501,22 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
 // SPLIT: the four waves of a workgroup share ONE (batch, head) and take every fourth batch of 16 keys each (small
 // B*H: one wave per head left the step latency-bound — 35 us per layer at batch 1 for 4.7 MB of K/V); their partial
 // (max, sum, P.V) meet in LDS.
-template <bool SPLIT>
+// rotate-half RoPE of the 8 values a lane holds of a 128-wide head row (lane c: dims 8c .. 8c+7; the partner half sits 8
+// lanes away in the same 16-lane row), rounded to bf16 as the stand-alone rope kernel stores it
+__device__ __forceinline__ void rope8(float (&x)[8], const float* cs_row, int c) {
+  const int ci = (c & 7) * 8;
+  float cv[8], sv[8];
+  load8(cs_row + ci, cv);
+  load8(cs_row + DEC_D / 2 + ci, sv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float other = __shfl_xor(x[j], 8, 64);
+    const float r = c < 8 ? x[j] * cv[j] - other * sv[j] : x[j] * cv[j] + other * sv[j];
+    x[j] = bf16_to_f32(f32_to_bf16(r));
+  }
+}
+
+template <bool SPLIT, bool ROPE = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   __shared__ float s_ml[4][2];
   __shared__ float s_o[4][DEC_D];
@@ -513,6 +533,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 
   float qv[8];
   load8(qb + c * 8, qv);
+  uint4 knew_bits = make_uint4(0, 0, 0, 0), vnew_bits = make_uint4(0, 0, 0, 0);
+  if (ROPE) {
+    // position of this step = Nk - 1: rotate q and the new k (transformers apply_rotary_pos_emb), append k, v to the caches
+    const float* cs_row = p.cos_sin + (long)(Nk - 1) * DEC_D;
+    rope8(qv, cs_row, c);
+    float kn[8];
+    load8(p.knew + (long)b * p.q_sb + (long)h * p.q_sh + c * 8, kn);
+    rope8(kn, cs_row, c);
+    knew_bits.x = pack_bf16x2(kn[0], kn[1]); knew_bits.y = pack_bf16x2(kn[2], kn[3]);
+    knew_bits.z = pack_bf16x2(kn[4], kn[5]); knew_bits.w = pack_bf16x2(kn[6], kn[7]);
+    vnew_bits = *reinterpret_cast<const uint4*>(p.vnew + (long)b * p.q_sb + (long)h * p.q_sh + c * 8);
+    if (g == 0 && (!SPLIT || wave == 0)) {
+      *reinterpret_cast<uint4*>(const_cast<bf16_t*>(kb) + (long)(Nk - 1) * p.k_st) = knew_bits;
+      *reinterpret_cast<uint4*>(const_cast<bf16_t*>(vb) + (long)(Nk - 1) * p.v_st) = vnew_bits;
+    }
+  }
   const float sl2 = p.scale * LOG2E;
 #pragma unroll
   for (int j = 0; j < 8; ++j) qv[j] *= sl2;
@@ -525,8 +561,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 #pragma unroll
     for (int u = 0; u < DEC_UNROLL; ++u) {
       const int key = min((it0 + u) * 4 + g, Nk - 1);
-      kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st);
-      vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st);
+      if (ROPE) {   // the newest row is not in the cache yet for the other waves: take it from registers
+        const int kc = min(key, max(Nk - 2, 0));
+        kr[u] = *reinterpret_cast<const uint4*>(kb + (long)kc * p.k_st);
+        vr[u] = *reinterpret_cast<const uint4*>(vb + (long)kc * p.v_st);
+        if (key == Nk - 1) { kr[u] = knew_bits; vr[u] = vnew_bits; }
+      } else {
+        kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * p.k_st);
+        vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * p.v_st);
+      }
     }
 #pragma unroll
     for (int u = 0; u < DEC_UNROLL; ++u) {
@@ -615,7 +658,7 @@ static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
   if (rel && (causal || S <= 0 || (Nk % S) != 0)) return HAFF_ERR_BAD_ARG;
   AttnArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
              reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
-             B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S, nk_rows};
+             B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S, nk_rows, nullptr, nullptr, nullptr};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
@@ -672,6 +715,31 @@ extern "C" int haff_attention_decode_rows_bf16(const void* q, long q_sb, long q_
   if (!nk_rows) return HAFF_ERR_BAD_ARG;
   return attention_bf16_impl(q, q_sb, q_sh, (long)H * d, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, (long)H * d, B, H, 1,
                              Nk, d, scale, 0, 0, nullptr, nullptr, 0, nk_rows, stream);
+}
+
+// One KV-cached decode position per (batch, head) with RoPE and the cache append fused in — replaces haff_rope_cache_rows +
+// haff_attention_decode_rows_bf16 (two launches per layer per generated token) on the Llama decode path (transformers
+// LlamaAttention.forward with a KV cache, reached from llava_llama.py:93-102; rotate-half RoPE, theta from cos_sin).
+// qkv: [B][ld] rows holding q | k | v of the new position (H heads x d each, RAW: not rotated); kcache / vcache:
+// [B][Tmax][H*d]; cos_sin f32 [Tmax][d] = cos(0..d/2) | sin(0..d/2); nk_rows[b] = position of the new token + 1
+// (DEVICE int32 [B]): the new k (rotated) and v are written at cache row nk_rows[b] - 1 and attended with every older row.
+// out: [B][H*d]. d must be 128. Bit-identical to the two-kernel path.
+extern "C" int haff_decode_attention_rope_rows_bf16(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_sin,
+                                                    void* out, int B, int H, int d, int Tmax, float scale, const int* nk_rows,
+                                                    void* stream) {
+  if (B <= 0 || H <= 0 || d != DEC_D || Tmax <= 0 || !nk_rows || !cos_sin || (ld & 7)) return HAFF_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(kcache) & 15) ||
+      (reinterpret_cast<uintptr_t>(vcache) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return HAFF_ERR_BAD_ARG;
+  const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
+  const long hd = (long)H * d;
+  AttnArgs p{q, reinterpret_cast<const bf16_t*>(kcache), reinterpret_cast<const bf16_t*>(vcache), reinterpret_cast<bf16_t*>(out),
+             ld, d, hd, (long)Tmax * hd, d, hd, (long)Tmax * hd, d, hd, hd, d, hd,
+             B, H, 1, Tmax, d, scale, 0, nullptr, nullptr, 0, nk_rows, q + hd, q + 2 * hd, cos_sin};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (B * H <= 1024) hipLaunchKernelGGL((attn_decode_kernel<true, true>), dim3(B * H), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_decode_kernel<false, true>), dim3((B * H + 3) / 4), dim3(256), 0, s, p);
+  return haff_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------------

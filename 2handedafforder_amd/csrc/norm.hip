@@ -87,9 +87,87 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T* x, long ldx, T*
   }
 }
 
+// Few wide rows (KV-cached decode steps: 1..64 rows of 4096 / 5120): one WORKGROUP per row — 256 lanes x 16-B loads cover
+// 4 KiB per pass, the two statistics meet in LDS. One wave per row left 1..16 workgroups on the chip with 8-10 dependent
+// loads each: 14 us per call at 64 x 4096, 7.8 us at 1 x 4096 — two calls per layer of every decode step.
+template <typename T, int NCH, bool RMS>
+__global__ __launch_bounds__(256) void norm_row_wg_kernel(const T* x, long ldx, T* y, long ldy, const float* w,
+                                                         const float* bvec, int C, float eps) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row = blockIdx.x;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (tid + 256 * i) * 8;
+    if (c < C) {
+      load8(x + row * ldx + c, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += RMS ? v[i][j] * v[i][j] : v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[0][wave] = sum;
+  __syncthreads();
+  sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  float mean = 0.f, rstd;
+  if (RMS) {
+    rstd = 1.0f / sqrtf(sum / (float)C + eps);
+  } else {
+    mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (tid + 256 * i) * 8;
+      if (c < C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dlt = v[i][j] - mean;
+          sq += dlt * dlt;
+        }
+      }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[1][wave] = sq;
+    __syncthreads();
+    sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (tid + 256 * i) * 8;
+    if (c < C) {
+      float wv[8], o[8];
+      load8(w + c, wv);
+      if (RMS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * wv[j];
+      } else {
+        float bb[8];
+        load8(bvec + c, bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bb[j];
+      }
+      store8(y + row * ldy + c, o);
+    }
+  }
+}
+
 template <typename T, bool RMS>
 int launch_norm(const void* x, long ldx, void* y, long ldy, const float* w, const float* b, const int* in_map,
                 int rows, int C, float eps, hipStream_t s) {
+  if (!in_map && rows <= 256 && C >= 2048 && C <= 3 * 2048) {
+    const T* xp = reinterpret_cast<const T*>(x);
+    T* yp = reinterpret_cast<T*>(y);
+    if (C <= 2048) hipLaunchKernelGGL((norm_row_wg_kernel<T, 1, RMS>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
+    else if (C <= 4096) hipLaunchKernelGGL((norm_row_wg_kernel<T, 2, RMS>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
+    else hipLaunchKernelGGL((norm_row_wg_kernel<T, 3, RMS>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
+    return haff_check_launch();
+  }
   const int nch = (C + 511) / 512;
   dim3 grid((rows + 3) / 4), block(256);
   const T* xp = reinterpret_cast<const T*>(x);

@@ -38,6 +38,8 @@ _PROTOS = {
                                         c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "haff_attention_decode_rows_f32": [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                        c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "haff_decode_attention_rope_rows_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_float, c_void_p, c_void_p],
     "haff_rope_cache_rows": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                              c_int, c_int, c_void_p],
     "haff_relpos_tables": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,

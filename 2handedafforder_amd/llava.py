@@ -183,11 +183,15 @@ class LlamaHip:
             h = ops.rmsnorm(x, L["n1"], l.rms_eps)
             qkv = ops.linear(h, L["wqkv"])
             kc, vc = cache["k"][li], cache["v"][li]
-            ops.rope_cache_rows(qkv, kc, vc, cs, B, 1, nh, nh, hd, pos)
-            q = qkv.view(B, 1, 3, nh, hd)[:, :, 0].permute(0, 2, 1, 3)
-            k = kc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)
-            v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)
-            a = ops.attention_decode_rows(q, k, v, hd ** -0.5, nk)
+            if self.dtype == torch.bfloat16 and hd == 128:
+                # RoPE of q and the new k, the cache append and the attention over the row's pos+1 keys in ONE launch
+                a = ops.decode_attention_rope(qkv, kc, vc, cs, nh, hd, hd ** -0.5, nk)
+            else:
+                ops.rope_cache_rows(qkv, kc, vc, cs, B, 1, nh, nh, hd, pos)
+                q = qkv.view(B, 1, 3, nh, hd)[:, :, 0].permute(0, 2, 1, 3)
+                k = kc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)
+                v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)
+                a = ops.attention_decode_rows(q, k, v, hd ** -0.5, nk)
             x = ops.linear(a.view(B, H), L["wo"], resid=x, out=x)
             h = ops.rmsnorm(x, L["n2"], l.rms_eps)
             g = ops.linear(h, L["wgu"], swiglu=True)

@@ -326,6 +326,21 @@ def attention_decode_rows(q, k, v, scale, nk_rows, out=None):
     return out
 
 
+def decode_attention_rope(qkv, kcache, vcache, cos_sin, H, d, scale, nk_rows):
+    """bf16 decode position with RoPE + cache append fused: qkv [B, 3*H*d] raw -> [B, 1, H*d]; nk_rows int32 [B] = new pos + 1."""
+    lib = load_library()
+    _req(qkv, "qkv")
+    B = qkv.shape[0]
+    assert qkv.dtype == torch.bfloat16 and qkv.stride(1) == 1 and kcache.is_contiguous() and vcache.is_contiguous()
+    assert nk_rows.dtype == torch.int32 and nk_rows.is_cuda and nk_rows.numel() == B and cos_sin.dtype == torch.float32
+    out = torch.empty((B, 1, H * d), dtype=qkv.dtype, device=qkv.device)
+    rc = lib.haff_decode_attention_rope_rows_bf16(qkv.data_ptr(), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
+                                                  cos_sin.data_ptr(), out.data_ptr(), B, H, d, kcache.shape[1], float(scale),
+                                                  nk_rows.data_ptr(), _stream())
+    check(rc, "haff_decode_attention_rope_rows_bf16")
+    return out
+
+
 def argmax_rows(logits):
     lib = load_library()
     _req(logits, "logits")

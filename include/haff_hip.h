@@ -82,6 +82,12 @@ int haff_attention_decode_rows_bf16(const void* q, long q_sb, long q_sh, const v
 int haff_attention_decode_rows_f32(const float* q, long q_sb, long q_sh, const float* k, long k_sb, long k_sh, long k_st,
                                    const float* v, long v_sb, long v_sh, long v_st, float* o, long o_sb, long o_sh, int B,
                                    int H, int Nk, int d, float scale, const int* nk_rows, void* stream);
+/* the same decode position with RoPE and the KV-cache append fused in: replaces haff_rope_cache_rows +
+ * haff_attention_decode_rows_bf16 (transformers LlamaAttention with a KV cache, llava_llama.py:93-102). qkv [B][ld]: raw
+ * q | k | v of the new position (H x d each); caches [B][Tmax][H*d]; cos_sin f32 [Tmax][d]; nk_rows[b] = new position + 1
+ * (DEVICE int32 [B]); out [B][H*d]; d == 128. Results are bit-identical to the two-kernel path. */
+int haff_decode_attention_rope_rows_bf16(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_sin, void* out,
+                                         int B, int H, int d, int Tmax, float scale, const int* nk_rows, void* stream);
 /* decomposed rel-pos terms (image_encoder.py:376-384, from the UNSCALED q, :244-248):
  * relh[bh][q][kh] = q . Rh[qh - kh + S - 1], relw[bh][q][kw] = q . Rw[qw - kw + S - 1]; N = S*S queries.
  * tab_*: [2S-1][d] (f32 for the generic entry, bf16 for the MFMA entry). */

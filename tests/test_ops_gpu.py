@@ -308,6 +308,44 @@ def test_attention(dev, case, dtype):
     _close(got, ref, 2e-2 if dtype == torch.bfloat16 else 2e-5, f"attention {case} {dtype}")
 
 
+@pytest.mark.parametrize("B,H", [(3, 4), (1, 32), (40, 32)])
+def test_decode_attention_rope_fused_is_bit_identical(dev, B, H):
+    """haff_decode_attention_rope_rows_bf16 (RoPE of q and the new k, KV-cache append and the attention in one launch) ==
+    haff_rope_cache_rows followed by haff_attention_decode_rows_bf16, bit for bit: outputs AND the caches, ragged positions
+    (a row at position 0 included), both wave layouts of the decode kernel (B*H <= 1024 and above)."""
+    ops = _ops()
+    d, Tmax = 128, 70
+    g = torch.Generator(device=dev).manual_seed(B * 100 + H)
+    qkv = torch.randn((B, 3 * H * d), generator=g, device=dev).to(torch.bfloat16)
+    kc = torch.randn((B, Tmax, H * d), generator=g, device=dev).to(torch.bfloat16)
+    vc = torch.randn((B, Tmax, H * d), generator=g, device=dev).to(torch.bfloat16)
+    pos = torch.randint(0, Tmax, (B,), generator=g, device=dev).to(torch.int32)
+    pos[0] = 0
+    pos[-1] = Tmax - 1
+    nk = pos + 1
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    ang = torch.arange(Tmax, dtype=torch.float32)[:, None] * inv[None, :]
+    cs = torch.cat([ang.cos(), ang.sin()], 1).contiguous().to(dev)
+    # two-kernel path
+    q1, k1, v1 = qkv.clone(), kc.clone(), vc.clone()
+    ops.rope_cache_rows(q1, k1, v1, cs, B, 1, H, H, d, pos)
+    ref = ops.attention_decode_rows(q1.view(B, 1, 3, H, d)[:, :, 0].permute(0, 2, 1, 3), k1.view(B, Tmax, H, d).permute(0, 2, 1, 3),
+                                    v1.view(B, Tmax, H, d).permute(0, 2, 1, 3), d ** -0.5, nk)
+    # fused
+    k2, v2 = kc.clone(), vc.clone()
+    got = ops.decode_attention_rope(qkv.clone(), k2, v2, cs, H, d, d ** -0.5, nk)
+    assert torch.equal(got, ref)
+    assert torch.equal(k2, k1) and torch.equal(v2, v1)
+    # and the pair agrees with the formula (fp64)
+    qf = q1.view(B, 3, H, d)[:, 0].double()
+    for b in (0, B - 1):
+        n = int(nk[b])
+        kk, vv = k1[b, :n].view(n, H, d).double(), v1[b, :n].view(n, H, d).double()
+        sc = torch.einsum("hd,nhd->hn", qf[b], kk) * d ** -0.5
+        o = torch.einsum("hn,nhd->hd", torch.softmax(sc, -1), vv).reshape(-1)
+        _close(got[b, 0], o, 2e-2, "fused decode attention vs formula")
+
+
 def test_attention_online_softmax_rescale(dev):
     """Force the running max to jump in a late KV tile (cdna guide rule 26)."""
     ops = _ops()
@@ -424,7 +462,7 @@ def test_window_attention_fused(dev, n_win):
     _close(got, old.float(), 2e-2, "fused vs generic window attention")
 
 
-@pytest.mark.parametrize("C", [64, 256, 1024, 1280, 4096, 5120])
+@pytest.mark.parametrize("C", [64, 256, 1024, 1280, 2048, 4096, 5120, 6144])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_norms(dev, C, dtype):
     ops = _ops()
