@@ -60,6 +60,10 @@ struct GemmArgs {
   int nb_inner;
   long sAo, sAi, sWo, sWi, sCo, sCi;
   int nt_out;         // non-temporal output stores (large outputs; chosen by the launcher)
+  // weight-streaming kernel with K split over blockIdx.y: each slice writes its fp32 partial tile to ws[slice][M][N]
+  // (caller-provided workspace) and skinny_reduce_kernel applies the epilogue to the slice sum, in slice order
+  float* ws;
+  int ksplit;
 };
 
 // Epilogue activations of the throughput (bf16) path. GELU matters for the K=1280 SAM MLP GEMM, whose epilogue touches
@@ -617,8 +621,9 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
   const int wave = threadIdx.x >> 6;
   const int fr = lane & 15, fh = lane >> 4;
   const int n0 = blockIdx.x * 16 * NT;
-  const int kq = p.K / KW;                     // K % (32 * KW) == 0: every wave gets whole 32-deep k-steps
-  const int k_lo = wave * kq;
+  const int KS = p.ksplit > 1 ? p.ksplit : 1;
+  const int kq = p.K / (KW * KS);              // K % (32 * KW * KS) == 0: every wave gets whole 32-deep k-steps
+  const int k_lo = (blockIdx.y * KW + wave) * kq;
   const bf16_t* xrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -704,6 +709,18 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
   if (wave >= MT) return;
   const int m = wave * 16 + fr;
   if (m >= p.M) return;
+  if (p.ksplit > 1) {   // K slice of a split launch: raw fp32 partial sums, the epilogue runs in skinny_reduce_kernel
+    float* wp = p.ws + ((long)blockIdx.y * p.M + m) * p.N;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + t * 16 + 4 * fh;
+      if (n + 3 < p.N) store4(wp + n, o[t]);
+      else
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) wp[n + r] = o[t][r];
+    }
+    return;
+  }
   long orow = m;
   if (p.row_map) {
     orow = p.row_map[m];
@@ -766,6 +783,72 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
   }
 }
 
+// Second half of a split-K weight-streaming product: out[m][n] = epi(sum over slices of ws[slice][m][n]), slices added
+// in index order (deterministic), 4 consecutive columns per thread. bias -> act -> +resid, row map, bf16 / f32 output.
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(GemmArgs p) {
+  const int n4 = (p.N + 3) / 4;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)p.M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool whole = n + 3 < p.N && (p.N & 3) == 0;
+  for (int ks = 0; ks < p.ksplit; ++ks) {
+    const float* wp = p.ws + ((long)ks * p.M + m) * p.N + n;
+    if (whole) {
+      float t[4];
+      load4(wp, t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += t[r];
+    } else {
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) v[r] += wp[r];
+    }
+  }
+  long orow = m;
+  if (p.row_map) {
+    orow = p.row_map[m];
+    if (orow < 0) return;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (n + r >= p.N) break;
+    float x = apply_act(v[r] + (p.bias ? p.bias[n + r] : 0.f), p.act);
+    if (p.out_f32) {
+      if (p.resid) x += reinterpret_cast<const float*>(p.resid)[orow * p.ldr + n + r];
+      reinterpret_cast<float*>(p.C)[orow * p.ldc + n + r] = x;
+    } else {
+      if (p.resid) x += bf16_to_f32(reinterpret_cast<const bf16_t*>(p.resid)[orow * p.ldr + n + r]);
+      reinterpret_cast<bf16_t*>(p.C)[orow * p.ldc + n + r] = f32_to_bf16(x);
+    }
+  }
+}
+
+// Split-K launch for the 64-row decode products on narrow weights (N <= 8192: o_proj, down_proj): with 16 weight rows per
+// workgroup every workgroup re-reads the whole activation matrix from L2 (4x the weight bytes at K = 4096, 1.4 MB per
+// workgroup at K = 11008) and the fabric, not HBM, sets the time. 64 (or 32) rows per workgroup and 4 (or 2) K slices keep
+// >= 192 workgroups while each reads only its slice of the activations. Returns false when no such split applies.
+static bool launch_skinny_splitk(GemmArgs& p, hipStream_t s) {
+  if (!p.ws || p.swiglu || p.ln_stats || p.M <= 32 || p.N > 8192) return false;
+  const int tiles = (p.N + 15) / 16;
+  int nt = 0, ks = 0;
+  for (int cand_nt : {4, 2}) {
+    for (int cand_ks : {4, 2}) {
+      if (p.K % (128 * cand_ks)) continue;
+      const int wgs = ((tiles + cand_nt - 1) / cand_nt) * cand_ks;
+      if (wgs >= 192 && wgs <= 640) { nt = cand_nt; ks = cand_ks; break; }
+    }
+    if (nt) break;
+  }
+  if (!nt) return false;
+  p.ksplit = ks;
+  const dim3 b(256);
+  if (nt == 4) hipLaunchKernelGGL((gemm_skinny_kernel<4, 4, false>), dim3((tiles + 3) / 4, ks), b, 0, s, p);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<4, 2, false>), dim3((tiles + 1) / 2, ks), b, 0, s, p);
+  const long n_thr = (long)p.M * ((p.N + 3) / 4);
+  hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), b, 0, s, p);
+  return true;
+}
+
 template <int MT>
 static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
   // Weight rows per workgroup (16 * NT): every workgroup re-reads the activations (from L2), so the bytes a launch moves
@@ -812,7 +895,8 @@ extern "C" int haff_gemm_trace_read(unsigned long long* host, int n_words) {
 static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, void* C,
                           long ldc, const float* bias, const void* resid, long ldr, const int* row_map, int M, int N,
                           int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream,
-                          const float* ln_stats = nullptr, const float* ln_colsum = nullptr) {
+                          const float* ln_stats = nullptr, const float* ln_colsum = nullptr, void* workspace = nullptr,
+                          long workspace_bytes = 0) {
   if (M <= 0 || N <= 0 || K <= 0) return HAFF_ERR_BAD_ARG;
   if ((K & 7) || (lda & 7) || (ldw & 7)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
@@ -823,6 +907,11 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   // weight-streaming kernel for decode-sized M; past 32 rows the 128x128 tile is faster again on very wide outputs
   // (M = 64: gate/up 53 vs 75 us, lm_head 68 vs 84 us; qkv 49 vs 42, o_proj 46 vs 24, down 113 vs 63)
   if (M <= 64 && (K % 128) == 0 && tile_cfg == 0 && !(M > 32 && N >= 16384)) {
+    if (M > 32 && workspace && workspace_bytes >= 4L * 4 * M * N && !a_map) {
+      p.ws = reinterpret_cast<float*>(workspace);
+      if (launch_skinny_splitk(p, s)) return haff_check_launch();
+      p.ws = nullptr;
+    }
     if (M <= 16) launch_skinny<1>(p, N, swiglu, s);
     else if (M <= 32) launch_skinny<2>(p, N, swiglu, s);
     else launch_skinny<4>(p, N, swiglu, s);
@@ -865,6 +954,18 @@ extern "C" int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, 
                               int M, int N, int K, int act, int out_f32, int swiglu, void* stream) {
   return gemm_bf16_impl(A, lda, nullptr, 0, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0,
                         stream);
+}
+
+// haff_gemm_bf16 with a caller-provided workspace (DEVICE memory, 16-B aligned, >= 16 * M * N bytes to be used): lets the
+// weight-streaming kernel split K over workgroups for 33..64-row products on narrow weights (decode-step o_proj / down_proj
+// at batch 64); fp32 partial tiles go through the workspace and are summed in a fixed order. Without a workspace (or when no
+// split applies) this is haff_gemm_bf16.
+extern "C" int haff_gemm_bf16_ws(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                                 const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
+                                 int swiglu, void* workspace, long workspace_bytes, void* stream) {
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return HAFF_ERR_BAD_ARG;
+  return gemm_bf16_impl(A, lda, nullptr, 0, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0,
+                        stream, nullptr, nullptr, workspace, workspace_bytes);
 }
 
 // Same with a gather on the A side: logical row m of the product reads A row a_map[m] (0 <= a_map[m] < a_rows).

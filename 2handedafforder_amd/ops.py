@@ -32,6 +32,19 @@ def _req(t, name):
         raise RuntimeError(f"{name} must live in HBM (cuda tensor); the hot path has no CPU fallback")
 
 
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    """Scratch HBM for kernels that take a caller-provided workspace: one buffer per (device, stream), so launches on
+    different HIP streams never share one."""
+    key = (device.index, _stream())
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WORKSPACES[key] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    return buf
+
+
 def row_stats(x, eps, rms=False):
     """Per-row {mean, rstd} (rms: {0, rsqrt(mean(x^2)+eps)}) as fp32 [rows, 2] — the normalisation itself is applied
     by linear(..., ln_stats=, ln_colsum=)."""
@@ -104,6 +117,13 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
                                        w.stride(0), out.data_ptr(), out.stride(0), _p(bias), _p(resid),
                                        0 if resid is None else resid.stride(0), _p(row_map), M, N, K, act,
                                        1 if out.dtype == torch.float32 else 0, 1 if swiglu else 0, _stream())
+    elif x.dtype == torch.bfloat16 and 32 < M <= 64 and N <= 8192 and not swiglu and not tile_cfg:
+        # decode-sized product on a narrow weight: split-K weight streaming through a per-stream fp32 workspace
+        assert w.dtype == torch.bfloat16
+        ws = _workspace(x.device, 16 * 64 * 8192)
+        rc = lib.haff_gemm_bf16_ws(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                                   _p(bias), _p(resid), 0 if resid is None else resid.stride(0), _p(row_map), M, N, K, act,
+                                   1 if out.dtype == torch.float32 else 0, 0, ws.data_ptr(), ws.numel(), _stream())
     elif x.dtype == torch.bfloat16:
         assert w.dtype == torch.bfloat16
         rc = lib.haff_gemm_bf16_cfg(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),

@@ -38,6 +38,13 @@ int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, lo
 int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                        const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
                        int swiglu, int tile_cfg, void* stream);
+/* haff_gemm_bf16 with a caller-provided DEVICE workspace (16-B aligned; 16 * M * N bytes are used when it applies): for
+ * 33..64-row products on weights of <= 8192 rows (the decode-step o_proj / down_proj of llava_llama.py:93-102 at batch 64)
+ * the weight-streaming kernel splits K over workgroups, fp32 partial tiles go through the workspace and are summed in a
+ * fixed order (deterministic). NULL workspace, or a shape with no useful split: identical to haff_gemm_bf16. */
+int haff_gemm_bf16_ws(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                      const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
+                      int swiglu, void* workspace, long workspace_bytes, void* stream);
 /* haff_gemm_bf16 with a gather on the A side: logical row m reads A row a_map[m] (0 <= a_map[m] < a_rows). Runs the
  * window-unpartition projection over real tokens only (image_encoder.py:186-188,291-318 drop the padded rows right
  * after proj). */

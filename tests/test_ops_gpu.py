@@ -89,7 +89,7 @@ def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
 
 
 @pytest.mark.parametrize("M", [1, 3, 8, 16, 17, 31, 32, 33, 50, 64])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (1003, 256), (320, 11008), (64, 128), (998, 384)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 11008), (5120, 13824), (1003, 256), (320, 11008), (64, 128), (998, 384)])
 def test_gemm_skinny(dev, M, N, K):
     """M <= 64 takes the weight-streaming kernel (one workgroup per 16 weight rows, K split over 4 waves, 1 / 2 / 4
     activation tiles of 16 rows): every epilogue feature, ragged M and N (N = 998: the packed 8-byte store falls back
