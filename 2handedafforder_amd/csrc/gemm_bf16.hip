@@ -99,6 +99,29 @@ __device__ __forceinline__ float gemm_act(float x) {
   }
 }
 
+// The same polynomial on two values at once: v_pk_fma_f32 / v_pk_mul_f32 (the epilogue has no MFMA beside it, where the
+// packed forms are an anti-lever; here they halve the instruction count of the 13-op chain). -DHAFF_GEMM_GELU_SCALAR: the
+// scalar form, for A/B.
+typedef float haff_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ haff_f2 gelu_pair(haff_f2 x) {
+  const haff_f2 lo = {-3.0f, -3.0f}, hi = {3.0f, 3.0f};
+  haff_f2 z = x * 0.70710678118654752440f;
+  z = __builtin_elementwise_min(__builtin_elementwise_max(z, lo), hi);
+  const haff_f2 u = z * z;
+  haff_f2 pz = {4.9182759198629356e-08f, 4.9182759198629356e-08f};
+  auto step = [&](float c) { const haff_f2 cc = {c, c}; pz = __builtin_elementwise_fma(pz, u, cc); };
+  step(-2.2677306787954876e-06f);
+  step(4.6147291868692264e-05f);
+  step(-0.0005535572418011725f);
+  step(0.004437862429767847f);
+  step(-0.02564961276948452f);
+  step(0.11186250299215317f);
+  step(-0.3758186101913452f);
+  step(1.1283628940582275f);
+  const haff_f2 hx = x * 0.5f;
+  return __builtin_elementwise_fma(hx, z * pz, hx);
+}
+
 #ifdef HAFF_GEMM_TRACE  // phase timestamps (100 MHz wall clock) of each workgroup's first tile, for tools/gemm_trace.py
 __device__ unsigned long long haff_gemm_trace_buf[8192 * 8];
 #define HAFF_TRACE(i) do { if (tid == 0 && blockIdx.x < 8192 && blockIdx.y == 0) haff_gemm_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
@@ -509,8 +532,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
           float v[4];
+#ifndef HAFF_GEMM_GELU_SCALAR
+          if constexpr (ACT == HAFF_ACT_GELU) {
+            const haff_f2 a = gelu_pair(haff_f2{acc[ni][mi][0] + bias_r[ni][0], acc[ni][mi][1] + bias_r[ni][1]});
+            const haff_f2 b = gelu_pair(haff_f2{acc[ni][mi][2] + bias_r[ni][2], acc[ni][mi][3] + bias_r[ni][3]});
+            v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+          } else
+#endif
+          {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gemm_act<ACT>(acc[ni][mi][r] + bias_r[ni][r]);
+            for (int r = 0; r < 4; ++r) v[r] = gemm_act<ACT>(acc[ni][mi][r] + bias_r[ni][r]);
+          }
           store4(row + ni * 16, v);
         }
       };

@@ -66,3 +66,67 @@ def test_full_size_7b_properties(dev):
     one = run(1, slice(1, 2))
     for a, b in ((one[1][0], l[1]), (one[2][0], r[1])):
         assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item() and _iou(a > 0, b > 0) >= 0.97
+
+
+def test_full_size_7b_batch64_throughput_config(dev):
+    """BASELINE.json configs[2] at its REAL batch: 64 x 1024^2 frames, SAM blocks of 32 frames, 32-token prompts, 8 generated
+    tokens (the shapes bench.py times: 131 072-row SAM GEMMs, 18 624-row Llama GEMMs, M = 64 decode GEMMs, 2 048 (batch, head)
+    decode attention). Size-independent properties: bitwise determinism, and the frames shared with a batch-2 run agree
+    within bf16 accumulation-order noise (different GEMM launch shapes)."""
+    import haff  # noqa: F401
+    from bench import make_inputs
+    from haff import checkpoint, config as hcfg
+    from haff.lisa import LisaMI355
+    cfg = hcfg.haff_7b()
+    sd = checkpoint.synthetic_state_dict(cfg, 1234, dev)
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev, sam_chunk=32)
+    del sd
+    B, S = 64, cfg.sam.img_size
+    frames, clip, ids, forced = make_inputs(cfg, B, 32, 8, dev)
+    sizes = [(S, S)] * B
+
+    def run(n):
+        with torch.no_grad():
+            o, l, r, t = model.evaluate(None, None, ids[:n], sizes[:n], sizes[:n], max_new_tokens=8, forced_answer=forced[:n],
+                                        frames_u8=frames[:n])
+        return o, torch.stack(l + r), torch.stack(t)
+    a = run(B)
+    b = run(B)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), "batch-64 step is not deterministic"
+    assert a[1].shape == (2 * B, 1, S, S) and bool(torch.isfinite(a[1]).all())
+    assert bool(((a[2].sum(-1) - 1.0).abs() < 1e-3).all())
+    small = run(2)
+    for i in range(2):
+        for side in (0, B):
+            big_m, small_m = a[1][side + i], small[1][(0 if side == 0 else 2) + i]
+            assert (big_m - small_m).abs().max().item() <= 3e-2 * small_m.abs().max().item()
+            assert _iou(big_m > 0, small_m > 0) >= 0.97
+
+
+def test_full_size_13b_batch8_config(dev):
+    """BASELINE.json configs[4]: the 13B geometry (H = 5120, 40 heads, ffn 13 824, 40 layers) at 8 frames per GPU end to end:
+    shapes, finiteness, probability rows, bitwise determinism, hipGraph decode == eager decode."""
+    import haff  # noqa: F401
+    from bench import make_inputs
+    from haff import checkpoint, config as hcfg
+    from haff.lisa import LisaMI355
+    cfg = hcfg.haff_13b()
+    sd = checkpoint.synthetic_state_dict(cfg, 1234, dev)
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev, sam_chunk=8)
+    del sd
+    B, S = 8, cfg.sam.img_size
+    frames, clip, ids, forced = make_inputs(cfg, B, 32, 8, dev)
+    sizes = [(S, S)] * B
+
+    def run():
+        with torch.no_grad():
+            o, l, r, t = model.evaluate(None, None, ids, sizes, sizes, max_new_tokens=8, forced_answer=forced, frames_u8=frames)
+        return o, torch.stack(l + r), torch.stack(t)
+    a = run()
+    assert a[0].shape == (B, ids.shape[1] + 8) and a[1].shape == (2 * B, 1, S, S)
+    assert bool(torch.isfinite(a[1]).all()) and bool(((a[2].sum(-1) - 1.0).abs() < 1e-3).all())
+    b = run()
+    assert all(torch.equal(x, y) for x, y in zip(a, b)), "13B step is not deterministic"
+    model.decode_graphs = False
+    c = run()
+    assert all(torch.equal(x, y) for x, y in zip(a, c)), "hipGraph decode differs from eager decode (13B)"
