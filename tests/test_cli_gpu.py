@@ -157,4 +157,5 @@ def test_inference_cli_batches_a_directory(dev, tmp_path, monkeypatch):
                         files[(th, i, side)] = open(p, "rb").read()
         outs[bs] = files
     assert len(outs[1]) >= 15 and set(outs[1]) == set(outs[3])
-    assert all(outs[1][k] == outs[3][k] for k in outs[1])
+    diff = [k for k in outs[1] if outs[1][k] != outs[3][k]]
+    assert not diff, f"batched CLI wrote different files for {diff}"
