@@ -949,6 +949,32 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
     else launch_skinny<4>(p, N, swiglu, s);
     return haff_check_launch();
   }
+  // Few output tiles, long K (prefill-sized o_proj / down_proj, the CLIP tower at one frame): K is split over
+  // blockIdx.y so that the 128x128 kernel's 512 resident-workgroup slots are used (96 tiles of 288x4096x4096 ran one
+  // 64-step K loop each on 96 CUs: 62 us; 4 slices: 384 workgroups x 16 steps). Each slice is a "batch" of the batched
+  // launch — operands offset by slice * K/ks along K, fp32 partial tile into ws[slice][M][N] — and skinny_reduce_kernel
+  // adds the slices in index order and applies the epilogue: deterministic.
+  if (tile_cfg == 0 && workspace && !ln_stats && !swiglu && M > 64 && (K % BK) == 0) {
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const int ksteps = K / BK;
+    int ks = 0;
+    if (t128 <= 256 && ksteps >= 32)   // (K = 1024: the second launch costs more than the shorter loop saves, 17.5 -> 19.8 us)
+      for (int c : {16, 8, 4, 2})
+        if (ksteps % c == 0 && ksteps / c >= 4 && t128 * c <= 512 && 4L * c * M * N <= workspace_bytes) { ks = c; break; }
+    if (ks) {
+      GemmArgs q = p;
+      q.C = workspace; q.ldc = N; q.bias = nullptr; q.resid = nullptr; q.ldr = 0; q.row_map = nullptr;
+      q.K = K / ks; q.act = 0; q.out_f32 = 1;
+      q.nb_inner = ks; q.sAo = 0; q.sWo = 0; q.sCo = 0; q.sAi = q.K; q.sWi = q.K; q.sCi = (long)M * N;
+      const int rc = launch_gemm<128, 128, 2, 2>(q, s, ks);
+      if (rc) return rc;
+      p.ws = reinterpret_cast<float*>(workspace);
+      p.ksplit = ks;
+      const long n_thr = (long)M * ((N + 3) / 4);
+      hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, p);
+      return haff_check_launch();
+    }
+  }
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
   const bool big_ok = (K % BK == 0) && ((long)(a_map ? a_rows : M) * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
   if (tile_cfg == 3 && big_ok) return launch_gemm<256, 256, 2, 2>(p, s);

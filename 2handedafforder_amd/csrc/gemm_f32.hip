@@ -168,6 +168,74 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
   }
 }
 
+// Few rows (M <= 16: the [SEG] MLP, the two-way decoders' token-side projections and MLPs, hypernetwork / IoU / taxonomy
+// heads at a handful of prompts): the product is a stream over W, and a 128x128 tile would run it on N/128 workgroups with
+// one exposed memory round trip per 16-deep K step (1 x 4096 x 4096: 314 us, 4 x 256 x 2048: 160 us, the 256-wide token
+// projections 24 us each). Here a workgroup owns NC output columns, its 4 waves take the 256-float K chunks round robin
+// (lane l: floats 4l..4l+3 of a chunk — 1 KiB coalesced per row), every lane keeps MR x NC fp32 partial sums (fmaf chain),
+// and the partials meet in a fixed order: lanes by xor-butterfly, then waves 0..3. No tile, no MFMA: HBM/L2-latency work.
+template <int MR, int NC>
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF32Args p) {
+  __shared__ float red[4][MR][NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * NC;
+  const float* wrow[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) wrow[c] = p.W + (long)min(n0 + c, p.N - 1) * p.ldw;
+  const float* arow[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) arow[m] = p.A + (long)min(m, p.M - 1) * p.lda;
+  float acc[MR][NC];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[m][c] = 0.f;
+  for (int k = wave * 256 + lane * 4; k < p.K; k += 1024) {
+    float4 w[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) w[c] = *reinterpret_cast<const float4*>(wrow[c] + k);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float4 a = *reinterpret_cast<const float4*>(arow[m] + k);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        acc[m][c] = fmaf(a.w, w[c].w, fmaf(a.z, w[c].z, fmaf(a.y, w[c].y, fmaf(a.x, w[c].x, acc[m][c]))));
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float v = acc[m][c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wave][m][c] = v;
+    }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= MR * NC) return;
+  const int m = t / NC, c = t - m * NC, n = n0 + c;
+  if (m >= p.M || n >= p.N) return;
+  long orow = m;
+  if (p.row_map) {
+    orow = p.row_map[m];
+    if (orow < 0) return;
+  }
+  float x = ((red[0][m][c] + red[1][m][c]) + red[2][m][c]) + red[3][m][c];
+  if (p.bias) x += p.bias[n];
+  x = apply_act(x, p.act);
+  if (p.resid) x += p.resid[orow * p.ldr + n];
+  p.C[orow * p.ldc + n] = x;
+}
+
+template <int MR>
+static void launch_f32_skinny(const GemmF32Args& p, hipStream_t s) {
+  // enough workgroups to cover the CUs on narrow outputs, 4 columns each once there are plenty (fewer A re-reads from L2)
+  if (p.N >= 2048) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MR, 4>), dim3((p.N + 3) / 4), dim3(256), 0, s, p);
+  else if (p.N >= 512) hipLaunchKernelGGL((gemm_f32_skinny_kernel<MR, 2>), dim3((p.N + 1) / 2), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f32_skinny_kernel<MR, 1>), dim3(p.N), dim3(256), 0, s, p);
+}
+
 }  // namespace
 
 extern "C" int haff_gemm_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc,
@@ -176,8 +244,18 @@ extern "C" int haff_gemm_f32(const float* A, long lda, const float* W, long ldw,
   if (M <= 0 || N <= 0 || K <= 0 || (K & 3) || (lda & 3) || (ldw & 3)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || resid)) return HAFF_ERR_BAD_ARG;
   GemmF32Args p{A, lda, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, swiglu, 0, 0, 0, 0, 0, 0, 0};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool al16 = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+  // every workgroup re-reads all M rows of A (L2): past 8 rows only while the weight is small enough not to care
+  if (!swiglu && al16 && (M <= 8 || (M <= 16 && (long)N * K <= (1L << 21)))) {
+    if (M <= 1) launch_f32_skinny<1>(p, s);
+    else if (M <= 4) launch_f32_skinny<4>(p, s);
+    else if (M <= 8) launch_f32_skinny<8>(p, s);
+    else launch_f32_skinny<16>(p, s);
+    return haff_check_launch();
+  }
   const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, s, p);
   return haff_check_launch();
 }
 

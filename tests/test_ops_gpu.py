@@ -57,6 +57,39 @@ def test_gemm_bf16_epilogues(dev, M, N, K, act):
     _close(got32, ACT_REF[act](x.float() @ w.float().T + bias), 2e-3, "gemm_bf16 f32-out")
 
 
+@pytest.mark.parametrize("M,N,K", [(288, 4096, 4096), (288, 4096, 11008), (257, 1024, 4096), (257, 3072, 1024), (257, 1003, 1024),
+                                   (100, 520, 2048), (1000, 256, 1280)])
+def test_gemm_bf16_split_k_tiles(dev, M, N, K):
+    """Few-tile products (one-frame prefill o_proj / down_proj, the CLIP tower): ops.linear hands the library a workspace and
+    the 128x128 kernel runs K slices as a batched launch, summed in slice order by the reduce kernel with the whole epilogue
+    (bias, activation, residual, row map, fp32 / bf16 output, ragged N). Same tolerance as the unsplit kernel; repeatable
+    bit for bit; identical to the unsplit kernel's result up to fp32 summation order."""
+    ops = _ops()
+    x = _rand((M, K), dev, torch.bfloat16, 21)
+    w = _rand((N, K), dev, torch.bfloat16, 22, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 23)
+    resid = _rand((M, N), dev, torch.bfloat16, 24)
+    y = x.float() @ w.float().T + bias
+    got = ops.linear(x, w, bias=bias, act=2, resid=resid)
+    _close(got, ACT_REF[2](y) + resid.float(), 1.2e-2, "split-K quick-gelu+resid")
+    assert torch.equal(got, ops.linear(x, w, bias=bias, act=2, resid=resid))
+    got32 = ops.linear(x, w, bias=bias, out_dtype=torch.float32)
+    _close(got32, y, 2e-3, "split-K f32 out")
+    unsplit = ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=1)
+    _close(got32, unsplit.float(), 1e-4, "split vs unsplit")
+    perm = torch.randperm(M, device=dev).to(torch.int32)
+    perm[::7] = -1
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+    ops.linear(x, w, bias=bias, resid=resid, row_map=perm, out=out)
+    ref = torch.zeros((M, N), dtype=torch.float32, device=dev)
+    keep = perm >= 0
+    ref[perm[keep].long()] = y[keep] + resid.float()[perm[keep].long()]
+    _close(out, ref, 1.2e-2, "split-K row_map")
+    xs = _rand((M, K + 64), dev, torch.bfloat16, 25)[:, 32:32 + K]     # strided view, 64-B aligned rows
+    if (K + 64) % 8 == 0:
+        _close(ops.linear(xs, w, out_dtype=torch.float32), xs.float() @ w.float().T, 2e-3, "split-K strided A")
+
+
 @pytest.mark.parametrize("tile_cfg", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 1003, 256), (300, 520, 64), (1111, 256, 1280)])
 def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
@@ -217,6 +250,32 @@ def test_gemm_f32(dev, M, N, K):
     got = ops.linear(x, w, bias=bias, act=1, resid=resid)
     ref = F.gelu(x.double() @ w.double().T + bias.double()) + resid.double()
     _close(got, ref, 2e-5, "gemm_f32")
+
+
+@pytest.mark.parametrize("M", [1, 3, 7, 8, 12, 16])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (256, 4096), (256, 256), (2048, 256), (256, 2048), (1003, 260), (32, 256), (5, 8)])
+def test_gemm_f32_few_rows(dev, M, N, K):
+    """The weight-streaming fp32 kernel behind haff_gemm_f32 for M <= 16 (decoder tail at a handful of prompts): every
+    epilogue feature, ragged N, K not a multiple of the 256-float chunk, scattered / dropped output rows; repeatable."""
+    ops = _ops()
+    x = _rand((M, K), dev, torch.float32, 31)
+    w = _rand((N, K), dev, torch.float32, 32, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 33)
+    resid = _rand((M + 3, N), dev, torch.float32, 34)
+    y = x.double() @ w.double().T + bias.double()
+    got = ops.linear(x, w, bias=bias, act=1, resid=resid[:M])
+    _close(got, F.gelu(y) + resid[:M].double(), 2e-5, "gemm_f32 few rows")
+    assert torch.equal(got, ops.linear(x, w, bias=bias, act=1, resid=resid[:M]))
+    _close(ops.linear(x, w, act=3), F.relu(x.double() @ w.double().T), 2e-5, "gemm_f32 few rows relu")
+    perm = torch.randperm(M + 3, device=dev)[:M].to(torch.int32)
+    if M > 2:
+        perm[1] = -1
+    out = torch.full((M + 3, N), 7.0, device=dev)
+    ops.linear(x, w, bias=bias, resid=resid, row_map=perm, out=out)
+    ref = torch.full((M + 3, N), 7.0, device=dev, dtype=torch.float64)
+    keep = perm >= 0
+    ref[perm[keep].long()] = y[keep] + resid.double()[perm[keep].long()]
+    _close(out, ref, 2e-5, "gemm_f32 few rows row_map")
 
 
 def test_gemm_f32_rowmap_views_and_tails(dev):
