@@ -516,10 +516,13 @@ __device__ __forceinline__ void rope8(float (&x)[8], const float* cs_row, int c)
   }
 }
 
-template <bool SPLIT, bool ROPE = false>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
-  __shared__ float s_ml[4][2];
-  __shared__ float s_o[4][DEC_D];
+// NW: waves per workgroup. SPLIT with 16 waves (few (batch, head) pairs: batch 1..4): each wave takes ONE trip of 16 keys
+// per 256 — a 300-key cache is one or two round trips per wave instead of five (10.7 -> ~6 us per layer at batch 1).
+template <bool SPLIT, bool ROPE = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_decode_kernel(AttnArgs p) {
+  static_assert(NW == 4 || SPLIT, "the one-wave-per-head form packs 4 heads per workgroup");
+  __shared__ float s_ml[NW][2];
+  __shared__ float s_o[NW][DEC_D];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int bh = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   float m_run = -1e30f, l_run = 0.f;
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int n_it = (Nk + 3) / 4;
-  for (int it0 = SPLIT ? wave * DEC_UNROLL : 0; it0 < n_it; it0 += (SPLIT ? 4 : 1) * DEC_UNROLL) {
+  for (int it0 = SPLIT ? wave * DEC_UNROLL : 0; it0 < n_it; it0 += (SPLIT ? NW : 1) * DEC_UNROLL) {
     uint4 kr[DEC_UNROLL], vr[DEC_UNROLL];
 #pragma unroll
     for (int u = 0; u < DEC_UNROLL; ++u) {
@@ -623,10 +626,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   }
   __syncthreads();
   if (wave == 0 && g == 0) {
-    const float M = fmaxf(fmaxf(s_ml[0][0], s_ml[1][0]), fmaxf(s_ml[2][0], s_ml[3][0]));
+    float M = s_ml[0][0];
+#pragma unroll
+    for (int w4 = 1; w4 < NW; ++w4) M = fmaxf(M, s_ml[w4][0]);
     float L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w4 = 0; w4 < 4; ++w4) {
+    for (int w4 = 0; w4 < NW; ++w4) {
       const float f = __builtin_amdgcn_exp2f(s_ml[w4][0] - M);   // a wave that saw no key carries max -1e30, sum 0
       L += s_ml[w4][1] * f;
 #pragma unroll
@@ -662,7 +667,8 @@ static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-    if (B * H <= 1024) hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * H), dim3(256), 0, s, p);
+    if (B * H <= 128) hipLaunchKernelGGL((attn_decode_kernel<true, false, 16>), dim3(B * H), dim3(1024), 0, s, p);
+    else if (B * H <= 1024) hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * H), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_decode_kernel<false>, dim3((B * H + 3) / 4), dim3(256), 0, s, p);
     return haff_check_launch();
   }
@@ -737,7 +743,8 @@ extern "C" int haff_decode_attention_rope_rows_bf16(const void* qkv, long ld, vo
              ld, d, hd, (long)Tmax * hd, d, hd, (long)Tmax * hd, d, hd, hd, d, hd,
              B, H, 1, Tmax, d, scale, 0, nullptr, nullptr, 0, nk_rows, q + hd, q + 2 * hd, cos_sin};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (B * H <= 1024) hipLaunchKernelGGL((attn_decode_kernel<true, true>), dim3(B * H), dim3(256), 0, s, p);
+  if (B * H <= 128) hipLaunchKernelGGL((attn_decode_kernel<true, true, 16>), dim3(B * H), dim3(1024), 0, s, p);
+  else if (B * H <= 1024) hipLaunchKernelGGL((attn_decode_kernel<true, true>), dim3(B * H), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((attn_decode_kernel<false, true>), dim3((B * H + 3) / 4), dim3(256), 0, s, p);
   return haff_check_launch();
 }

@@ -135,15 +135,24 @@ __global__ void rope_cache_kernel(T* qkv, long ld, T* kcache, T* vcache, const f
   }
 }
 
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, long ld, long* out, int V) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
+// First maximum of each row (torch.argmax tie rule). One 1024-thread workgroup per row, 8 independent loads per thread
+// per trip: a 32 003-entry logit row is 4 trips (the 256-thread, one-load-per-trip form spent 38 us per decode step on
+// 125 dependent L2 round trips).
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* x, long ld, long* out, int V) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
   const float* r = x + (long)blockIdx.x * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < V; i += 256) {
-    const float v = r[i];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  for (int i0 = threadIdx.x; i0 < V; i0 += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (i0 + j * 1024 < V) ? r[i0 + j * 1024] : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j * 1024;
+      if (i < V && (v[j] > best || (v[j] == best && i < bi))) { best = v[j]; bi = i; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -154,9 +163,42 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, long l
   if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
     out[blockIdx.x] = bi;
+  }
+}
+
+// Greedy-decode bookkeeping of one generated token per row, entirely on the device so that it can sit inside the decode
+// hipGraph (LISA.py:443-450's generate loop: the host only looks at `finished` between steps). Block b, step s = steps[b]:
+//   token = forced ? forced[b][s] : newest argmax; a finished row emits pad; out_ids[b][lens[b] + s] = token;
+//   finished[b] |= token == eos; tok[b] = token (next embedding lookup); pos[b] = t_rows[b] + s, nk[b] = pos + 1 (the
+//   position the token will be decoded at); for s >= 1 the hidden state of the previous token (h1 row b, row_bytes
+//   bytes) is filed at hidden[b][t_rows[b] + s - 1]; steps[b] = s + 1.
+struct DecodeBookArgs {
+  const long* nxt_raw; const long* forced; long forced_ld; const int* use_forced;
+  int* steps; unsigned char* finished; long* out_ids; long out_ld; const long* lens; const int* t_rows;
+  long* tok; int* pos; int* nk; const char* h1; char* hidden; long hid_sb, row_bytes; long pad, eos;
+};
+__global__ __launch_bounds__(256) void decode_book_kernel(DecodeBookArgs p) {
+  const int b = blockIdx.x;
+  const int s = p.steps[b];
+  if (s >= 1 && p.h1) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.h1 + (long)b * p.row_bytes);
+    uint4* dst = reinterpret_cast<uint4*>(p.hidden + (long)b * p.hid_sb + (long)(p.t_rows[b] + s - 1) * p.row_bytes);
+    for (int i = threadIdx.x; i < (int)(p.row_bytes >> 4); i += 256) dst[i] = src[i];
+  }
+  __syncthreads();   // every thread has read steps[b] before thread 0 advances it
+  if (threadIdx.x == 0) {
+    long t = (*p.use_forced) ? p.forced[(long)b * p.forced_ld + s] : p.nxt_raw[b];
+    const bool fin = p.finished[b] != 0;
+    if (fin) t = p.pad;
+    p.out_ids[(long)b * p.out_ld + p.lens[b] + s] = t;
+    p.finished[b] = (fin || t == p.eos) ? 1 : 0;
+    p.tok[b] = t;
+    p.pos[b] = p.t_rows[b] + s;
+    p.nk[b] = p.t_rows[b] + s + 1;
+    p.steps[b] = s + 1;
   }
 }
 
@@ -272,7 +314,25 @@ extern "C" int haff_rope_cache_rows(void* qkv, long ld, void* kcache, void* vcac
 
 extern "C" int haff_argmax_rows(const float* x, long ld, long* out, int rows, int V, void* stream) {
   if (rows <= 0 || V <= 0) return HAFF_ERR_BAD_ARG;
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, HAFF_STREAM(stream), x, ld, out, V);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(1024), 0, HAFF_STREAM(stream), x, ld, out, V);
+  return haff_check_launch();
+}
+
+// One generated token of the greedy decode loop (see decode_book_kernel). All pointers are device memory: nxt_raw int64 [B]
+// (newest argmax), forced int64 [B][forced_ld] used when *use_forced != 0, steps int32 [B], finished uint8 [B], out_ids int64
+// [B][out_ld], lens int64 [B], t_rows int32 [B], tok int64 [B], pos / nk int32 [B], h1 [B][row_bytes] (may be null),
+// hidden [B][hid_sb bytes per row] with row_bytes per position (row_bytes % 16 == 0, 16-B aligned bases).
+extern "C" int haff_decode_book(const long* nxt_raw, const long* forced, long forced_ld, const int* use_forced, int* steps,
+                                unsigned char* finished, long* out_ids, long out_ld, const long* lens, const int* t_rows,
+                                long* tok, int* pos, int* nk, const void* h1, void* hidden, long hid_sb, long row_bytes,
+                                long pad, long eos, int B, void* stream) {
+  if (B <= 0 || !nxt_raw || !use_forced || !steps || !finished || !out_ids || !lens || !t_rows || !tok || !pos || !nk)
+    return HAFF_ERR_BAD_ARG;
+  if (h1 && ((row_bytes & 15) || (hid_sb & 15) || (reinterpret_cast<uintptr_t>(h1) & 15) || (reinterpret_cast<uintptr_t>(hidden) & 15)))
+    return HAFF_ERR_BAD_ARG;
+  DecodeBookArgs p{nxt_raw, forced, forced_ld, use_forced, steps, finished, out_ids, out_ld, lens, t_rows, tok, pos, nk,
+                   reinterpret_cast<const char*>(h1), reinterpret_cast<char*>(hidden), hid_sb, row_bytes, pad, eos};
+  hipLaunchKernelGGL(decode_book_kernel, dim3(B), dim3(256), 0, HAFF_STREAM(stream), p);
   return haff_check_launch();
 }
 

@@ -65,6 +65,8 @@ _PROTOS = {
     "haff_rope_cache": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                         c_int, c_int, c_void_p],
     "haff_argmax_rows": [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p],
+    "haff_decode_book": [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p],
     "haff_add_bcast": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
     "haff_softmax_rows": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "haff_upscale_mask": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

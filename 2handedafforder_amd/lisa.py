@@ -36,6 +36,7 @@ class LisaMI355:
         # (+4-5 % frames/s); False serialises everything on the caller's stream (per-kernel measurements). Results are
         # bit-identical either way (tests/test_fullsize_gpu.py; the history of that check: DESIGN.md section 10a).
         self.overlap_streams = True
+        self.sam_beside_decode = None   # None: by batch size (<= 4 frames: encoder enqueued behind the prefill); True / False force
         # KV-cached decode steps are launch-bound at small batch (32 layers x 9 launches per token): each step is
         # captured once per (batch, position) into a hipGraph and replayed. The KV cache is persistent per
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
@@ -71,7 +72,7 @@ class LisaMI355:
 
     # ---- a6-a8: splice + greedy generate -----------------------------------------------------------------
     @torch.no_grad()
-    def generate(self, images_clip, input_ids, max_new_tokens=32, forced_answer=None, attention_mask=None):
+    def generate(self, images_clip, input_ids, max_new_tokens=32, forced_answer=None, attention_mask=None, after_prefill=None):
         """Greedy KV-cached decode (LISA.py:443-450). Rows may have different prompt lengths: input_ids is right-padded
         (utils/dataset.py:90-93) and attention_mask [B, L] (bool, True on real tokens; None = every row is full length)
         marks the real prefix of each row, as collate_fn builds it (:144-150). Row b's generated tokens are appended right
@@ -98,34 +99,37 @@ class LisaMI355:
         T = L + n_img - 1
         t_rows = lens + (n_img - 1)                      # real positions per row after the splice
         cache = self._persistent_cache(B, T + max_new_tokens)
+        st = cache["book"]
         prefill = self.llm.forward(x, cache)             # causal: a row's real positions never see its padding
-        H = prefill.shape[2]
-        hidden = torch.zeros((B, T + max(max_new_tokens - 1, 0), H), dtype=prefill.dtype, device=self.device)
+        if after_prefill is not None:                    # work the caller wants enqueued (elsewhere) behind the prefill
+            after_prefill()
+        hidden, out_ids = st["hidden"], st["out_ids"]    # persistent [B, tmax, H] / [B, tmax]: the decode graph writes into them
         hidden[:, :T] = prefill
-        rows = torch.arange(B, device=self.device)
-        cache["pos"].copy_(t_rows.to(torch.int32))
-        cache["nk"].copy_((t_rows + 1).to(torch.int32))
-        out_ids = torch.full((B, L + max_new_tokens), cfg.pad_token_id, dtype=input_ids.dtype, device=self.device)
+        hidden[:, T:].zero_()
+        out_ids.fill_(cfg.pad_token_id)
         out_ids[:, :L] = torch.where(torch.arange(L, device=self.device)[None, :] < lens[:, None], input_ids,
                                      torch.full_like(input_ids, cfg.pad_token_id))
-        finished = torch.zeros(B, dtype=torch.bool, device=self.device)
+        if max_new_tokens <= 0:
+            return out_ids[:, :L].clone(), hidden[:, :T - 1].clone()
+        st["t_rows"].copy_(t_rows)
+        st["lens"].copy_(lens)
+        st["steps"].zero_()
+        st["finished"].zero_()
         if forced_answer is not None:
-            forced_answer = forced_answer.to(self.device)
+            assert forced_answer.shape[0] == B and forced_answer.shape[1] >= max_new_tokens
+            st["forced"][:, :max_new_tokens] = forced_answer[:, :max_new_tokens].to(self.device)
+        st["use_forced"].fill_(0 if forced_answer is None else 1)
+        rows = torch.arange(B, device=self.device)
         logits = self.llm.next_token_logits(prefill[rows, t_rows - 1].contiguous())
-        nxt = ops.argmax_rows(logits)
-        n_done = 0
-        for step in range(max_new_tokens):
-            if forced_answer is not None:
-                nxt = forced_answer[:, step].clone()
-            nxt = torch.where(finished, torch.full_like(nxt, cfg.pad_token_id), nxt)
-            out_ids[rows, lens + step] = nxt
-            n_done = step + 1
-            finished = finished | (nxt == cfg.eos_token_id)
-            if step == max_new_tokens - 1 or bool(finished.all()):
-                break
-            h1, nxt = self._decode_step(nxt, cache)
-            hidden[rows, t_rows + step] = h1[:, 0]
-        return out_ids[:, :L + n_done], hidden[:, :T + n_done - 1]
+        # token 0 (from the prefill logits), then one decode step per further token: embedding of the token just written ->
+        # layers at each row's own position -> logits -> argmax -> bookkeeping of the next token, all device-side; the host
+        # only reads the rows' finished flags between steps (generate()'s stopping rule)
+        ops.decode_book(ops.argmax_rows(logits), st, None, cfg.pad_token_id, cfg.eos_token_id)
+        n_done = 1
+        while n_done < max_new_tokens and not bool(st["finished"].all()):
+            self._decode_book_step(cache)
+            n_done += 1
+        return out_ids[:, :L + n_done].clone(), hidden[:, :T + n_done - 1].clone()
 
     def _persistent_cache(self, B, tmax):
         key = (B, tmax)
@@ -134,10 +138,49 @@ class LisaMI355:
             if len(self._caches) >= 4:   # a few shapes at most stay resident (7B, B=64, 299 positions: 10 GB)
                 old = next(iter(self._caches))
                 del self._caches[old]
-                self._graphs = {k: v for k, v in self._graphs.items() if k[:2] != old}
+                self._graphs = {k: v for k, v in self._graphs.items() if k[-2:] != old}
             c = self._caches[key] = self.llm.new_cache(B, tmax)
+            dev, i64, i32 = self.device, torch.int64, torch.int32
+            # generate()'s per-row state, persistent so that the decode hipGraph can address it (ops.decode_book)
+            c["book"] = {"forced": torch.zeros((B, tmax), dtype=i64, device=dev), "use_forced": torch.zeros((1,), dtype=i32, device=dev),
+                         "steps": torch.zeros((B,), dtype=i32, device=dev), "finished": torch.zeros((B,), dtype=torch.uint8, device=dev),
+                         "out_ids": torch.zeros((B, tmax), dtype=i64, device=dev), "lens": torch.zeros((B,), dtype=i64, device=dev),
+                         "t_rows": torch.zeros((B,), dtype=i32, device=dev), "tok": torch.zeros((B,), dtype=i64, device=dev),
+                         "pos": c["pos"], "nk": c["nk"],
+                         "hidden": torch.zeros((B, tmax, self.cfg.llm.hidden), dtype=self.dtype, device=dev)}
         c["len"] = 0
         return c
+
+    def _decode_book_eager(self, cache):
+        st = cache["book"]
+        B = st["tok"].shape[0]
+        x1 = self.llm.embed.index_select(0, st["tok"]).view(B, 1, -1)
+        h1 = self.llm.decode_rows(x1, cache)
+        logits = self.llm.next_token_logits(h1[:, -1])
+        ops.decode_book(ops.argmax_rows(logits), st, h1.reshape(B, -1), self.cfg.pad_token_id, self.cfg.eos_token_id)
+
+    def _decode_book_step(self, cache):
+        """One greedy step of generate(): the token written last (cache["book"]["tok"]) is decoded at each row's position and
+        the next token is chosen and filed — ONE hipGraph replay per step (per (batch, capacity): the per-row state lives in
+        device memory), nothing else on the stream. The first step of a new shape runs eagerly (it is the warm-up of the
+        lazily built state inside the ops) and is followed by the capture, which executes nothing."""
+        if not self.decode_graphs:
+            return self._decode_book_eager(cache)
+        key = ("book", cache["book"]["tok"].shape[0], cache["tmax"])
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 16:
+                self._graphs.clear()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            self._decode_book_eager(cache)
+            torch.cuda.current_stream(self.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+                self._decode_book_eager(cache)
+            self._graphs[key] = g
+            return
+        g.replay()
 
     def _decode_step_eager(self, nxt, cache):
         B = nxt.shape[0]
@@ -249,20 +292,35 @@ class LisaMI355:
                                              for f in frames_u8], 0)
                 else:
                     images_clip = ing.clip_pixels(frames_u8, self.cfg.clip.image, self.dtype)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            if frames_u8 is not None:
-                from .preprocess import SAM_MEAN, SAM_STD
-                # a1 on the device: ResizeLongestSide (identity when the long side is img_size), then the fused
-                # normalise + pad + patchify of haff_patchify_u8
-                if frame_list:
-                    emb = self.get_visual_embs_frames(frames_u8, SAM_MEAN, SAM_STD)
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(cur)
+        sam_out = []
+
+        def launch_sam():
+            side.wait_event(inputs_ready)
+            with torch.cuda.stream(side):
+                if frames_u8 is not None:
+                    from .preprocess import SAM_MEAN, SAM_STD
+                    # a1 on the device: ResizeLongestSide (identity when the long side is img_size), then the fused
+                    # normalise + pad + patchify of haff_patchify_u8
+                    if frame_list:
+                        sam_out.append(self.get_visual_embs_frames(frames_u8, SAM_MEAN, SAM_STD))
+                    else:
+                        sam_u8, _ = self.frame_ingest().sam_frames(frames_u8, self.cfg.sam.img_size)
+                        sam_out.append(self.get_visual_embs_u8(sam_u8, SAM_MEAN, SAM_STD))
                 else:
-                    sam_u8, _ = self.frame_ingest().sam_frames(frames_u8, self.cfg.sam.img_size)
-                    emb = self.get_visual_embs_u8(sam_u8, SAM_MEAN, SAM_STD)
-            else:
-                emb = self.get_visual_embs(images)
-        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask)
+                    sam_out.append(self.get_visual_embs(images))
+
+        # Where the encoder is enqueued. Throughput batches: first, so its GEMMs run beside the CLIP tower and the prefill.
+        # A few frames (latency): behind the prefill, so it runs beside the HBM-bound decode steps, which leave the matrix
+        # cores idle, instead of time-slicing them with the prefill (and the host enqueues it while the prefill runs).
+        late = self.overlap_streams and self.sam_beside_decode is not False and \
+            (self.sam_beside_decode is True or input_ids.shape[0] <= 4)
+        if not late:
+            launch_sam()
+        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask,
+                                           after_prefill=launch_sam if late else None)
+        emb = sam_out[0]
         pred, frame_idx, counts = self.seg_embeddings(output_ids, hidden)
         cur.wait_stream(side)
         emb.record_stream(cur)

@@ -373,6 +373,23 @@ def argmax_rows(logits):
     return out
 
 
+def decode_book(nxt_raw, st, h1, pad, eos):
+    """Device-side bookkeeping of one greedy-decode token (haff_decode_book). st: the persistent per-(batch, capacity) state
+    dict of LisaMI355._persistent_cache (forced, use_forced, steps, finished, out_ids, lens, t_rows, tok, pos, nk, hidden)."""
+    lib = load_library()
+    _req(nxt_raw, "nxt_raw")
+    B = nxt_raw.shape[0]
+    hid = st["hidden"]
+    assert nxt_raw.dtype == torch.int64 and st["out_ids"].dtype == torch.int64 and st["forced"].dtype == torch.int64
+    assert hid.is_contiguous() and (h1 is None or (h1.is_contiguous() and h1.numel() == B * hid.shape[2] and h1.dtype == hid.dtype))
+    rc = lib.haff_decode_book(nxt_raw.data_ptr(), st["forced"].data_ptr(), st["forced"].stride(0), st["use_forced"].data_ptr(),
+                              st["steps"].data_ptr(), st["finished"].data_ptr(), st["out_ids"].data_ptr(), st["out_ids"].stride(0),
+                              st["lens"].data_ptr(), st["t_rows"].data_ptr(), st["tok"].data_ptr(), st["pos"].data_ptr(),
+                              st["nk"].data_ptr(), _p(h1), hid.data_ptr(), hid.stride(0) * hid.element_size(),
+                              hid.shape[2] * hid.element_size(), int(pad), int(eos), B, _stream())
+    check(rc, "haff_decode_book")
+
+
 def add_bcast(a, b, mod=None, out=None):
     """out[r] = a[r] + b[r % mod]; a [R,C], b [mod,C]."""
     lib = load_library()

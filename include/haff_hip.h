@@ -154,6 +154,15 @@ int haff_rope_cache_rows(void* qkv, long ld, void* kcache, void* vcache, const f
                          int Hkv, int d, const int* pos0_rows, int Tmax, int dtype, void* stream);
 /* greedy token: first index of the row maximum (generate(num_beams=1), LISA.py:443-450) */
 int haff_argmax_rows(const float* x, long ld, long* out, int rows, int V, void* stream);
+/* One generated token per row of the greedy decode loop, on the device (replaces the per-step host bookkeeping of
+ * transformers' generate as used by LISA.py:443-450; sits inside the decode hipGraph). Row b, step s = steps[b]:
+ * token = *use_forced ? forced[b][s] : nxt_raw[b]; pad if finished[b]; out_ids[b][lens[b]+s] = token; finished[b] |= token == eos;
+ * tok[b] = token; pos[b] = t_rows[b]+s; nk[b] = pos[b]+1; for s >= 1 and h1 != NULL: hidden[b][t_rows[b]+s-1] = h1[b]
+ * (row_bytes bytes, multiple of 16); steps[b] = s+1. All pointers device memory; hid_sb = bytes between rows b of hidden. */
+int haff_decode_book(const long* nxt_raw, const long* forced, long forced_ld, const int* use_forced, int* steps,
+                     unsigned char* finished, long* out_ids, long out_ld, const long* lens, const int* t_rows, long* tok,
+                     int* pos, int* nk, const void* h1, void* hidden, long hid_sb, long row_bytes, long pad, long eos, int B,
+                     void* stream);
 /* out[r] = a[r] + b[r % mod]  (PE adds, transformer.py:166-178; src + dense prompt, mask_decoder.py:141) */
 int haff_add_bcast(const void* a, const void* b, void* out, long rows, int C, int mod, int dtype, void* stream);
 /* row softmax to f32 (taxonomy head, mask_decoder.py:177) */
