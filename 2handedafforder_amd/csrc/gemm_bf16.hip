@@ -340,7 +340,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #ifdef HAFF_GEMM_TRACE
       if (kt == 5) HAFF_TRACE(7);
 #endif
+#ifndef HAFF_EXP_NOREAD   // timing experiments only (results are wrong): drop the LDS fragment reads / the DMA of the loop
       read_frags(cur, 1);
+#endif
       mfma_rows(0, 0, TM);
 
       mfma_rows(1, 0, HEAD);
@@ -364,11 +366,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #ifdef HAFF_GEMM_TRACE
         if (kt == 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); HAFF_TRACE(5); }
 #endif
+#ifndef HAFF_EXP_NODMA
         if (!late && kt + 2 < nk) stage(cur, (kt + 2) * BK);
+#endif
 #ifdef HAFF_GEMM_TRACE
         if (kt == 4) HAFF_TRACE(6);
 #endif
+#ifndef HAFF_EXP_NOREAD
         read_frags(cur ^ 1, 0);
+#endif
 #if HAFF_GEMM_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -380,7 +386,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       __builtin_amdgcn_s_setprio(3);
 #endif
       mfma_rows(1, HEAD, TM);
-      if (late && kt + 2 < nk) {   // the partner issued its share before its fragment reads; this wave after its tail MFMAs
+#ifndef HAFF_EXP_NODMA
+      if (late && kt + 2 < nk)
+#else
+      if (false)
+#endif
+      {   // the partner issued its share before its fragment reads; this wave after its tail MFMAs
         __builtin_amdgcn_sched_barrier(0);
         stage(cur, (kt + 2) * BK);
         __builtin_amdgcn_sched_barrier(0);
