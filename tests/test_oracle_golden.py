@@ -98,6 +98,36 @@ def test_seg_token_rule_and_losses_closed_form():
     assert m[0].nonzero().flatten().tolist() == [255 + 5] and m[1].nonzero().flatten().tolist() == [255 + 3, 255 + 6]
 
 
+def test_dice_and_bce_losses_closed_form():
+    """LISA.py:16-59 against hand-computed values (float64 arithmetic of the same formulas, no torch):
+    dice = sum_masks[1 - (2*sum(p/1000 * t) + 1e-6) / (sum(p/1000) + sum(t/1000) + 1e-6)] / (num_masks + 1e-8),
+    bce = sum_masks[mean_pixels(softplus(x) - x*t)] / (num_masks + 1e-8). Cases: logits 0 (p = 1/2 everywhere), a perfect
+    saturated prediction (loss -> 0), an empty target with a saturated-negative prediction (the eps/eps = 1 corner: loss 0),
+    and random logits against the float64 formula."""
+    H, W = 6, 10
+    t = torch.zeros((2, H, W))
+    t[0, :3] = 1.0                       # 30 positive pixels of 60
+    t[1, 0, :4] = 1.0                    # 4 positive pixels
+    zeros = torch.zeros((2, H, W))
+    n = 2.0
+    # p = 0.5: numerator = n_pos / 1000, denominator = (0.5 * HW + n_pos) / 1000
+    exp_dice = sum(1 - (npos / 1000 + 1e-6) / ((0.5 * H * W + npos) / 1000 + 1e-6) for npos in (30, 4)) / (n + 1e-8)
+    assert abs(O.dice_loss(zeros, t, n).item() - exp_dice) < 1e-6
+    assert abs(O.sigmoid_ce_loss(zeros, t, n).item() - 2 * np.log(2.0) / (n + 1e-8)) < 1e-6
+    sat = (t * 2 - 1) * 40.0             # sigmoid saturates to the target
+    assert O.dice_loss(sat, t, n).item() < 1e-5 and O.sigmoid_ce_loss(sat, t, n).item() < 1e-6
+    empty = torch.zeros((1, H, W))
+    assert abs(O.dice_loss(torch.full((1, H, W), -40.0), empty, 1.0).item()) < 1e-6      # (0 + eps) / (0 + eps) = 1
+    assert abs(O.dice_loss(torch.full((1, H, W), 40.0), empty, 1.0).item() - (1 - 1e-6 / (H * W / 1000 + 1e-6))) < 1e-6
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, H, W), generator=g) * 3
+    xd, td = x.double().numpy().reshape(2, -1), t.double().numpy().reshape(2, -1)
+    pd = 1.0 / (1.0 + np.exp(-xd))
+    dice = (1 - (2 * (pd / 1000 * td).sum(-1) + 1e-6) / ((pd / 1000).sum(-1) + (td / 1000).sum(-1) + 1e-6)).sum() / (n + 1e-8)
+    bce = (np.logaddexp(0.0, xd) - xd * td).mean(-1).sum() / (n + 1e-8)
+    assert abs(O.dice_loss(x, t, n).item() - dice) < 1e-5 and abs(O.sigmoid_ce_loss(x, t, n).item() - bce) < 1e-5
+
+
 def test_host_helpers_match_reference():
     from haff import prompt as P
     with open(os.path.join(GOLD, "host_helpers.json")) as f:
