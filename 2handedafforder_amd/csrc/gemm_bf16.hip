@@ -64,6 +64,15 @@ struct GemmArgs {
   // (caller-provided workspace) and skinny_reduce_kernel applies the epilogue to the slice sum, in slice order
   float* ws;
   int ksplit;
+  // RMSNorm carried between decode-sized products without a norm kernel (weight-streaming kernel, M <= 16):
+  //   producer (ssq_out): workgroup b writes ssq_out[b][m] = sum over ITS output columns of bf16(C[m][n])^2, m < 16;
+  //   consumer (ssq_in):  rstd_m = rsqrt(sum_b ssq_in[b][m] / K + ssq_eps) (b < ssq_n, fixed order) scales row m of the
+  //   product of the RAW activations with gamma-folded weights — the same fold as ln_stats, with the statistic assembled
+  //   from the producer's partials instead of a pass over the row.
+  float* ssq_out;
+  const float* ssq_in;
+  int ssq_n;
+  float ssq_eps;
 };
 
 // Epilogue activations of the throughput (bf16) path. GELU matters for the K=1280 SAM MLP GEMM, whose epilogue touches
@@ -676,6 +685,22 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
   const bf16_t* wrow[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wrow[t] = p.W + (long)min(n0 + t * 16 + fr, p.N - 1) * p.ldw + k_lo + fh * 8;
+  // folded RMSNorm from producer partials: thread (bl = tid >> 4, m = tid & 15) gathers partials b = bl, bl + 16, ...;
+  // the loads go out before the weight stream and are only consumed after the K loop
+  __shared__ float s_ssq[KW][16];
+  // thread t fetches partial workgroups b = t and t + 256 of each row (<= 4 rows, <= 512 partials: haff_gemm_bf16_rms checks);
+  // the values stay untouched in registers until after the K loop, so the weight stream starts without waiting for them
+  // (summing them here — a dependent L2 round trip before the first weight load — made the step slower than the norm kernels)
+  constexpr int SSQ_M = 4;
+  float ssq_a[SSQ_M], ssq_b[SSQ_M];
+  if (MT == 1 && p.ssq_in) {
+#pragma unroll
+    for (int mm = 0; mm < SSQ_M; ++mm) {
+      const int b0 = threadIdx.x, b1 = threadIdx.x + 64 * KW;
+      ssq_a[mm] = (mm < p.M && b0 < p.ssq_n) ? p.ssq_in[b0 * 16 + mm] : 0.f;
+      ssq_b[mm] = (mm < p.M && b1 < p.ssq_n) ? p.ssq_in[b1 * 16 + mm] : 0.f;
+    }
+  }
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -727,6 +752,16 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
       compute(1, k + KB);
     }
   }
+  if (MT == 1 && p.ssq_in) {   // lanes by butterfly, then the KW waves in index order (after the barrier below)
+#pragma unroll
+    for (int mm = 0; mm < SSQ_M; ++mm)
+      if (mm < p.M) {
+        float v = ssq_a[mm] + ssq_b[mm];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_ssq[wave][mm] = v;
+      }
+  }
   // the four K-quarters meet in LDS, one weight tile at a time; wave w then owns activation tile w of every weight
   // tile (lane holds D[n = 4*fh + r][m = 16*w + fr])
   float o[NT][4];
@@ -770,6 +805,16 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
     if (orow < 0) return;
   }
   const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
+  if (MT == 1 && p.ssq_in) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < KW; ++w4) tot += s_ssq[w4][fr];
+    const float rstd = rsqrtf(tot / (float)p.K + p.ssq_eps);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[t][r] *= rstd;
+  }
   if (p.ln_stats) {
     const float mean = p.ln_stats[2 * m], rstd = p.ln_stats[2 * m + 1];
 #pragma unroll
@@ -781,6 +826,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
       }
   }
   constexpr int NOUT = SWIGLU ? NT / 2 : NT;     // 16-column output tiles of this workgroup
+  float ssq_acc = 0.f;
 #pragma unroll
   for (int j = 0; j < NOUT; ++j) {
     float val[4];
@@ -817,12 +863,25 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
         ov.x = pack_bf16x2(val[0], val[1]);
         ov.y = pack_bf16x2(val[2], val[3]);
         *reinterpret_cast<uint2*>(c) = ov;
+        const float q0 = __builtin_bit_cast(float, ov.x << 16), q1 = __builtin_bit_cast(float, ov.x & 0xffff0000u);
+        const float q2 = __builtin_bit_cast(float, ov.y << 16), q3 = __builtin_bit_cast(float, ov.y & 0xffff0000u);
+        ssq_acc += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (nb + r < n_total_out) c[r] = f32_to_bf16(val[r] + (rs ? bf16_to_f32(rs[r]) : 0.f));
+          if (nb + r < n_total_out) {
+            const bf16_t q = f32_to_bf16(val[r] + (rs ? bf16_to_f32(rs[r]) : 0.f));
+            c[r] = q;
+            ssq_acc += bf16_to_f32(q) * bf16_to_f32(q);
+          }
       }
     }
+  }
+  if (MT == 1 && p.ssq_out && !p.out_f32) {
+    // the 4 lanes that share output row m = fr (fh = 0..3) hold this workgroup's columns of it between them
+    ssq_acc += __shfl_xor(ssq_acc, 16, 64);
+    ssq_acc += __shfl_xor(ssq_acc, 32, 64);
+    if (fh == 0) p.ssq_out[(long)blockIdx.x * 16 + fr] = ssq_acc;
   }
 }
 
@@ -1035,6 +1094,31 @@ extern "C" int haff_gemm_bf16_ws(const void* A, long lda, const void* W, long ld
   if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return HAFF_ERR_BAD_ARG;
   return gemm_bf16_impl(A, lda, nullptr, 0, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0,
                         stream, nullptr, nullptr, workspace, workspace_bytes);
+}
+
+// Decode-sized product (M <= 16; with ssq_in M <= 4 and ssq_n <= 512; K % 128 == 0; weight-streaming kernel) that carries Llama's RMSNorm between products
+// without a norm kernel (LlamaDecoderLayer as reached from llava_llama.py:93-102: input_layernorm -> q/k/v,
+// post_attention_layernorm -> gate/up):
+//   ssq_in  != NULL: C = epi( rstd_m * (A . W^T) ), rstd_m = rsqrt(sum_{b < ssq_n} ssq_in[b][m] / K + eps), W = the weights with
+//                    the norm's gamma folded into their columns (caller), A = the un-normalised residual stream;
+//   ssq_out != NULL: (bf16 output) workgroup b also writes ssq_out[b][m] = sum over its output columns of bf16(C[m][n])^2,
+//                    m < 16 — the partials the next product's ssq_in consumes; *n_parts_out = number of workgroups b.
+// Both are fp32 [parts][16] device arrays. Sums run in a fixed order: results are bit-repeatable.
+extern "C" int haff_gemm_bf16_rms(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                                  const void* resid, long ldr, int M, int N, int K, int act, int out_f32, int swiglu,
+                                  const float* ssq_in, int ssq_n, float eps, float* ssq_out, int* n_parts_out, void* stream) {
+  if (M <= 0 || M > 16 || N <= 0 || K <= 0 || (K % 128) || (lda & 7) || (ldw & 7)) return HAFF_ERR_BAD_ARG;
+  if (ssq_in && (M > 4 || ssq_n > 512)) return HAFF_ERR_BAD_ARG;   // consumer side: <= 4 rows, <= 512 producer workgroups
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
+  if (swiglu && ((N & 31) || (ldc & 3) || resid)) return HAFF_ERR_BAD_ARG;
+  if ((ssq_in && ssq_n <= 0) || (ssq_out && (out_f32 || swiglu))) return HAFF_ERR_BAD_ARG;
+  GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
+             bias, resid, ldr, nullptr, nullptr, 8, nullptr, nullptr, M, N, K, act, out_f32, swiglu, 0, 0, 0, 0, 0, 0, 0};
+  p.ssq_in = ssq_in; p.ssq_n = ssq_n; p.ssq_eps = eps; p.ssq_out = ssq_out;
+  // launch_skinny<1>: 16 weight rows per workgroup (32 for SwiGLU pairs)
+  if (n_parts_out) *n_parts_out = swiglu ? (N + 31) / 32 : (N + 15) / 16;
+  launch_skinny<1>(p, N, swiglu, reinterpret_cast<hipStream_t>(stream));
+  return haff_check_launch();
 }
 
 // Same with a gather on the A side: logical row m of the product reads A row a_map[m] (0 <= a_map[m] < a_rows).

@@ -21,6 +21,8 @@ _PROTOS = {
                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_bf16_ws": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p],
+    "haff_gemm_bf16_rms": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
+                           c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "haff_gemm_bf16_gather": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                               c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_bf16_ln": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,

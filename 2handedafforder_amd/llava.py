@@ -122,6 +122,10 @@ class LlamaHip:
             del wqkv, wgu
         self.norm = _f32(sd["model.norm.weight"], dev)
         self.lm_head = sd["lm_head.weight"].to(dev, dtype).contiguous()
+        # Decode steps of <= 4 rows carry RMSNorm between the products (ops.linear_rms): no norm kernels, the q/k/v and gate/up
+        # weights get a second copy with the norm weight folded in (built on first use; +9 GB at 7B, +18 GB at 13B of 288)
+        self.carry_rms = dtype == torch.bfloat16 and self.hd == 128 and l.hidden % 128 == 0 and l.ffn % 128 == 0
+        self._folded = None
         self._cs = None
 
     def _cos_sin(self, tmax):
@@ -179,6 +183,8 @@ class LlamaHip:
         cs = self._cos_sin(cache["tmax"])
         pos, nk = cache["pos"], cache["nk"]
         x = x1.reshape(B, H).clone() if not x1.is_contiguous() else x1.reshape(B, H)
+        if self.carry_rms and B <= 4:
+            return self._decode_rows_carry(x, cache, cs, nk)
         for li, L in enumerate(self.layers):
             h = ops.rmsnorm(x, L["n1"], l.rms_eps)
             qkv = ops.linear(h, L["wqkv"])
@@ -196,6 +202,33 @@ class LlamaHip:
             h = ops.rmsnorm(x, L["n2"], l.rms_eps)
             g = ops.linear(h, L["wgu"], swiglu=True)
             x = ops.linear(g, L["wd"], resid=x, out=x)
+        return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, 1, H)
+
+    def _decode_rows_carry(self, x, cache, cs, nk):
+        """decode_rows for <= 4 rows without norm kernels: o_proj / down_proj write, beside the residual stream, each
+        workgroup's sum of squares of its slice of it; the next q/k/v or gate/up product (on norm-weight-folded weights and the
+        RAW stream) turns the partials into 1/rms in its epilogue. 5 launches per layer instead of 7 (layer 0 takes its
+        statistic from one pass over the embedding rows)."""
+        l = self.cfg
+        B, H = x.shape
+        nh, hd = l.heads, self.hd
+        if self._folded is None:
+            self._folded = [((L["wqkv"].float() * L["n1"][None, :]).to(torch.bfloat16).contiguous(),
+                             (L["wgu"].float() * L["n2"][None, :]).to(torch.bfloat16).contiguous()) for L in self.layers]
+        if "ssq" not in cache:
+            cache["ssq"] = [torch.zeros((H // 16, 16), dtype=torch.float32, device=self.device) for _ in range(2)]
+        pa, pb = cache["ssq"]
+        stats = ops.row_stats(x, l.rms_eps, rms=True)
+        for li, L in enumerate(self.layers):
+            wq, wgu = self._folded[li]
+            if li == 0:
+                qkv = ops.linear(x, wq, ln_stats=stats)
+            else:
+                qkv = ops.linear_rms(x, wq, ssq_in=pb, eps=l.rms_eps)
+            a = ops.decode_attention_rope(qkv, cache["k"][li], cache["v"][li], cs, nh, hd, hd ** -0.5, nk)
+            ops.linear_rms(a.view(B, H), L["wo"], resid=x, out=x, ssq_out=pa)
+            g = ops.linear_rms(x, wgu, swiglu=True, ssq_in=pa, eps=l.rms_eps)
+            ops.linear_rms(g, L["wd"], resid=x, out=x, ssq_out=pb)
         return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, 1, H)
 
     def next_token_logits(self, hidden_last):

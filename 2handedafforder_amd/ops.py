@@ -140,6 +140,32 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
     return out
 
 
+def linear_rms(x, w, resid=None, out=None, swiglu=False, ssq_in=None, ssq_out=None, eps=0.0):
+    """Decode-sized bf16 product (M <= 16) carrying RMSNorm statistics between products (haff_gemm_bf16_rms):
+    ssq_in fp32 [parts,16]: rows are scaled by rsqrt(sum(ssq_in[:, m]) / K + eps) (w = gamma-folded weights, x = raw
+    residual stream); ssq_out fp32 [>= N/16, 16]: receives this product's per-workgroup sums of squares of the bf16 output."""
+    lib = load_library()
+    _req(x, "x")
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    assert out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.shape == (M, n_out)
+    if resid is not None:
+        assert resid.dtype == out.dtype and resid.stride(1) == 1
+    if ssq_in is not None:
+        assert ssq_in.dtype == torch.float32 and ssq_in.is_contiguous() and ssq_in.shape[1] == 16
+    if ssq_out is not None:
+        assert ssq_out.dtype == torch.float32 and ssq_out.is_contiguous() and ssq_out.shape[1] == 16 and ssq_out.shape[0] * 16 >= N
+    rc = lib.haff_gemm_bf16_rms(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), None,
+                                _p(resid), 0 if resid is None else resid.stride(0), M, N, K, ACT_NONE, 0, 1 if swiglu else 0,
+                                _p(ssq_in), 0 if ssq_in is None else ssq_in.shape[0], float(eps), _p(ssq_out), None, _stream())
+    check(rc, "haff_gemm_bf16_rms")
+    return out
+
+
 def attention(q, k, v, scale, causal=False, q_pos0=0, relh=None, relw=None, S=0, out=None):
     """q [B,H,Nq,d], k/v [B,H,Nk,d] strided views (unit stride on d). Returns out [B,Nq,H*d] (token-major)."""
     lib = load_library()

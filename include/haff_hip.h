@@ -45,6 +45,16 @@ int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C
 int haff_gemm_bf16_ws(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                       const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
                       int swiglu, void* workspace, long workspace_bytes, void* stream);
+/* Decode-sized product (M <= 16; with ssq_in: M <= 4, ssq_n <= 512; K % 128 == 0) that carries Llama's RMSNorm between products without a norm kernel
+ * (transformers LlamaDecoderLayer as reached from 2Haff/model/llava/model/language_model/llava_llama.py:93-102:
+ * input_layernorm -> q/k/v_proj, post_attention_layernorm -> gate/up_proj). ssq_in != NULL: row m of A . W^T is scaled by
+ * rsqrt(sum_{b < ssq_n} ssq_in[b][m] / K + eps) before the epilogue — W must have the norm weight folded into its columns
+ * and A is the un-normalised residual stream. ssq_out != NULL (bf16 output, no SwiGLU): workgroup b writes
+ * ssq_out[b][m] = sum over its output columns of bf16(C[m][n])^2 (m < 16), *n_parts_out (host int, may be NULL) = number of
+ * workgroups — exactly what the next product's ssq_in / ssq_n take. Both arrays: DEVICE fp32 [parts][16]. */
+int haff_gemm_bf16_rms(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
+                       const void* resid, long ldr, int M, int N, int K, int act, int out_f32, int swiglu,
+                       const float* ssq_in, int ssq_n, float eps, float* ssq_out, int* n_parts_out, void* stream);
 /* haff_gemm_bf16 with a gather on the A side: logical row m reads A row a_map[m] (0 <= a_map[m] < a_rows). Runs the
  * window-unpartition projection over real tokens only (image_encoder.py:186-188,291-318 drop the padded rows right
  * after proj). */

@@ -210,6 +210,51 @@ def test_full_width_llama_layer_matches_oracle(dev, width, mode):
     assert err <= (2e-4 if mode == "f32" else 2.5e-2)
 
 
+@pytest.mark.parametrize("width", ["7b", "13b"])
+def test_decode_rows_carrying_rmsnorm_matches_oracle(dev, width):
+    """Decode steps of <= 4 rows run without norm kernels (LlamaHip._decode_rows_carry: o_proj / down_proj emit per-workgroup
+    sums of squares, the next product on norm-weight-folded weights applies 1/rms): after a 291-position prefill, two cached
+    steps at full width equal the oracle's no-cache recompute within the bf16 tolerance of the plain path, agree with the
+    plain path (norm kernels), and repeat bit for bit."""
+    import haff  # noqa: F401
+    from haff import weights as hw
+    from haff.llava import LlamaHip
+    from oracle import lisa_oracle as O
+    cfg = _llm_cfg(width)
+    shapes = {k: v for k, v in hw.llm_shapes(cfg).items() if k.startswith("model.layers.") or k == "model.norm.weight"}
+    shapes["model.embed_tokens.weight"] = (8, cfg.llm.hidden)
+    shapes["lm_head.weight"] = (8, cfg.llm.hidden)
+    sd = hw.round_to_bf16_(hw.make_state_dict(cfg, 33, shapes))
+    g = torch.Generator().manual_seed(5)
+    for k in sd:   # norm weights away from 1 so that the fold matters
+        if k.endswith("layernorm.weight") or k == "model.norm.weight":
+            sd[k] = (1.0 + 0.5 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16).float()
+    B, T, Hd = 3, 291, cfg.llm.hidden
+    x = torch.randn((B, T + 2, Hd), generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = O.llama_forward(sd, x, cfg.llm)[:, T:]
+    llm = LlamaHip(sd, cfg.llm, torch.bfloat16, dev)
+    assert llm.carry_rms
+    xd = x.to(dev, torch.bfloat16)
+
+    def steps(carry):
+        llm.carry_rms = carry
+        cache = llm.new_cache(B, T + 2)
+        llm.forward(xd[:, :T].contiguous(), cache)
+        out = []
+        for s_ in range(2):
+            cache["pos"].fill_(T + s_)
+            cache["nk"].fill_(T + s_ + 1)
+            out.append(llm.decode_rows(xd[:, T + s_:T + s_ + 1].clone(), cache).clone())
+        return torch.cat(out, 1).float().cpu()
+    carry, plain = steps(True), steps(False)
+    scale = ref.abs().max().item()
+    e_c, e_p = (carry - ref).abs().max().item() / scale, (plain - ref).abs().max().item() / scale
+    print(f"llama {width} decode: carry {e_c:.3e}, norm kernels {e_p:.3e}, carry vs plain {(carry - plain).abs().max().item() / scale:.3e}")
+    assert e_c <= 2.5e-2 and e_p <= 2.5e-2 and (carry - plain).abs().max().item() <= 2e-2 * scale
+    assert torch.equal(carry, steps(True))
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_full_width_clip_layer_and_projector_match_oracle(dev, mode):
     """CLIP-L/14 width (1024 / 16 heads / mlp 4096, 257 tokens): embeddings + pre-LN + the encoder layers that

@@ -57,6 +57,38 @@ def test_gemm_bf16_epilogues(dev, M, N, K, act):
     _close(got32, ACT_REF[act](x.float() @ w.float().T + bias), 2e-3, "gemm_bf16 f32-out")
 
 
+@pytest.mark.parametrize("M", [1, 3, 4])
+@pytest.mark.parametrize("H,N2", [(4096, 12288), (512, 1000), (5120, 27648)])
+def test_linear_rms_carries_the_norm(dev, M, H, N2):
+    """haff_gemm_bf16_rms: a residual product that also emits per-workgroup sums of squares of its bf16 output, and a product
+    on norm-weight-folded weights that turns those partials into 1/rms — against RMSNorm + product in fp32, and the
+    residual stream bit-equal to the plain kernel's."""
+    ops = _ops()
+    eps = 1e-5
+    a = _rand((M, H), dev, torch.bfloat16, 41)
+    x0 = _rand((M, H), dev, torch.bfloat16, 42)
+    wo = _rand((H, H), dev, torch.bfloat16, 43, H ** -0.5)
+    gamma = (1.0 + 0.3 * _rand((H,), dev, torch.float32, 44))
+    w2 = _rand((N2, H), dev, torch.bfloat16, 45, H ** -0.5)
+    w2f = (w2.float() * gamma[None, :]).to(torch.bfloat16).contiguous()
+    parts = torch.full((H // 16, 16), float("nan"), device=dev)
+    x1 = ops.linear_rms(a, wo, resid=x0, out=x0.clone(), ssq_out=parts)
+    assert torch.equal(x1, ops.linear(a, wo, resid=x0))
+    ssq = (x1.float() ** 2).view(M, H // 16, 16).sum(-1).T            # [H/16, M]
+    _close(parts[:, :M], ssq, 1e-5, "per-workgroup sums of squares")
+    rstd = torch.rsqrt((x1.float() ** 2).mean(-1, keepdim=True) + eps)
+    swiglu = N2 % 32 == 0
+    y = ops.linear_rms(x1, w2f, ssq_in=parts, eps=eps, swiglu=swiglu)
+    lin = (x1.float() * rstd) @ w2f.float().T
+    if swiglu:
+        lin = lin.view(M, N2 // 32, 2, 16)
+        lin = (F.silu(lin[:, :, 0]) * lin[:, :, 1]).reshape(M, N2 // 2)
+    _close(y, lin, 1.2e-2, "folded rms product")
+    assert torch.equal(y, ops.linear_rms(x1, w2f, ssq_in=parts, eps=eps, swiglu=swiglu))
+    if not swiglu:   # against the unfused kernels (norm weight applied to the activations instead of the weights)
+        _close(y, ops.linear(ops.rmsnorm(x1, gamma, eps), w2), 2.5e-2, "vs norm kernel + product")
+
+
 @pytest.mark.parametrize("M,N,K", [(288, 4096, 4096), (288, 4096, 11008), (257, 1024, 4096), (257, 3072, 1024), (257, 1003, 1024),
                                    (100, 520, 2048), (1000, 256, 1280)])
 def test_gemm_bf16_split_k_tiles(dev, M, N, K):
