@@ -26,6 +26,7 @@
 // deep so the 4 MiB per-XCD L2 holds the A and W panels the concurrently running tiles share.
 #include <type_traits>
 
+#include <cstdlib>
 #include "haff_common.h"
 
 namespace {
@@ -1062,7 +1063,18 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   // Raster group depth: 8 M-tiles share their A panels across the N sweep; with a long K loop (>= 5120) and few N tiles
   // the concurrently running tiles drift apart and a 2-deep group keeps more of the sweep in the 4 MiB L2
   // (measured +5 % on 131072x1280x5120 and 18624x4096x11008, tools/gemm_variant.py).
-  if (big && K >= 5120 && (N + 255) / 256 <= 32) p.group_m = 2;
+  if (big) {
+    // (sweep of 1..32 on the bench shapes, tools/gemm_variant.py with HAFF_GEMM_GROUP_M: <= 5 N-tiles: 1 (+4 % on
+    // 131072x1280x1280), <= 16 N-tiles: 4 (+1.4 % on 131072x3840x1280), 20 N-tiles: 8; all within 3 % of each other)
+    const int tn = (N + 255) / 256;
+    if (tn <= 5) p.group_m = 1;
+    else if (K >= 5120 && tn <= 32) p.group_m = 2;
+    else if (tn <= 16) p.group_m = 4;
+  }
+  {   // A/B override of the raster group depth (tools/gemm_variant.py)
+    static const int gm_env = [] { const char* e = getenv("HAFF_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
+    if (gm_env > 0) p.group_m = gm_env;
+  }
 #ifndef HAFF_GEMM_NO_NT
   p.nt_out = (long)M * (swiglu ? N / 2 : N) * (out_f32 ? 4 : 2) >= (64L << 20);
 #endif
