@@ -67,8 +67,13 @@ class LisaMI355:
     # ---- a4/a5: CLIP tower + projector -------------------------------------------------------------------
     def encode_images(self, images_clip):
         B = images_clip.shape[0]
-        h = self.clip.hidden(images_clip.to(self.device))
-        return self.clip.project(h, B, self.w_proj, self.b_proj)
+        images_clip = images_clip.to(self.device)
+
+        def fn(x):
+            return (self.clip.project(self.clip.hidden(x), B, self.w_proj, self.b_proj),)
+        if not self.decode_graphs or B > 4:
+            return fn(images_clip)[0]
+        return self._replay(("clip", B, images_clip.dtype, tuple(images_clip.shape[1:])), fn, [images_clip.contiguous()])[0]
 
     # ---- a6-a8: splice + greedy generate -----------------------------------------------------------------
     @torch.no_grad()
@@ -327,7 +332,7 @@ class LisaMI355:
         B = output_ids.shape[0]
         pred_masks_left, pred_masks_right, taxonomies = [], [], []
         if pred.shape[0] > 0:
-            lo_l, lo_r, tax, _, _ = self.sam_decoder.decode(emb, frame_idx, pred)
+            lo_l, lo_r, tax = self._decoder_tail(emb, frame_idx, pred)
         offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cpu().long().cumsum(0)]).tolist()
         for i in range(B):
             a, b = offs[i], offs[i + 1]
@@ -343,6 +348,36 @@ class LisaMI355:
         return output_ids, pred_masks_left, pred_masks_right, taxonomies
 
     predict = evaluate
+
+    def _replay(self, key, fn, inputs):
+        """fn(*static inputs) -> tuple of tensors, as ONE hipGraph per key (a few frames: these stages are ~150-190 small
+        launches each and the host, not the GPU, sets their pace). First use runs eagerly (warm-up and result), then captures."""
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 16:
+                self._graphs.clear()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            static = [t.clone() for t in inputs]
+            out = fn(*static)
+            torch.cuda.current_stream(self.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+                outs = fn(*static)
+            self._graphs[key] = (g, static, outs)
+            return out
+        g, static, outs = ent
+        for dst, src in zip(static, inputs):
+            dst.copy_(src)
+        g.replay()
+        return tuple(o.clone() for o in outs)
+
+    def _decoder_tail(self, emb, frame_idx, pred):
+        """Prompt encoder + both two-way mask decoders -> (low-res left, low-res right, taxonomy)."""
+        fn = lambda e, i, t: tuple(self.sam_decoder.decode(e, i, t)[:3])   # noqa: E731
+        if not self.decode_graphs or pred.shape[0] > 8 or emb.shape[0] > 8:
+            return fn(emb, frame_idx, pred)
+        return self._replay(("tail", emb.shape[0], pred.shape[0], emb.dtype), fn, [emb, frame_idx, pred])
 
     def eval(self):
         return self
