@@ -198,10 +198,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   // running tiles share A and W panels in the 4 MiB per-XCD L2.
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
-  int m0, n0;
-  {
-    const int nwg = tiles_m * tiles_n;
-    const int t = blockIdx.x;
+  const int nwg = tiles_m * tiles_n;
+  auto tile_origin = [&](int t, int& tm0, int& tn0) {
     const int q = nwg >> 3, r = nwg & 7, xcd = t & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
     const int GROUP_M = p.group_m;
@@ -210,9 +208,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     const int first_m = g * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
     const int in_g = lin - g * per_group;
-    m0 = (first_m + in_g % gsz) * BM;
-    n0 = (in_g / gsz) * BN;
-  }
+    tm0 = (first_m + in_g % gsz) * BM;
+    tn0 = (in_g / gsz) * BN;
+  };
+  // The 8-wave tile is PERSISTENT when the launcher caps the grid (one workgroup per CU): a workgroup takes tiles
+  // blockIdx.x, blockIdx.x + gridDim.x, ... (same XCD, consecutive waves of its raster), and the first K-tile of the next
+  // tile is requested BEFORE the epilogue of the current one into the LDS buffer the epilogue does not use, so the
+  // first-load latency and the store drain of tile i sit under each other instead of in sequence (K = 1280: the epilogue
+  // and the first load were ~7 of a tile's ~41 us).
+  int tile = blockIdx.x;
+  int m0, n0;
+  tile_origin(tile, m0, n0);
   HAFF_TRACE(0);
 
   // ---- per-thread staging coordinates: 16-B chunks of the K-tile ----
@@ -224,30 +230,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const bf16_t* w_src[OFF32 ? 1 : NW];
   int a_kcol[OFF32 ? 1 : NA], w_kcol[OFF32 ? 1 : NW];
   unsigned a_off[OFF32 ? NA : 1], w_off[OFF32 ? NW : 1];
+  auto stage_coords = [&](int tm0, int tn0) {
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int pos = i * NTHREADS + tid, row = pos >> 3;
-    const int kcol = ((pos & 7) ^ (row & 7)) * 8;
-    int arow = min(m0 + row, p.M - 1);
-    if (p.a_map) arow = p.a_map[arow];
-    if constexpr (OFF32) {
-      a_off[i] = ((unsigned)arow * (unsigned)p.lda + kcol) * 2u;  // bytes
-    } else {
-      a_kcol[i] = kcol;
-      a_src[i] = p.A + (long)arow * p.lda + kcol;
+    for (int i = 0; i < NA; ++i) {
+      const int pos = i * NTHREADS + tid, row = pos >> 3;
+      const int kcol = ((pos & 7) ^ (row & 7)) * 8;
+      int arow = min(tm0 + row, p.M - 1);
+      if (p.a_map) arow = p.a_map[arow];
+      if constexpr (OFF32) {
+        a_off[i] = ((unsigned)arow * (unsigned)p.lda + kcol) * 2u;  // bytes
+      } else {
+        a_kcol[i] = kcol;
+        a_src[i] = p.A + (long)arow * p.lda + kcol;
+      }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < NW; ++i) {
-    const int pos = i * NTHREADS + tid, row = pos >> 3;
-    const int kcol = ((pos & 7) ^ (row & 7)) * 8;
-    if constexpr (OFF32) {
-      w_off[i] = ((unsigned)(min(n0 + row, p.N - 1)) * (unsigned)p.ldw + kcol) * 2u;
-    } else {
-      w_kcol[i] = kcol;
-      w_src[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + kcol;
+    for (int i = 0; i < NW; ++i) {
+      const int pos = i * NTHREADS + tid, row = pos >> 3;
+      const int kcol = ((pos & 7) ^ (row & 7)) * 8;
+      if constexpr (OFF32) {
+        w_off[i] = ((unsigned)(min(tn0 + row, p.N - 1)) * (unsigned)p.ldw + kcol) * 2u;
+      } else {
+        w_kcol[i] = kcol;
+        w_src[i] = p.W + (long)min(tn0 + row, p.N - 1) * p.ldw + kcol;
+      }
     }
-  }
+  };
+  stage_coords(m0, n0);
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(haff_zero_page);
 
   auto stage = [&](int buf, int k0) {
@@ -292,11 +301,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const int nk = (p.K + BK - 1) / BK;
 
   f32x4 acc[TN][TM];  // [ni][mi]
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   bf16x8 wf[2][TN], af[2][TM];  // fragments of one K-tile: [32-deep k-step][16-row tile]
   auto read_frags = [&](int buf, int ks) {
     const bf16_t* sA = smem + buf * STAGE_ELEMS;
@@ -321,6 +325,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[ks][mi], acc[ni][mi], 0, 0, 0);
   };
 
+  int buf0 = 0;           // LDS buffer that holds K-tile 0 of the current tile
+  bool first_tile = true;
+  for (;;) {              // tiles of this workgroup (one pass unless the grid was capped: persistent 8-wave tile)
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   // K loop, software-pipelined ACROSS the workgroup barrier. One barrier per K-tile: after it every wave's share of
   // tile kt+1 has landed and every wave is done reading tile kt-1's buffer, so the DMA of tile kt+2 may overwrite it
   // and has a whole K-tile of MFMAs to land. The second half of k-step 1's MFMAs (operands already in registers) is
@@ -332,9 +343,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #define HAFF_GEMM_HEAD (TM / 2)
 #endif
     constexpr int HEAD = HAFF_GEMM_HEAD;
-    stage(0, 0);
+    if (first_tile) stage(buf0, 0);   // later tiles: requested under the previous tile's epilogue
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();     // K-tile 0 landed; every wave is past its previous epilogue (its LDS staging is free)
     HAFF_TRACE(1);
     // SIMD partners (waves w and w+4) issue their share of the next tile's DMA at different points after the barrier:
     // a wave's 8 DMA instructions take ~340 ns to issue (the CU accepts requests at the rate memory serves them;
@@ -343,10 +354,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     // (+2.5...+7 % per shape, tools/gemm_variant.py; both partners right after the barrier idled the matrix pipe;
     // moving the late group's issue into the middle of the next K-tile's MFMA stream instead cost 10-18 %).
     const bool late = wave >= 4;
-    if (nk > 1) stage(1, BK);
-    read_frags(0, 0);
+    if (nk > 1) stage(buf0 ^ 1, BK);
+    read_frags(buf0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
+      const int cur = (kt & 1) ^ buf0;
 #ifdef HAFF_GEMM_TRACE
       if (kt == 5) HAFF_TRACE(7);
 #endif
@@ -449,6 +460,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   }
   __builtin_amdgcn_s_barrier();  // the epilogue reuses stage memory: every wave is done reading fragments
   HAFF_TRACE(2);
+  // the buffer the last K-tile was read from takes the epilogue's staging images; the other one is idle: the next tile's
+  // first K-tile goes there now (8-wave persistent form)
+  const int ebuf = ((nk - 1) & 1) ^ buf0;
+  const int m0e = m0, n0e = n0;
+  const int tile_next = tile + (int)gridDim.x;
+  const bool has_next = (WM * WN == 8) && tile_next < nwg;
+  if (has_next) {
+    tile_origin(tile_next, m0, n0);
+    stage_coords(m0, n0);
+    stage(ebuf ^ 1, 0);
+  }
 
   // ---- epilogue, staged through LDS so global traffic is whole 128-B row segments ----
   // lane holds D[n = 4*fh + reg][m = fr] of each 16x16 tile -> (+bias, act) -> fp32 LDS image [16 rows][WCOLS],
@@ -463,11 +485,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int STEPS = 16 / RPS;
   constexpr int WROWS = BM / WM;            // output rows owned by a wave (64 or 128)
   static_assert(WM * WN * 16 * RS * 4 <= STAGE_ELEMS * 2, "epilogue staging must fit in one LDS stage");
-  float* sEp = reinterpret_cast<float*>(smem) + wave * (16 * RS);
+  float* sEp = reinterpret_cast<float*>(smem + ebuf * STAGE_ELEMS) + wave * (16 * RS);
   const int n_total_out = SWIGLU ? (p.N >> 1) : p.N;
-  const int n_wave_in = n0 + wn * WNC;                          // first (interleaved) input column of the wave
+  const int n_wave_in = n0e + wn * WNC;                         // first (interleaved) input column of the wave
   const int n_wave_out = SWIGLU ? (n_wave_in >> 1) : n_wave_in;
-  const int m_wave = m0 + wm * WROWS;
+  const int m_wave = m0e + wm * WROWS;
   const bool c_vec = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((p.ldc & 7) == 0);
   const bool r_vec = p.resid && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) && ((p.ldr & 7) == 0);
   const bool fast = c_vec && (!p.resid || r_vec) && (n_wave_out + WCOLS <= n_total_out);
@@ -488,8 +510,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   }
   // folded norm: this wave's {mean, rstd} rows and column sums go through LDS (free stage memory past the staging
   // images) so the per-pass code reads them back instead of holding 2*TM + 4*TN more registers
-  static_assert(WM * WN * 16 * RS * 4 <= STAGE_ELEMS * 2 && WM * WN * (2 * WROWS + WNC) * 4 <= STAGE_ELEMS * 2, "epilogue LDS");
-  float* sStat = reinterpret_cast<float*>(smem + STAGE_ELEMS) + wave * (2 * WROWS + WNC);   // stage 1 (staging images: stage 0)
+  static_assert((WM * WN * 16 * RS + WM * WN * (2 * WROWS + WNC)) * 4 <= STAGE_ELEMS * 2, "epilogue LDS fits one stage");
+  float* sStat = reinterpret_cast<float*>(smem + ebuf * STAGE_ELEMS) + WM * WN * 16 * RS + wave * (2 * WROWS + WNC);   // behind the staging images
   float* sCsum = sStat + 2 * WROWS;
   if (p.ln_stats) {
 #pragma unroll
@@ -651,6 +673,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   HAFF_TRACE(4);
 #endif
+  if (!has_next) break;
+  tile = tile_next;
+  buf0 = ebuf ^ 1;
+  first_tile = false;
+  }   // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -977,7 +1004,11 @@ static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const int gx = tiles;
+  int gx = tiles;
+  if (WM * WN == 8) {   // persistent 8-wave tile: one workgroup per CU (HAFF_GEMM_PERSIST: other cap, 0 = one tile each)
+    static const int cap = [] { const char* e = getenv("HAFF_GEMM_PERSIST"); return e ? atoi(e) : 256; }();
+    if (cap > 0 && gx > cap) gx = cap;
+  }
   dim3 grid(gx, nbatch), block(64 * WM * WN);
   if (p.swiglu) {
     if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
