@@ -136,6 +136,7 @@ def parity_vs_oracle(device):
         with torch.no_grad():
             r_ids, r_left, r_right, r_tax = O.lisa_evaluate(sd, cfg, images_clip, images, ids, [(S, S)], [(S, S)],
                                                              max_new_tokens=4, forced_answer=forced, taps=taps)
+            r_greedy = O.lisa_evaluate(sd, cfg, images_clip, images, ids, [(S, S)], [(S, S)], max_new_tokens=8)[0]
             # floor: exact fp32 everywhere, the image embedding alone rounded to bf16 once
             g = (cfg.sam.grid,) * 2
             pe = O.sam_dense_pe(sd, V + ".prompt_encoder", g)
@@ -169,12 +170,27 @@ def parity_vs_oracle(device):
             st = stats(((left[0], r_left[0]), (right[0], r_right[0])))
             st["taxonomy_max_abs_err"] = (tax[0].float().cpu() - r_tax[0]).abs().max().item()
             st["token_ids_equal"] = bool(torch.equal(o_ids.cpu(), r_ids))
+            # free-running greedy decode (no forced answer): the argmax chain itself, 8 tokens
+            g_ids = model.evaluate(images_clip.to(device), images.to(device), ids.to(device), [(S, S)], [(S, S)], max_new_tokens=8)[0]
+            st["greedy_token_ids_equal"] = bool(g_ids.shape == r_greedy.shape and torch.equal(g_ids.cpu(), r_greedy))
             res[name] = st
             del model
         out[cfg_name] = res
     # the keys round 1 reported, for continuity: configs[0]
     out["config"] = "BASELINE.json configs[0] (tiny) and the mid geometry, 1 frame each, forced answer with one [SEG]"
     out["bf16"], out["fp32"] = out["tiny"]["bf16"], out["tiny"]["fp32"]
+    # the gate bench.py enforces (exit code 3 after the line is printed): fp32 mode meets BASELINE's targets outright; the
+    # bf16 mode is held to the band the random-weight floor allows and to the forced-token identity
+    fails = []
+    for cfg_name in ("tiny", "mid"):
+        f32, b16 = out[cfg_name]["fp32"], out[cfg_name]["bf16"]
+        if f32["mask_iou_vs_oracle"] < 0.999 or f32["mask_logit_max_err_rel"] > 1e-3 or not f32["token_ids_equal"] or not f32["greedy_token_ids_equal"]:
+            fails.append(f"{cfg_name}/fp32")
+        if b16["mask_iou_vs_oracle"] < 0.98 or b16["mask_logit_max_err_rel"] > 2e-2 or not b16["token_ids_equal"]:
+            fails.append(f"{cfg_name}/bf16")
+    out["gate"] = {"fp32": "IoU >= 0.999, logits within 1e-3, forced and free-running greedy tokens identical",
+                   "bf16": "IoU >= 0.98 (floor of a bf16-rounded embedding: iou_floor_*), logits within 2e-2, forced tokens identical",
+                   "failed": fails}
     return out
 
 
@@ -299,6 +315,7 @@ def stub_main(args):
 
 
 def main(argv=None):
+    exit_code = 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -460,11 +477,15 @@ def main(argv=None):
             del model
             line["parity"] = parity_vs_oracle(device)
         print(json.dumps(line), flush=True)
+        if (line.get("parity") or {}).get("gate", {}).get("failed"):
+            print("parity gate failed: " + ", ".join(line["parity"]["gate"]["failed"]), file=sys.stderr)
+            exit_code = 3
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
