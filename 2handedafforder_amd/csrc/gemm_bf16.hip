@@ -916,6 +916,37 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
 // Second half of a split-K weight-streaming product: out[m][n] = epi(sum over slices of ws[slice][m][n]), slices added
 // in index order (deterministic), 4 consecutive columns per thread. bias -> act -> +resid, row map, bf16 / f32 output.
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(GemmArgs p) {
+  if (p.swiglu) {
+    // partial tiles hold the interleaved [gate x16 | up x16] columns; 4 consecutive OUTPUT columns per thread (they sit in
+    // one 16-column group): out = silu(sum gate + bias_g) * (sum up + bias_u)
+    const int nout = p.N >> 1, n4 = nout >> 2;   // N % 32 == 0
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+    const int ng = 32 * (n >> 4) + (n & 15);
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < p.ksplit; ++ks) {
+      const float* wp = p.ws + ((long)ks * p.M + m) * p.N + ng;
+      float a[4], b[4];
+      load4(wp, a);
+      load4(wp + 16, b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { g[r] += a[r]; u[r] += b[r]; }
+    }
+    long orow = m;
+    if (p.row_map) {
+      orow = p.row_map[m];
+      if (orow < 0) return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gg = g[r] + (p.bias ? p.bias[ng + r] : 0.f), uu = u[r] + (p.bias ? p.bias[ng + 16 + r] : 0.f);
+      const float x = gg * __builtin_amdgcn_rcpf(1.0f + __expf(-gg)) * uu;
+      if (p.out_f32) reinterpret_cast<float*>(p.C)[orow * p.ldc + n + r] = x;
+      else reinterpret_cast<bf16_t*>(p.C)[orow * p.ldc + n + r] = f32_to_bf16(x);
+    }
+    return;
+  }
   const int n4 = (p.N + 3) / 4;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)p.M * n4) return;
@@ -1056,7 +1087,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   // 64-step K loop each on 96 CUs: 62 us; 4 slices: 384 workgroups x 16 steps). Each slice is a "batch" of the batched
   // launch — operands offset by slice * K/ks along K, fp32 partial tile into ws[slice][M][N] — and skinny_reduce_kernel
   // adds the slices in index order and applies the epilogue: deterministic.
-  if (tile_cfg == 0 && workspace && !ln_stats && !swiglu && M > 64 && (K % BK) == 0) {
+  if (tile_cfg == 0 && workspace && !ln_stats && M > 32 && (K % BK) == 0) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int ksteps = K / BK;
     int ks = 0;
@@ -1066,13 +1097,13 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
     if (ks) {
       GemmArgs q = p;
       q.C = workspace; q.ldc = N; q.bias = nullptr; q.resid = nullptr; q.ldr = 0; q.row_map = nullptr;
-      q.K = K / ks; q.act = 0; q.out_f32 = 1;
+      q.K = K / ks; q.act = 0; q.out_f32 = 1; q.swiglu = 0;   // raw interleaved columns: the reduce kernel pairs them
       q.nb_inner = ks; q.sAo = 0; q.sWo = 0; q.sCo = 0; q.sAi = q.K; q.sWi = q.K; q.sCi = (long)M * N;
       const int rc = launch_gemm<128, 128, 2, 2>(q, s, ks);
       if (rc) return rc;
       p.ws = reinterpret_cast<float*>(workspace);
       p.ksplit = ks;
-      const long n_thr = (long)M * ((N + 3) / 4);
+      const long n_thr = swiglu ? (long)M * (N / 8) : (long)M * ((N + 3) / 4);
       hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, p);
       return haff_check_launch();
     }

@@ -117,14 +117,14 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
                                        w.stride(0), out.data_ptr(), out.stride(0), _p(bias), _p(resid),
                                        0 if resid is None else resid.stride(0), _p(row_map), M, N, K, act,
                                        1 if out.dtype == torch.float32 else 0, 1 if swiglu else 0, _stream())
-    elif x.dtype == torch.bfloat16 and 32 < M <= 1024 and not swiglu and not tile_cfg:
+    elif x.dtype == torch.bfloat16 and 32 < M <= 1024 and not tile_cfg:
         # few output tiles (decode at batch 33..64 on narrow weights, prefill / CLIP at one frame): the library may split K
         # over workgroups through a per-stream fp32 workspace (partials summed in a fixed order)
         assert w.dtype == torch.bfloat16
         ws = _workspace(x.device, 64 << 20)
         rc = lib.haff_gemm_bf16_ws(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
                                    _p(bias), _p(resid), 0 if resid is None else resid.stride(0), _p(row_map), M, N, K, act,
-                                   1 if out.dtype == torch.float32 else 0, 0, ws.data_ptr(), ws.numel(), _stream())
+                                   1 if out.dtype == torch.float32 else 0, 1 if swiglu else 0, ws.data_ptr(), ws.numel(), _stream())
     elif x.dtype == torch.bfloat16:
         assert w.dtype == torch.bfloat16
         rc = lib.haff_gemm_bf16_cfg(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),

@@ -122,6 +122,27 @@ def test_gemm_bf16_split_k_tiles(dev, M, N, K):
         _close(ops.linear(xs, w, out_dtype=torch.float32), xs.float() @ w.float().T, 2e-3, "split-K strided A")
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 22016, 4096), (40, 16384, 4096), (100, 2048, 4096), (64, 32000, 4096)])
+def test_gemm_bf16_split_k_swiglu(dev, M, N, K):
+    """33..64-row products on very wide weights (batch-64 decode gate/up, lm_head) and SwiGLU products with few tiles: K
+    slices of the 128x128 tile, (gate, up) pairs formed in the reduce kernel. Against the fp32 reference and the unsplit tile."""
+    ops = _ops()
+    x = _rand((M, K), dev, torch.bfloat16, 51)
+    w = _rand((N, K), dev, torch.bfloat16, 52, K ** -0.5)
+    F_ = N // 2
+    wi = torch.stack([w[:F_].reshape(F_ // 16, 16, K), w[F_:].reshape(F_ // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+    y = x.float() @ w.float().T
+    ref = F.silu(y[:, :F_]) * y[:, F_:]
+    got = ops.linear(x, wi, swiglu=True)
+    _close(got, ref, 1.5e-2, "split-K swiglu")
+    assert torch.equal(got, ops.linear(x, wi, swiglu=True))
+    _close(got, ops.linear(x, wi, swiglu=True, tile_cfg=1).float(), 1.2e-2, "split vs unsplit swiglu")
+    got32 = ops.linear(x, wi, swiglu=True, out_dtype=torch.float32)
+    _close(got32, ref, 3e-3, "split-K swiglu f32 out")
+    plain = ops.linear(x, w, out_dtype=torch.float32)     # the same shapes without SwiGLU (lm_head-like)
+    _close(plain, y, 2e-3, "split-K wide plain")
+
+
 @pytest.mark.parametrize("tile_cfg", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 1003, 256), (300, 520, 64), (1111, 256, 1280)])
 def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
