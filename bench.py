@@ -327,6 +327,7 @@ def main(argv=None):
     ap.add_argument("--sam-chunk", type=int, default=32)
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
+    ap.add_argument("--fold-norms", action="store_true", help="SAM blocks: LayerNorm carried into the qkv / lin1 products (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
@@ -344,7 +345,11 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
     sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
+    if args.fold_norms:
+        cfg.sam.fold_norms = True
     model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=device, sam_chunk=args.sam_chunk)
+    if args.fold_norms:
+        model.sam_encoder.fold_norms = True
     model.overlap_streams = not args.single_stream
     del sd
     torch.cuda.empty_cache()
