@@ -315,6 +315,11 @@ class SamPromptDecoderHip:
         self.no_mask = sd[P + ".no_mask_embed.weight"].reshape(1, C).to(device, dtype).contiguous()
         self.left = SamDecoderSideHip(sd, V + ".mask_decoder_left", cfg, dtype, device, True)
         self.right = SamDecoderSideHip(sd, V + ".mask_decoder_right", cfg, dtype, device, False)
+        # a handful of prompts: the two decoders are two independent chains of ~70 latency-bound launches each; they run
+        # side by side on two HIP streams (inside the tail's hipGraph: two parallel branches). Many prompts fill the chip
+        # per launch and stay on one stream.
+        self.pair_streams = True
+        self._pair_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
     def decode(self, emb, frame_idx, text, taps=None):
         """emb [Bf, N, C]; frame_idx int64 [P] (prompt -> frame); text [P, C]."""
@@ -322,6 +327,20 @@ class SamPromptDecoderHip:
         N, C = emb.shape[1], emb.shape[2]
         src = emb.index_select(0, frame_idx).reshape(P * N, C).to(self.dtype)
         src = ops.add_bcast(src, self.no_mask, mod=1).view(P, N, C)
+        if self.pair_streams and self._pair_stream is not None and P <= 8 and taps is None:
+            cur, side = torch.cuda.current_stream(self.device), self._pair_stream
+            capturing = torch.cuda.is_current_stream_capturing()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                lo_r, iou_r, _ = self.right(src, self.key_pe, text, self.cfg.grid)
+            lo_l, iou_l, tax = self.left(src, self.key_pe, text, self.cfg.grid, taps)
+            cur.wait_stream(side)
+            if not capturing:   # allocator bookkeeping for tensors that crossed streams (graph pools need none)
+                for t in (src, text):
+                    t.record_stream(side)
+                for t in (lo_r, iou_r):
+                    t.record_stream(cur)
+            return lo_l, lo_r, tax, iou_l, iou_r
         lo_l, iou_l, tax = self.left(src, self.key_pe, text, self.cfg.grid, taps)
         lo_r, iou_r, _ = self.right(src, self.key_pe, text, self.cfg.grid)
         return lo_l, lo_r, tax, iou_l, iou_r
