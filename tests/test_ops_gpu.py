@@ -819,3 +819,43 @@ def test_kernels_stable_beside_second_stream(dev):
         torch.cuda.synchronize()
         bad = sum(int(not torch.equal(o, ref)) for o in outs)
         assert bad == 0, f"{name}: {bad}/40 launches differ with a second stream active"
+
+
+def test_decode_book_kernel(dev):
+    """haff_decode_book against the host loop it replaces (generate()'s per-token bookkeeping): forced vs greedy token,
+    finished rows emit pad, EOS sets the flag, out_ids / hidden rows land at each row's own position, positions advance."""
+    ops = _ops()
+    B, H, tmax, pad, eos = 5, 64, 24, 0, 2
+    i64, i32 = torch.int64, torch.int32
+    lens = torch.tensor([4, 7, 5, 6, 3], dtype=i64, device=dev)
+    t_rows = (lens + 9).to(i32)
+    for use_forced in (0, 1):
+        st = {"forced": torch.randint(3, 50, (B, tmax), dtype=i64, device=dev), "use_forced": torch.full((1,), use_forced, dtype=i32, device=dev),
+              "steps": torch.zeros((B,), dtype=i32, device=dev), "finished": torch.zeros((B,), dtype=torch.uint8, device=dev),
+              "out_ids": torch.full((B, tmax), pad, dtype=i64, device=dev), "lens": lens, "t_rows": t_rows,
+              "tok": torch.zeros((B,), dtype=i64, device=dev), "pos": torch.zeros((B,), dtype=i32, device=dev),
+              "nk": torch.zeros((B,), dtype=i32, device=dev), "hidden": torch.zeros((B, tmax, H), dtype=torch.bfloat16, device=dev)}
+        st["forced"][1, 2] = eos                      # row 1 ends at its third token when forced
+        ref_out = st["out_ids"].clone().cpu()
+        ref_hid = torch.zeros((B, tmax, H))
+        fin = [False] * B
+        g = torch.Generator().manual_seed(7 + use_forced)
+        for s_ in range(6):
+            nxt = torch.randint(3, 50, (B,), generator=g)
+            if s_ == 3:
+                nxt[3] = eos                          # row 3 ends at its fourth token when greedy
+            h1 = torch.randn((B, H), generator=g).to(torch.bfloat16)
+            ops.decode_book(nxt.to(dev), st, h1.to(dev) if s_ else None, pad, eos)
+            for b in range(B):
+                t = int(st["forced"][b, s_]) if use_forced else int(nxt[b])
+                if fin[b]:
+                    t = pad
+                ref_out[b, int(lens[b]) + s_] = t
+                fin[b] = fin[b] or t == eos
+                if s_ >= 1:
+                    ref_hid[b, int(t_rows[b]) + s_ - 1] = h1[b].float()
+                assert int(st["tok"][b]) == t and int(st["pos"][b]) == int(t_rows[b]) + s_ and int(st["nk"][b]) == int(t_rows[b]) + s_ + 1
+            assert st["finished"].cpu().bool().tolist() == fin and st["steps"].cpu().tolist() == [s_ + 1] * B
+        assert torch.equal(st["out_ids"].cpu(), ref_out) and torch.equal(st["hidden"].float().cpu(), ref_hid)
+        assert any(fin)
+
