@@ -84,6 +84,11 @@ int main() {
     }
   }
   for (int wgs : {1024, 2048}) run<8, true>(src, total, wgs, 4, 2048, clk);
+  // footprints between the 32 MiB of L2 and the 256 MiB memory-side cache: re-read every pass (MALL-resident after the first)
+  for (long win_kb : {256L, 512L, 768L, 1024L}) {
+    run<16, true>(src, total, 256, 4, win_kb, clk);
+    run<16, false>(src, total, 256, 4, win_kb, clk);
+  }
   // few workgroups streaming from HBM: what one CU can pull on misses, by bytes in flight
   for (int wgs : {32, 96, 128, 192}) {
     run<4, false>(src, total, wgs, 4, 16384, clk);
