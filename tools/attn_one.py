@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One attention shape for rocprofv3 --pmc passes. usage: attn_one.py B H N d S [iters]"""
+"""The SAM global-attention launch of the bench (32 frames x 16 heads, 4096 x 4096, d = 80, decomposed rel-pos) a few times —
+the target of rocprofv3 --pmc passes.  usage: attn_one.py [frames] [iters]"""
 import os
 import sys
 
@@ -9,16 +10,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import haff  # noqa
 from haff import ops
 
-B, H, N, d, S = (int(v) for v in sys.argv[1:6])
-iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device("cuda:0")
-qkv = torch.randn((B, N, 3, H, d), device=dev).to(torch.bfloat16)
+H, N, d, S = 16, 4096, 80, 64
+qkv = (torch.randn((B, N, 3, H, d), device=dev) * 0.5).to(torch.bfloat16)
 q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-relh = relw = None
-if S:
-    th = torch.randn((2 * S - 1, d), device=dev)
-    tw = torch.randn((2 * S - 1, d), device=dev)
-    relh, relw = ops.relpos_tables(q, th, tw, S)
+relh = torch.randn((B * H, N, S), device=dev) * 0.1
+relw = torch.randn((B * H, N, S), device=dev) * 0.1
 for _ in range(iters):
     ops.attention(q, k, v, d ** -0.5, relh=relh, relw=relw, S=S)
 torch.cuda.synchronize()
