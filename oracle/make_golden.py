@@ -104,6 +104,41 @@ def sam_goldens(ref, name, cfg, seed, n_prompts, input_size, original_size):
           "logit std %.3f" % lo_l.std().item())
 
 
+def sam_vith_golden(ref, name, seed):
+    """The reference's ImageEncoderViT at the REAL ViT-H block geometry (dim 1280, 16 heads of 80, mlp 5120, 14x14 windows on
+    the 64x64 grid of a 1024^2 frame -> 5x5 padded windows, rel-pos tables of (27, 80) / (127, 80)), depth cut to 2 (one
+    windowed + one global block), ONE frame. Output-only, and subsampled to stay small: every second position of every
+    second row of all 256 channels (1 MiB) + per-channel float64 sums over the full map + per-block (mean, std, |max|).
+    The input frame is not stored: the test regenerates it from the seed."""
+    import copy
+    cfg = copy.deepcopy(hcfg.haff_7b())
+    cfg.sam.depth, cfg.sam.global_idx = 2, (1,)
+    s = cfg.sam
+    shapes = {k: v for k, v in hw.sam_shapes(s).items() if ".image_encoder." in k}
+    sd = hw.make_state_dict(cfg, seed, shapes)
+    from functools import partial
+    enc = ref.ImageEncoderViT(
+        depth=s.depth, embed_dim=s.embed_dim, img_size=s.img_size, mlp_ratio=s.mlp_ratio,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=s.heads, patch_size=s.patch, qkv_bias=True,
+        use_rel_pos=True, global_attn_indexes=list(s.global_idx), window_size=s.window, out_chans=s.out_chans).eval()
+    pre = "model.visual_model.image_encoder."
+    missing, unexpected = enc.load_state_dict({k[len(pre):]: v for k, v in sd.items()}, strict=True)
+    rng = np.random.default_rng(seed + 1000)
+    x = torch.from_numpy(rng.standard_normal((1, 3, s.img_size, s.img_size), dtype=np.float32))
+    stats = {}
+    hooks = [blk.register_forward_hook(lambda m, a, o, i=i: stats.__setitem__(
+        f"block{i}", np.array([o.mean().item(), o.std().item(), o.abs().max().item()], dtype=np.float64)))
+        for i, blk in enumerate(enc.blocks)]
+    with torch.no_grad():
+        emb = enc(x)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, depth=s.depth, global_idx=np.array(s.global_idx),
+                        emb_sub=emb[:, :, ::2, ::2].numpy(), emb_channel_sums=emb.double().sum((0, 2, 3)).numpy(),
+                        emb_abs_sum=emb.double().abs().sum().item(), **{"stat_" + k: v for k, v in stats.items()})
+    print(name, "emb", tuple(emb.shape), "std %.4f" % emb.std().item(), {k: v.tolist() for k, v in stats.items()})
+
+
 def llama_golden(name, cfg, seed):
     from transformers import LlamaConfig, LlamaForCausalLM
     l = cfg.llm
@@ -208,6 +243,7 @@ def main():
     ref = load_ref_modeling()
     sam_goldens(ref, "sam_tiny", hcfg.tiny(), seed=11, n_prompts=2, input_size=(224, 168), original_size=(120, 90))
     sam_goldens(ref, "sam_mid", hcfg.mid(), seed=12, n_prompts=1, input_size=(320, 320), original_size=(320, 320))
+    sam_vith_golden(ref, "sam_vith_depth2", seed=15)
     llama_golden("llama_tiny", hcfg.tiny(), seed=13)
     clip_golden("clip_tiny", hcfg.tiny(), seed=14)
     host_goldens()

@@ -59,6 +59,35 @@ def test_sam_against_reference_modules(name, cfg):
     assert torch.equal((lo_l > 0)[safe], (ref > 0)[safe])
 
 
+def test_sam_vith_geometry_against_reference_modules():
+    """The oracle's image encoder at the REAL ViT-H block geometry (dim 1280, 16 x 80 heads, 14x14 windows on the 64x64 grid
+    with padding to 5x5 windows, rel-pos tables (27, 80) / (127, 80), one windowed + one global block, one 1024^2 frame)
+    against the reference's own ImageEncoderViT (oracle/make_golden.py::sam_vith_golden; fixture: subsampled output +
+    full-map channel sums + per-block statistics). This is the geometry tests/test_lisa_gpu.py's ViT-H-width tests and
+    bench.py's cpu_baseline lean on; the tiny / mid goldens stop at grid 20, window 7."""
+    import copy
+    g = _load("sam_vith_depth2")
+    cfg = copy.deepcopy(hcfg.haff_7b())
+    cfg.sam.depth, cfg.sam.global_idx = int(g["depth"]), tuple(int(v) for v in g["global_idx"])
+    s = cfg.sam
+    shapes = {k: v for k, v in hw.sam_shapes(s).items() if ".image_encoder." in k}
+    sd = hw.make_state_dict(cfg, int(g["seed"]), shapes)
+    rng = np.random.default_rng(int(g["seed"]) + 1000)
+    x = torch.from_numpy(rng.standard_normal((1, 3, s.img_size, s.img_size), dtype=np.float32))
+    taps = {}
+    with torch.no_grad():
+        emb = O.sam_image_encoder(sd, V + ".image_encoder", x, s, taps)
+    assert emb.shape == (1, 256, 64, 64)
+    assert _maxerr(emb[:, :, ::2, ::2], g["emb_sub"]) < 2e-4
+    sums = emb.double().sum((0, 2, 3))
+    assert (sums - _t(g["emb_channel_sums"])).abs().max().item() < 2e-2          # 4096 terms of O(1) per channel
+    assert abs(emb.double().abs().sum().item() - float(g["emb_abs_sum"])) < 1e-6 * float(g["emb_abs_sum"])
+    for i in range(s.depth):
+        t = taps[f"block{i}"]
+        st = g[f"stat_block{i}"]
+        assert abs(t.mean().item() - st[0]) < 1e-5 and abs(t.std().item() - st[1]) < 1e-5 and abs(t.abs().max().item() - st[2]) < 1e-3
+
+
 def test_llama_against_transformers():
     cfg = hcfg.tiny()
     g = _load("llama_tiny")
