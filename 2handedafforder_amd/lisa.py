@@ -334,8 +334,20 @@ class LisaMI355:
         if pred.shape[0] > 0:
             lo_l, lo_r, tax = self._decoder_tail(emb, frame_idx, pred)
         offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cpu().long().cumsum(0)]).tolist()
+        # frames of one size (a batch of equally sized frames: the throughput case): ONE postprocess launch per hand over all
+        # prompts, sliced per frame below, instead of two launches per frame
+        same = pred.shape[0] > 0 and all(tuple(r) == tuple(resize_list[0]) for r in resize_list) and \
+            all(tuple(o) == tuple(original_size_list[0]) for o in original_size_list)
+        if same:
+            post_l = self.sam_decoder.postprocess(lo_l.contiguous(), resize_list[0], original_size_list[0])
+            post_r = self.sam_decoder.postprocess(lo_r.contiguous(), resize_list[0], original_size_list[0])
         for i in range(B):
             a, b = offs[i], offs[i + 1]
+            if same and b > a:
+                pred_masks_left.append(post_l[a:b])
+                pred_masks_right.append(post_r[a:b])
+                taxonomies.append(tax[a:b])
+                continue
             if b == a:
                 h0, w0 = original_size_list[i]
                 pred_masks_left.append(torch.empty((0, h0, w0), dtype=torch.float32, device=self.device))
