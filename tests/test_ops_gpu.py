@@ -122,7 +122,8 @@ def test_gemm_bf16_split_k_tiles(dev, M, N, K):
         _close(ops.linear(xs, w, out_dtype=torch.float32), xs.float() @ w.float().T, 2e-3, "split-K strided A")
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 22016, 4096), (40, 16384, 4096), (100, 2048, 4096), (64, 32000, 4096)])
+@pytest.mark.parametrize("M,N,K", [(64, 22016, 4096), (40, 16384, 4096), (100, 2048, 4096), (64, 32000, 4096), (288, 22016, 4096),
+                                   (320, 1024, 1024), (65, 4096, 256)])
 def test_gemm_bf16_split_k_swiglu(dev, M, N, K):
     """33..64-row products on very wide weights (batch-64 decode gate/up, lm_head) and SwiGLU products with few tiles: K
     slices of the 128x128 tile, (gate, up) pairs formed in the reduce kernel. Against the fp32 reference and the unsplit tile."""
