@@ -170,8 +170,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //   <128,128,2,2>: 256 threads, 64 KiB LDS, 2 workgroups/CU  — small / ragged problems
 //   <256,256,2,4>: 512 threads, 128 KiB LDS, 1 workgroup/CU  — half the L2->LDS bytes per MFMA (the 128^2 tile needs
 //                  ~64 B/clk/CU from L2 at full MFMA rate, more than the ~56 B/clk/CU the L2 can deliver)
-template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
+  static_assert(!PP || (BM == 256 && BN == 256 && WM == 2 && WN == 4), "the ping-pong ring loop is the 8-wave 256x256 tile");
   constexpr int NTHREADS = 64 * WM * WN;
   constexpr int A_ELEMS = BM * BK, W_ELEMS = BN * BK;
   constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;
@@ -296,12 +297,50 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     }
   };
 
+  // PP loop: a K-tile is staged as four 16 KiB QUARTERS (A rows 0-127 / 128-255, W rows 0-127 / 128-255 of the stage), two
+  // DMA instructions per wave each, so the request stream can be spread over the phases of the K loop.
+  auto stage_a_q = [&](int buf, int k0, auto half) {
+    if constexpr (OFF32) {
+      constexpr int H = decltype(half)::value;
+      bf16_t* sA = smem + buf * STAGE_ELEMS;
+      const bf16_t* a_base = p.A + k0;
+      asm volatile("" : "+s"(a_base));
+#pragma unroll
+      for (int i = 2 * H; i < 2 * H + 2; ++i) {
+        unsigned o = a_off[i];
+        asm volatile("" : "+v"(o));
+        const bf16_t* ga = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(a_base) + o);
+        bf16_t* la = sA + (i * NTHREADS + wave * 64) * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)la, 16, 0, 0);
+      }
+    }
+  };
+  auto stage_w_q = [&](int buf, int k0, auto half) {
+    if constexpr (OFF32) {
+      constexpr int H = decltype(half)::value;
+      bf16_t* sW = smem + buf * STAGE_ELEMS + A_ELEMS;
+      const bf16_t* w_base = p.W + k0;
+      asm volatile("" : "+s"(w_base));
+#pragma unroll
+      for (int i = 2 * H; i < 2 * H + 2; ++i) {
+        unsigned o = w_off[i];
+        asm volatile("" : "+v"(o));
+        const bf16_t* gw = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(w_base) + o);
+        bf16_t* lw = sW + (i * NTHREADS + wave * 64) * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)gw, (lptr_t)lw, 16, 0, 0);
+      }
+    }
+  };
+  using Q0 = std::integral_constant<int, 0>;
+  using Q1 = std::integral_constant<int, 1>;
+
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fh = lane >> 4;
   const int nk = (p.K + BK - 1) / BK;
 
   f32x4 acc[TN][TM];  // [ni][mi]
-  bf16x8 wf[2][TN], af[2][TM];  // fragments of one K-tile: [32-deep k-step][16-row tile]
+  bf16x8 wf[2][TN], af[2][TM];  // fragments of one K-tile: [32-deep k-step][16-row tile] (unused by the PP loop)
+  bf16x8 pa[2][4], pwl[2][2], pwh[2][2];   // PP loop: one half of the A fragments, both halves of the W fragments
   auto read_frags = [&](int buf, int ks) {
     const bf16_t* sA = smem + buf * STAGE_ELEMS;
     const bf16_t* sW = sA + A_ELEMS;
@@ -327,18 +366,149 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 
   int buf0 = 0;           // LDS buffer that holds K-tile 0 of the current tile
   bool first_tile = true;
+  if constexpr (PP) {     // K-tile 0 of the first tile; later tiles get theirs from the K loop of the tile before
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   for (;;) {              // tiles of this workgroup (one pass unless the grid was capped: persistent 8-wave tile)
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int m0e = m0, n0e = n0;                       // this tile's origin (the PP loop moves m0 / n0 on to the next tile)
+  const int tile_next = tile + (int)gridDim.x;
+  const bool has_next = (WM * WN == 8) && tile_next < nwg;
   // K loop, software-pipelined ACROSS the workgroup barrier. One barrier per K-tile: after it every wave's share of
   // tile kt+1 has landed and every wave is done reading tile kt-1's buffer, so the DMA of tile kt+2 may overwrite it
   // and has a whole K-tile of MFMAs to land. The second half of k-step 1's MFMAs (operands already in registers) is
   // held back and issued AFTER the barrier, where it keeps the MFMA pipe busy while the first fragments of the
   // next K-tile come back from LDS. (Measured alternatives, tools/gemm_variant.py: two barriers per K-tile -7 %,
   // no hold-back -4 %, an LDS-counter split barrier and a ping-pong wave schedule no better than this.)
-  if constexpr (WM * WN == 8) {
+  if constexpr (PP) {
+    // ---- ping-pong ring loop (round 3) ----
+    // The two wave groups (wm = 0: waves 0-3, wm = 1: waves 4-7; waves w and w+4 share a SIMD) run the same program ONE
+    // workgroup barrier apart: while one group multiplies a 64x32 quadrant of its 128x64 wave tile over the whole K-tile
+    // (16 MFMAs, operands in registers), the other reads its next fragments from LDS and issues its share of ONE 16 KiB
+    // quarter of a later K-tile. A K-tile is four phases:
+    //   phase 0: read W lo (4), A lo (8);  DMA A rows   0-127 of K-tile kt+1;  quadrant (A lo, W lo)
+    //   phase 1: read W hi (4);            DMA A rows 128-255 of K-tile kt+1;  quadrant (A lo, W hi)
+    //   phase 2: read A hi (8);            DMA W rows   0-127 of K-tile kt+2;  quadrant (A hi, W hi)
+    //   phase 3: (W lo is still held);     DMA W rows 128-255 of K-tile kt+2;  quadrant (A hi, W lo);  wait for K-tile kt+1
+    // The request stream never drains: the one wait per K-tile is COUNTED (s_waitcnt vmcnt(4): the two W quarters of
+    // K-tile kt+2 stay in flight across the barriers), every quarter has 5 to 12 barrier intervals (>= 1.3k cycles) to
+    // land, and a wave issues two DMA instructions per phase instead of eight in a burst. Counted waits over LDS-DMA are
+    // safe: the operations leave vmcnt in issue order (tools/probes/vmcnt_order_probe.hip); what bit round 1 was a
+    // write-after-read race (tools/vmcnt_forensics.py). Hazards of this schedule, in barrier intervals
+    // ("slots"; group g reads / issues in slot 8kt + 2q + g and multiplies in the next one):
+    //   RAW  every wave waits for its share of K-tile kt+1 in phase 3 of K-tile kt, BEFORE the barrier that closes that
+    //        slot; the first reads of K-tile kt+1 come at least one barrier later.
+    //   WAR  a quarter is requested only after a barrier that follows the last read of its previous content, and every
+    //        load section ends with an explicit s_waitcnt lgkmcnt(0) BEFORE its barrier (hipcc would otherwise sink the
+    //        wait below the barrier): W quarters are last read in phase 1 (slots 8kt+2, +3) and requested in phases 2, 3
+    //        (slots 8kt+4 ...), which is why W lo stays in registers for phase 3; A quarters of buffer cur^1 were last
+    //        read in phase 2 of K-tile kt-1.
+    // Tile boundary (persistent form): K-tile "nk" is K-tile 0 of the workgroup's next tile (staging coordinates move on
+    // at phase 2 of K-tile nk-2), K-tile "nk+1" is not requested — its buffer holds the epilogue's staging images — and
+    // its W quarters go out right after the epilogue, its A quarters in phases 0 and 1 as always.
+    auto read_a = [&](int buf, auto half) {
+      constexpr int H = decltype(half)::value;
+      const bf16_t* sA = smem + buf * STAGE_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fh;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ra = wm * (BM / WM) + (H * 4 + t) * 16 + fr;
+          pa[ks][t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
+        }
+      }
+    };
+    auto read_w = [&](int buf, bf16x8 (&dst)[2][2], auto half) {
+      constexpr int H = decltype(half)::value;
+      const bf16_t* sW = smem + buf * STAGE_ELEMS + A_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fh;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rw = wn * (BN / WN) + (H * 2 + t) * 16 + fr;
+          dst[ks][t] = *reinterpret_cast<const bf16x8*>(sW + rw * BK + ((c ^ (rw & 7)) << 3));
+        }
+      }
+    };
+    auto quad = [&](const bf16x8 (&wq)[2][2], auto ni0, auto mi0) {
+      constexpr int N0 = decltype(ni0)::value, M0 = decltype(mi0)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[N0 + j][M0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks][j], pa[ks][t], acc[N0 + j][M0 + t], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto close_load = [&]() {   // my LDS reads are DONE before the barrier (WAR), then the barrier; nothing moves across
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto close_mfma = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    // W quarters of K-tile 1 (the buffer was the previous tile's epilogue staging; the barrier behind that epilogue, or
+    // the one behind the first tile's prologue, has passed)
+    stage_w_q(buf0 ^ 1, BK, Q0{});
+    stage_w_q(buf0 ^ 1, BK, Q1{});
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = (kt & 1) ^ buf0;
+      const bool a_next = (kt + 1 < nk) || has_next;
+      const int a_k0 = (kt + 1 < nk) ? (kt + 1) * BK : 0;
+      const bool w_next = (kt + 2 < nk) || (kt + 2 == nk && has_next);
+      const int w_k0 = (kt + 2 < nk) ? (kt + 2) * BK : 0;
+      // phase 0
+      read_w(cur, pwl, Q0{});
+      read_a(cur, Q0{});
+      if (a_next) stage_a_q(cur ^ 1, a_k0, Q0{});
+      close_load();
+      quad(pwl, I0{}, I0{});
+      close_mfma();
+      // phase 1
+      read_w(cur, pwh, Q1{});
+      if (a_next) stage_a_q(cur ^ 1, a_k0, Q1{});
+      close_load();
+      quad(pwh, I2{}, I0{});
+      close_mfma();
+      // phase 2
+      if (kt + 2 == nk && has_next) {   // from here on the staging coordinates are the next tile's
+        tile_origin(tile_next, m0, n0);
+        stage_coords(m0, n0);
+      }
+      read_a(cur, Q1{});
+      if (w_next) stage_w_q(cur, w_k0, Q0{});
+      close_load();
+      quad(pwh, I2{}, I4{});
+      close_mfma();
+      // phase 3
+      if (w_next) {
+        stage_w_q(cur, w_k0, Q1{});
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K-tile kt+1 landed (my share); W of K-tile kt+2 stays in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      close_load();
+      quad(pwl, I0{}, I4{});
+      if (!(wm == 1 && kt == nk - 1)) close_mfma();   // group 1 gives back the barrier it took at the top
+    }
+  } else if constexpr (WM * WN == 8) {
 #ifndef HAFF_GEMM_HEAD
 #define HAFF_GEMM_HEAD (TM / 2)
 #endif
@@ -458,18 +628,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       }
     }
   }
-  __builtin_amdgcn_s_barrier();  // the epilogue reuses stage memory: every wave is done reading fragments
+  // the epilogue reuses stage memory: every wave is done reading fragments (PP: the loop's last barrier says so)
+  if constexpr (!PP) __builtin_amdgcn_s_barrier();
   HAFF_TRACE(2);
   // the buffer the last K-tile was read from takes the epilogue's staging images; the other one is idle: the next tile's
-  // first K-tile goes there now (8-wave persistent form)
+  // first K-tile goes there now (8-wave persistent form; the PP loop has requested AND waited for it already)
   const int ebuf = ((nk - 1) & 1) ^ buf0;
-  const int m0e = m0, n0e = n0;
-  const int tile_next = tile + (int)gridDim.x;
-  const bool has_next = (WM * WN == 8) && tile_next < nwg;
-  if (has_next) {
-    tile_origin(tile_next, m0, n0);
-    stage_coords(m0, n0);
-    stage(ebuf ^ 1, 0);
+  if constexpr (!PP) {
+    if (has_next) {
+      tile_origin(tile_next, m0, n0);
+      stage_coords(m0, n0);
+      stage(ebuf ^ 1, 0);
+    }
   }
 
   // ---- epilogue, staged through LDS so global traffic is whole 128-B row segments ----
@@ -674,6 +844,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   HAFF_TRACE(4);
 #endif
   if (!has_next) break;
+  if constexpr (PP) __builtin_amdgcn_s_barrier();   // every wave is past its epilogue: its staging buffer takes K-tile 1
   tile = tile_next;
   buf0 = ebuf ^ 1;
   first_tile = false;
@@ -1032,7 +1203,7 @@ static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
 
 }  // namespace
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PP = false>
 static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   int gx = tiles;
@@ -1042,11 +1213,11 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   }
   dim3 grid(gx, nbatch), block(64 * WM * WN);
   if (p.swiglu) {
-    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, PP>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true, PP>), grid, block, 0, s, p);
   } else {
-    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false, PP>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false, PP>), grid, block, 0, s, p);
   }
   return haff_check_launch();
 }
@@ -1111,7 +1282,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
   const bool big_ok = (K % BK == 0) && ((long)(a_map ? a_rows : M) * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
   if (tile_cfg == 3 && big_ok) return launch_gemm<256, 256, 2, 2>(p, s);
-  bool big = tile_cfg == 2 && big_ok;
+  bool big = (tile_cfg == 2 || tile_cfg == 4) && big_ok;
   if (tile_cfg == 0 && big_ok) {
     // Pick the tile by wave-quantisation efficiency (tiles / slots rounded up) times the measured per-tile
     // advantage of the 256^2 kernel (tools/gemm_bench.py: ~1.2x at equal quantisation): 128^2 runs 2
@@ -1140,10 +1311,13 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
 #ifndef HAFF_GEMM_NO_NT
   p.nt_out = (long)M * (swiglu ? N / 2 : N) * (out_f32 ? 4 : 2) >= (64L << 20);
 #endif
+  // the ping-pong ring loop needs two K-tiles; tile_cfg 4 keeps the one-barrier-per-K-tile loop of rounds 1-2 for A/B runs
+  if (big && tile_cfg != 4 && K >= 2 * BK) return launch_gemm<256, 256, 2, 4, true>(p, s);
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
 
-// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (8 waves), 3 = force 256x256 (4 waves) (for A/B measurements)
+// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (8 waves, ping-pong ring loop), 3 = force 256x256 (4 waves),
+// 4 = force 256x256 (8 waves, the drained double-buffer loop of rounds 1-2) (for A/B measurements)
 extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                                   const float* bias, const void* resid, long ldr, const int* row_map,
                                   int M, int N, int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {

@@ -144,11 +144,12 @@ def test_gemm_bf16_split_k_swiglu(dev, M, N, K):
     _close(plain, y, 2e-3, "split-K wide plain")
 
 
-@pytest.mark.parametrize("tile_cfg", [1, 2, 3])
+@pytest.mark.parametrize("tile_cfg", [1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 1003, 256), (300, 520, 64), (1111, 256, 1280)])
 def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
-    """Every tile of the template (128^2 / 4 waves, 256^2 / 8 waves, 256^2 / 4 waves with 128-column wave tiles) through
-    every epilogue feature, ragged edges included; the auto heuristic only picks the big tiles on large problems."""
+    """Every tile of the template (128^2 / 4 waves, 256^2 / 8 waves with the ping-pong ring loop (2) and with the drained
+    double-buffer loop (4), 256^2 / 4 waves with 128-column wave tiles) through every epilogue feature, ragged edges
+    included; the auto heuristic only picks the big tiles on large problems."""
     ops = _ops()
     x = _rand((M, K), dev, torch.bfloat16, 11)
     w = _rand((N, K), dev, torch.bfloat16, 12, K ** -0.5)
@@ -741,30 +742,60 @@ def test_upscale_mask_and_resize(dev, dtype):
     assert torch.equal(th, ((crop > 0).to(torch.uint8) * 255))
 
 
-@pytest.mark.parametrize("tile_cfg", [1, 2, 3])
-def test_gemm_stable_beside_second_stream(dev, tile_cfg):
-    """Regression for the counted-vmcnt race of the 128x128 tile: a GEMM on structured operands (every
-    K-tile of A holds one small integer, W is all ones: the fp32 result is exact, any stale K fragment is an exact
-    multiple of 16) launched repeatedly while (LayerNorm, qkv GEMM) pairs run on another HIP stream must return the
-    same bits every time. Before the fix 5-10 % of the 128x128 launches differed."""
+@pytest.mark.parametrize("tile_cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("M", [592, 4400])
+def test_gemm_stable_beside_second_stream(dev, tile_cfg, M):
+    """Regression for the LDS staging races of the tile loops: a GEMM on structured operands (K-tile kt of
+    A holds kt + 1, W is all ones: the fp32 result is exact; a fragment that still holds K-tile kt-2 lowers an output by a
+    multiple of 16, one that already holds K-tile kt+2 raises it) launched repeatedly while (LayerNorm, qkv GEMM) pairs
+    run on another HIP stream must return the same bits every time. Round 1's 128x128 loop failed 5-10 % of its launches
+    here (a write-after-read race: tools/vmcnt_forensics.py). M = 4400: 288 tiles of 256^2 on 256 workgroups, so the
+    persistent ring loop crosses a tile boundary with its requests in flight."""
     ops = _ops()
     k = torch.arange(4096, device=dev)
-    a = (1 + (k // 64) % 4).to(torch.bfloat16)[None, :].expand(592, 4096).contiguous()
+    a = (1 + k // 64).to(torch.bfloat16)[None, :].expand(M, 4096).contiguous()
     w = torch.ones(4096, 4096, dtype=torch.bfloat16, device=dev)
     x = _rand((9800, 1280), dev, torch.bfloat16, 31)
     wq = _rand((3840, 1280), dev, torch.bfloat16, 32, 1280 ** -0.5)
     lw, lb = torch.ones(1280, device=dev), torch.zeros(1280, device=dev)
     ref = ops.linear(a, w, tile_cfg=tile_cfg, out_dtype=torch.float32).clone()
-    assert float(ref.min()) == float(ref.max()) == 64.0 * 16 * (1 + 2 + 3 + 4)
+    assert float(ref.min()) == float(ref.max()) == 64.0 * (64 * 65 // 2)
     side = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(60):
             ops.linear(ops.layernorm(x, lw, lb, 1e-6), wq)
-    outs = [ops.linear(a, w, tile_cfg=tile_cfg, out_dtype=torch.float32) for _ in range(200)]
+    n_rep = 200 if M < 1000 else 60
+    outs = [ops.linear(a, w, tile_cfg=tile_cfg, out_dtype=torch.float32) for _ in range(n_rep)]
     torch.cuda.synchronize()
     bad = sum(int(not torch.equal(o, ref)) for o in outs)
-    assert bad == 0, f"{bad}/200 launches differ with a second stream active"
+    assert bad == 0, f"{bad}/{n_rep} launches differ with a second stream active"
+
+
+@pytest.mark.parametrize("M,N,K", [(4400, 4100, 128), (4352, 4096, 192), (8192, 2304, 320), (70000, 1280, 1280), (2100, 33000, 256)])
+def test_gemm_ring_loop_across_tiles(dev, M, N, K):
+    """The persistent ping-pong ring loop of the 8-wave tile (tile_cfg 2): more than 256 tiles, so workgroups walk 2+ tiles
+    and the K-tile stream runs across the tile boundary (K-tile 0 of the next tile is requested from inside the K loop);
+    short K loops (2, 3, 5 K-tiles: every prologue / tail case of the request schedule), a gathered A operand, a row map
+    and a residual. Against the fp32 product and bit-for-bit against the 128x128 tile, whose loop shares nothing with it."""
+    ops = _ops()
+    x = _rand((M, K), dev, torch.bfloat16, 21)
+    w = _rand((N, K), dev, torch.bfloat16, 22, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 23)
+    y = x.float() @ w.float().T + bias
+    got = ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=2)
+    _close(got, y, 2e-3, "ring loop f32 out")
+    assert torch.equal(got, ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=1)), "ring loop vs 128x128 tile"
+    assert torch.equal(got, ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=4)), "ring loop vs drained loop"
+    if M * N < 100_000_000:
+        resid = _rand((M, N), dev, torch.bfloat16, 24)
+        amap = torch.randperm(M, device=dev).to(torch.int32)
+        rmap = torch.randperm(M, device=dev).to(torch.int32)
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+        ops.linear(x, w, bias=bias, resid=resid, a_map=amap, row_map=rmap, out=out, tile_cfg=2)
+        ref = torch.zeros((M, N), dtype=torch.float32, device=dev)
+        ref[rmap.long()] = y[amap.long()] + resid.float()[rmap.long()]
+        _close(out, ref, 1.2e-2, "ring loop gather + row map + residual")
 
 
 def test_kernels_stable_beside_second_stream(dev):
