@@ -437,36 +437,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         }
       }
     };
-    auto quad = [&](const bf16x8 (&wq)[2][2], auto ni0, auto mi0) {
-      constexpr int N0 = decltype(ni0)::value, M0 = decltype(mi0)::value;
-      __builtin_amdgcn_s_setprio(1);
+#ifndef HAFF_PP_HEAD
+#define HAFF_PP_HEAD 0
+#endif
+    constexpr int HEAD = HAFF_PP_HEAD;   // MFMAs of a cluster issued BEFORE the barrier that opens its slot (they touch no LDS)
+    // one 64x32 quadrant over the K-tile: 16 MFMAs, [first, last) of them issued here
+    auto quad = [&](const bf16x8 (&wq)[2][2], auto ni0, auto mi0, auto first, auto last) {
+      constexpr int N0 = decltype(ni0)::value, M0 = decltype(mi0)::value, F = decltype(first)::value, L = decltype(last)::value;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[N0 + j][M0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks][j], pa[ks][t], acc[N0 + j][M0 + t], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+          for (int j = 0; j < 2; ++j) {
+            const int idx = (ks * 4 + t) * 2 + j;
+            if (idx >= F && idx < L)
+              acc[N0 + j][M0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks][j], pa[ks][t], acc[N0 + j][M0 + t], 0, 0, 0);
+          }
+    };
+    auto slot_barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     };
     auto close_load = [&]() {   // my LDS reads are DONE before the barrier (WAR), then the barrier; nothing moves across
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto close_mfma = [&]() {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+      slot_barrier();
     };
     using I0 = std::integral_constant<int, 0>;
     using I2 = std::integral_constant<int, 2>;
     using I4 = std::integral_constant<int, 4>;
+    using I16 = std::integral_constant<int, 16>;
+    using IHD = std::integral_constant<int, HEAD>;
     // W quarters of K-tile 1 (the buffer was the previous tile's epilogue staging; the barrier behind that epilogue, or
     // the one behind the first tile's prologue, has passed)
     stage_w_q(buf0 ^ 1, BK, Q0{});
     stage_w_q(buf0 ^ 1, BK, Q1{});
+    HAFF_TRACE(1);
     if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = (kt & 1) ^ buf0;
@@ -474,39 +481,58 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       const int a_k0 = (kt + 1 < nk) ? (kt + 1) * BK : 0;
       const bool w_next = (kt + 2 < nk) || (kt + 2 == nk && has_next);
       const int w_k0 = (kt + 2 < nk) ? (kt + 2) * BK : 0;
-      // phase 0
-      read_w(cur, pwl, Q0{});
-      read_a(cur, Q0{});
-      if (a_next) stage_a_q(cur ^ 1, a_k0, Q0{});
-      close_load();
-      quad(pwl, I0{}, I0{});
-      close_mfma();
-      // phase 1
-      read_w(cur, pwh, Q1{});
-      if (a_next) stage_a_q(cur ^ 1, a_k0, Q1{});
-      close_load();
-      quad(pwh, I2{}, I0{});
-      close_mfma();
-      // phase 2
+#ifdef HAFF_EXP_NODMA     // timing experiments only (results are wrong): no operand requests / no fragment reads in the loop
+#define PP_DMA(x) do {} while (0)
+#else
+#define PP_DMA(x) x
+#endif
+#ifdef HAFF_EXP_NOREAD
+#define PP_READ(x) do { if (kt == 0) { x; } } while (0)
+#else
+#define PP_READ(x) x
+#endif
+      // ---- load slot A: W lo, W hi, A lo; requests for the A quarters of K-tile kt+1 ----
+      PP_READ(read_w(cur, pwl, Q0{}));
+      PP_READ(read_a(cur, Q0{}));
+      PP_READ(read_w(cur, pwh, Q1{}));
+      if (a_next) {
+        PP_DMA(stage_a_q(cur ^ 1, a_k0, Q0{}));
+        PP_DMA(stage_a_q(cur ^ 1, a_k0, Q1{}));
+      }
+      // ---- multiply slot A: quadrants (A lo, W lo), (A lo, W hi); the first HEAD MFMAs go out BEFORE the barrier that opens
+      // the slot, beside the last MFMAs of the SIMD partner's cluster, so the matrix pipe does not idle over the barrier ----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads are DONE before the barrier (WAR)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      quad(pwl, I0{}, I0{}, I0{}, IHD{});
+      slot_barrier();
+      quad(pwl, I0{}, I0{}, IHD{}, I16{});
+      quad(pwh, I2{}, I0{}, I0{}, I16{});
+      __builtin_amdgcn_s_setprio(0);
+      slot_barrier();
+      // ---- load slot B: A hi; requests for the W quarters of K-tile kt+2; the wait for K-tile kt+1 ----
       if (kt + 2 == nk && has_next) {   // from here on the staging coordinates are the next tile's
         tile_origin(tile_next, m0, n0);
         stage_coords(m0, n0);
       }
-      read_a(cur, Q1{});
-      if (w_next) stage_w_q(cur, w_k0, Q0{});
-      close_load();
-      quad(pwh, I2{}, I4{});
-      close_mfma();
-      // phase 3
+      PP_READ(read_a(cur, Q1{}));
       if (w_next) {
-        stage_w_q(cur, w_k0, Q1{});
+        PP_DMA(stage_w_q(cur, w_k0, Q0{}));
+        PP_DMA(stage_w_q(cur, w_k0, Q1{}));
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K-tile kt+1 landed (my share); W of K-tile kt+2 stays in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      close_load();
-      quad(pwl, I0{}, I4{});
-      if (!(wm == 1 && kt == nk - 1)) close_mfma();   // group 1 gives back the barrier it took at the top
+      // ---- multiply slot B: quadrants (A hi, W hi), (A hi, W lo) ----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      quad(pwh, I2{}, I4{}, I0{}, IHD{});
+      slot_barrier();
+      quad(pwh, I2{}, I4{}, IHD{}, I16{});
+      quad(pwl, I0{}, I4{}, I0{}, I16{});
+      __builtin_amdgcn_s_setprio(0);
+      if (!(wm == 1 && kt == nk - 1)) slot_barrier();   // group 1 gives back the barrier it took at the top
     }
   } else if constexpr (WM * WN == 8) {
 #ifndef HAFF_GEMM_HEAD

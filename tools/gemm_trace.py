@@ -30,8 +30,8 @@ SHAPES = [
 
 def main():
     dev = torch.device("cuda:0")
-    for cfg in (2, 1):
-        bm = 256 if cfg == 2 else 128
+    for cfg in [int(c) for c in os.environ.get("CFGS", "2,4,1").split(",")]:
+        bm = 128 if cfg == 1 else 256
         for name, M, N, K, kind in SHAPES:
             x = torch.randn((M, K), device=dev).to(torch.bfloat16)
             w = (torch.randn((N, K), device=dev) * K ** -0.5).to(torch.bfloat16)
@@ -48,13 +48,15 @@ def main():
             torch.cuda.synchronize()
             tiles = ((M + bm - 1) // bm) * ((N + bm - 1) // bm)
             nb = min(tiles, 8192)
+            if cfg != 1:   # persistent 8-wave tile: one record per workgroup (its LAST tile)
+                nb = min(nb, int(os.environ.get("HAFF_GEMM_PERSIST", "256")) or nb)
             buf = np.zeros(nb * 8, dtype=np.uint64)
             assert lib.haff_gemm_trace_read(buf.ctypes.data, nb * 8) == 0
             t = buf.reshape(nb, 8).astype(np.int64)
             d = np.diff(t[:, :5], axis=1) / 100.0  # us
             med = np.median(d, axis=0)
             span = (t[:, 4].max() - t[:, 0].min()) / 100.0
-            per_slot = (512 if cfg == 1 else 256)
+            per_slot = min(nb, 512 if cfg == 1 else 256)
             first = t[:per_slot]
             print(f"cfg{cfg} {name:24s} tiles {tiles:5d} | load {med[0]:6.2f} kloop {med[1]:6.2f} epi-issue {med[2]:6.2f} "
                   f"drain {med[3]:6.2f} us | tile total {np.median(t[:, 4] - t[:, 0]) / 100.0:6.2f} | "

@@ -26,8 +26,9 @@ def main():
     libs = {n: load(n) for n in names}
     dev = torch.device("cuda:0")
     for M, N, K in SHAPES:
-        x = torch.randn((M, K), device=dev).to(torch.bfloat16)
-        w = (torch.randn((N, K), device=dev) * K ** -0.5).to(torch.bfloat16)
+        pad = int(os.environ.get("LDPAD", "0"))   # row stride of both operands = K + pad elements (L2 channel experiments)
+        x = torch.randn((M, K + pad), device=dev).to(torch.bfloat16)
+        w = (torch.randn((N, K + pad), device=dev) * K ** -0.5).to(torch.bfloat16)
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         act = int(os.environ.get("ACT", "0"))
         bias = torch.randn((N,), device=dev) if act else None
@@ -40,7 +41,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    rc = libs[n].haff_gemm_bf16_cfg(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N,
+                    rc = libs[n].haff_gemm_bf16_cfg(x.data_ptr(), K + pad, w.data_ptr(), K + pad, out.data_ptr(), N,
                                                     bias.data_ptr() if act else None,
                                                     resid.data_ptr() if resid is not None else None, N if resid is not None else 0,
                                                     None, M, N, K, act, 0, 0, cfg_id, None)
