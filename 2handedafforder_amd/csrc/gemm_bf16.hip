@@ -163,6 +163,15 @@ __device__ __forceinline__ void store8_c(float* p, const float (&v)[8], bool nt)
   }
 }
 
+// v_permlane16_swap_b32: lanes 16..31 of x trade places with lanes 0..15 of y, lanes 48..63 of x with lanes 32..47 of y
+// (checked on MI355X). Inline asm, not __builtin_amdgcn_permlane16_swap: with float operands hipcc (ROCm 7.2) used the
+// builtin's FIRST result where the second was asked for (every second group of four output columns came out wrong).
+// The s_nop pair covers the VALU-write -> permlane-read and permlane-write -> VALU-read wait states the compiler would
+// otherwise insert itself (it pads nothing around inline asm).
+__device__ __forceinline__ void permlane16_swap(unsigned& x, unsigned& y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -211,6 +220,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     const int in_g = lin - g * per_group;
     tm0 = (first_m + in_g % gsz) * BM;
     tn0 = (in_g / gsz) * BN;
+#ifdef HAFF_EXP_SAMETILE   // timing experiment: every workgroup computes tile (0, 0): all operand bytes come from L2
+    tm0 = 0; tn0 = 0;
+#endif
   };
   // The 8-wave tile is PERSISTENT when the launcher caps the grid (one workgroup per CU): a workgroup takes tiles
   // blockIdx.x, blockIdx.x + gridDim.x, ... (same XCD, consecutive waves of its raster), and the first K-tile of the next
@@ -730,6 +742,161 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     const int m = m_wave + h * 64 + lane;
     orow_l[h] = m < p.M ? (p.row_map ? p.row_map[m] : m) : -1;
   }
+#ifndef HAFF_EPI_LDS   // -DHAFF_EPI_LDS: every tile through the LDS-staged epilogue below (A/B runs)
+  // ---- register epilogue (interior tiles, 16-B aligned rows) ----
+  // The swapped MFMA orientation leaves 4 consecutive output columns of ONE row in each lane (chunk c = 16-column
+  // group, columns 16c + 4fh .. +3). Two neighbouring chunks are made into 8 consecutive columns per lane by ONE
+  // v_permlane16_swap per register (lanes 16 apart trade halves: lane fh even keeps chunk 2j and receives the next four
+  // columns of it from lane fh+1, which receives chunk 2j+1's previous four in return), so a lane stores 16 B and the
+  // four lanes of a row cover 64 contiguous bytes of it: no LDS round trip, no wave barriers, no dependent
+  // write -> read -> store chain per pass. (Measured on the LDS-staged form: its stores cost 8 % of a K = 1280 launch, the
+  // staging around them 20 %: tools/gemm_variant.py nostore / noepi.)
+  if (fast) {
+    // ALL = every row of the wave tile is written (no row map, not the ragged last M-tile): the loads and stores below are
+    // then unconditional, which lets hipcc wait for a prefetched residual with a COUNTED vmcnt (behind an exec-masked
+    // store it falls back to vmcnt(0): every pass would drain the previous pass's stores first).
+    auto reg_epilogue = [&](auto all_tag) {
+    constexpr bool ALL = decltype(all_tag)::value;
+    constexpr int NCH = SWIGLU ? TN / 2 : TN;   // 4-column chunks per lane per pass
+    const int coff = 16 * (fh & 1) + 4 * (fh & 2);   // first of this lane's 8 columns inside a chunk pair (bf16 output)
+    auto out_row = [&](int mi) -> int {
+      if constexpr (ALL) return m_wave + mi * 16 + fr;
+      else return __shfl(orow_l[(mi * 16) >> 6], (mi * 16 + fr) & 63);
+    };
+    // bf16 residual of pass mi + 1, requested before the stores of pass mi go out
+    uint4 rnext[NCH / 2 > 0 ? NCH / 2 : 1];
+    auto fetch_r = [&](int mi) {
+      const int orow = out_row(mi);
+#pragma unroll
+      for (int j = 0; j < NCH / 2; ++j) {
+        rnext[j] = uint4{0u, 0u, 0u, 0u};
+        if (ALL || orow >= 0)
+          rnext[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)orow * p.ldr + n_wave_out +
+                                                     32 * j + coff);
+      }
+    };
+    const bool pre = !OUT_F32 && p.resid;
+    if (pre) fetch_r(0);
+    // ALL: the lane's output address is affine in the pass index — one 64-bit base per tile and a scalar stride per pass
+    // instead of a 64-bit multiply-add chain per store (the epilogue is instruction-bound: two waves per SIMD, ~60 VALU
+    // per pass before this)
+    const char* c_lane = reinterpret_cast<const char*>(p.C) +
+                         ((long)(m_wave + fr) * p.ldc + n_wave_out + (OUT_F32 ? 4 * fh : coff)) * (OUT_F32 ? 4 : 2);
+    const long c_pass = 16L * p.ldc * (OUT_F32 ? 4 : 2);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      if (p.ln_stats) {   // rstd * (acc - mean * colsum) in place; bias / activation follow as usual
+        const float2 st = *reinterpret_cast<const float2*>(sStat + 2 * (mi * 16 + fr));
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          float cs[4];
+          load4(sCsum + ni * 16 + fh * 4, cs);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ni][mi][r] = (acc[ni][mi][r] - st.x * cs[r]) * st.y;
+        }
+      }
+      float val[NCH][4];
+      if constexpr (!SWIGLU) {
+        auto act_side = [&](auto tag) {   // the activation is resolved ONCE per pass (wave-uniform switch)
+          constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            if constexpr (ACT == HAFF_ACT_GELU) {
+              const haff_f2 a = gelu_pair(haff_f2{acc[ni][mi][0] + bias_r[ni][0], acc[ni][mi][1] + bias_r[ni][1]});
+              const haff_f2 b = gelu_pair(haff_f2{acc[ni][mi][2] + bias_r[ni][2], acc[ni][mi][3] + bias_r[ni][3]});
+              val[ni][0] = a[0]; val[ni][1] = a[1]; val[ni][2] = b[0]; val[ni][3] = b[1];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) val[ni][r] = gemm_act<ACT>(acc[ni][mi][r] + bias_r[ni][r]);
+            }
+          }
+        };
+        switch (p.act) {
+          case HAFF_ACT_GELU: act_side(std::integral_constant<int, HAFF_ACT_GELU>{}); break;
+          case HAFF_ACT_QUICK_GELU: act_side(std::integral_constant<int, HAFF_ACT_QUICK_GELU>{}); break;
+          case HAFF_ACT_RELU: act_side(std::integral_constant<int, HAFF_ACT_RELU>{}); break;
+          case HAFF_ACT_SILU: act_side(std::integral_constant<int, HAFF_ACT_SILU>{}); break;
+          default: act_side(std::integral_constant<int, HAFF_ACT_NONE>{}); break;
+        }
+      } else {
+#pragma unroll
+        for (int nj = 0; nj < TN / 2; ++nj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g = acc[2 * nj][mi][r] + bias_r[2 * nj][r];
+            const float u = acc[2 * nj + 1][mi][r] + bias_r[2 * nj + 1][r];
+            val[nj][r] = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u;
+          }
+      }
+      const int orow = out_row(mi);
+      if constexpr (OUT_F32) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (ALL || orow >= 0) {
+            const long o = n_wave_out + 16 * c + 4 * fh;
+            if (p.resid) {
+              float rr[4];
+              load4(reinterpret_cast<const float*>(p.resid) + (long)orow * p.ldr + o, rr);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) val[c][r] += rr[r];
+            }
+            haff_f32x4 q = {val[c][0], val[c][1], val[c][2], val[c][3]};
+            float* dst = ALL ? reinterpret_cast<float*>(const_cast<char*>(c_lane) + mi * c_pass) + 16 * c
+                             : reinterpret_cast<float*>(p.C) + (long)orow * p.ldc + o;
+            if (nt_out) __builtin_nontemporal_store(q, reinterpret_cast<haff_f32x4*>(dst));
+            else *reinterpret_cast<haff_f32x4*>(dst) = q;
+          }
+        }
+      } else {
+        uint4 rcur[NCH / 2 > 0 ? NCH / 2 : 1];
+#pragma unroll
+        for (int j = 0; j < NCH / 2; ++j) rcur[j] = rnext[j];
+        if (pre && mi + 1 < TM) fetch_r(mi + 1);
+#pragma unroll
+        for (int j = 0; j < NCH / 2; ++j) {
+          haff_u32x4 q;
+          if (p.resid) {   // the residual is added in fp32: trade fp32 registers, add, round once
+            float v8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              unsigned tx = __builtin_bit_cast(unsigned, val[2 * j][r]), ty = __builtin_bit_cast(unsigned, val[2 * j + 1][r]);
+              permlane16_swap(tx, ty);
+              v8[r] = __builtin_bit_cast(float, tx);
+              v8[4 + r] = __builtin_bit_cast(float, ty);
+            }
+            const unsigned w[4] = {rcur[j].x, rcur[j].y, rcur[j].z, rcur[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v8[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+              v8[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            }
+            q = haff_u32x4{pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]), pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7])};
+          } else {
+            unsigned x0 = pack_bf16x2(val[2 * j][0], val[2 * j][1]), y0 = pack_bf16x2(val[2 * j + 1][0], val[2 * j + 1][1]);
+            unsigned x1 = pack_bf16x2(val[2 * j][2], val[2 * j][3]), y1 = pack_bf16x2(val[2 * j + 1][2], val[2 * j + 1][3]);
+            permlane16_swap(x0, y0);
+            permlane16_swap(x1, y1);
+            q = haff_u32x4{x0, x1, y0, y1};
+          }
+#ifdef HAFF_EXP_NOSTORE   // timing experiment: everything but the global store
+          asm volatile("" ::"v"(q));
+#else
+          if (ALL || orow >= 0) {
+            bf16_t* dst = ALL ? reinterpret_cast<bf16_t*>(const_cast<char*>(c_lane) + mi * c_pass) + 32 * j
+                              : reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n_wave_out + 32 * j + coff;
+            if (nt_out) __builtin_nontemporal_store(q, reinterpret_cast<haff_u32x4*>(dst));
+            else *reinterpret_cast<haff_u32x4*>(dst) = q;
+          }
+#endif
+        }
+      }
+    }
+    };   // reg_epilogue
+    if (!p.row_map && m_wave + WROWS <= p.M) reg_epilogue(std::true_type{});
+    else reg_epilogue(std::false_type{});
+  } else
+#endif
+  {
   const int rb_r = lane / LPR, rb_c = (lane % LPR) * 8;   // read-back row within a step / first column
   const long n_out = n_wave_out + rb_c;
 
@@ -751,6 +918,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const bool pre_r = PREFETCH_R && fast && p.resid;
   if (pre_r) fetch_resid(0);
 
+#ifdef HAFF_EXP_NOEPI   // timing experiment: the accumulators are kept alive, nothing is written
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(acc[ni][mi]));
+#else
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     float* row = sEp + fr * RS + fh * 4;
@@ -836,7 +1009,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
                 v[2 * j + 1] += __builtin_bit_cast(float, w[j] & 0xffff0000u);
               }
             }
+#ifdef HAFF_EXP_NOSTORE   // timing experiment: everything but the global store
+            asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#else
             store8_c(reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n_out, v, nt_out);
+#endif
           }
         }
       }
@@ -864,6 +1041,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+#endif
+  }   // LDS-staged epilogue
   HAFF_TRACE(3);
 #ifdef HAFF_GEMM_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

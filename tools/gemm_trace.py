@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(HERE, "2handedafforder_amd", "lib", "libhaff_gemm_trace.so"))
+lib = ctypes.CDLL(os.path.join(HERE, "2handedafforder_amd", "lib", "libhaff_gemm_%s.so" % os.environ.get("TRACELIB", "trace")))
 vp, cl, ci = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
 lib.haff_gemm_bf16_cfg.argtypes = [vp, cl, vp, cl, vp, cl, vp, vp, cl, vp, ci, ci, ci, ci, ci, ci, ci, vp]
 lib.haff_gemm_bf16_cfg.restype = ci
