@@ -132,6 +132,15 @@ __device__ __forceinline__ haff_f2 gelu_pair(haff_f2 x) {
   return __builtin_elementwise_fma(hx, z * pz, hx);
 }
 
+#ifdef HAFF_GEMM_TRACE2  // fine timestamps (100 MHz wall clock) of waves 0 and 4 around the epilogue of a workgroup's LAST tile
+__device__ unsigned long long haff_gemm_trace2_buf[256 * 2 * 16];
+#define HAFF_TRACE2(i) do { if ((tid & 255) == 0 && blockIdx.x < 256 && blockIdx.y == 0) haff_gemm_trace2_buf[(blockIdx.x * 2 + (tid >> 8)) * 16 + (i)] = wall_clock64(); } while (0)
+extern "C" int haff_gemm_trace2_read(unsigned long long* host, int n_words) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(haff_gemm_trace2_buf), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : 1;
+}
+#else
+#define HAFF_TRACE2(i) do {} while (0)
+#endif
 #ifdef HAFF_GEMM_TRACE  // phase timestamps (100 MHz wall clock) of each workgroup's first tile, for tools/gemm_trace.py
 __device__ unsigned long long haff_gemm_trace_buf[8192 * 8];
 #define HAFF_TRACE(i) do { if (tid == 0 && blockIdx.x < 8192 && blockIdx.y == 0) haff_gemm_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
@@ -148,7 +157,9 @@ typedef float haff_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store8_c(bf16_t* p, const float (&v)[8], bool nt) {
   if (nt) {
     haff_u32x4 r = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    asm volatile("");   // keeps hipcc from merging this store with the plain one of the other branch (the hint would be dropped)
     __builtin_nontemporal_store(r, reinterpret_cast<haff_u32x4*>(p));
+    asm volatile("");
   } else {
     store8(p, v);
   }
@@ -156,8 +167,10 @@ __device__ __forceinline__ void store8_c(bf16_t* p, const float (&v)[8], bool nt
 __device__ __forceinline__ void store8_c(float* p, const float (&v)[8], bool nt) {
   if (nt) {
     haff_f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    asm volatile("");
     __builtin_nontemporal_store(a, reinterpret_cast<haff_f32x4*>(p));
     __builtin_nontemporal_store(b, reinterpret_cast<haff_f32x4*>(p + 4));
+    asm volatile("");
   } else {
     store8(p, v);
   }
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;             // 16x16 MFMA tiles per wave
   constexpr int WNC = BN / WN;                                    // columns per wave: 64, or 128 for the 4-wave 256^2 tile
   static_assert(WNC == 64 || WNC == 128, "wave tile width");
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS];  // [buf][A | W]
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS + (PP ? 512 : 0)];  // [buf][A | W] (+ PP: the tile's bias)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -483,6 +496,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     using IHD = std::integral_constant<int, HEAD>;
     // W quarters of K-tile 1 (the buffer was the previous tile's epilogue staging; the barrier behind that epilogue, or
     // the one behind the first tile's prologue, has passed)
+    // the tile's 256 bias values ride along as ONE more DMA instruction (wave 0), a whole K loop ahead of the epilogue that
+    // reads them from LDS: a global load issued there sat in front of pass 0 with its full latency exposed, once per tile
+    if (p.bias && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && wave == 0)
+      __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + n0 + lane * 4), (lptr_t)(smem + 2 * STAGE_ELEMS), 16, 0, 0);
     stage_w_q(buf0 ^ 1, BK, Q0{});
     stage_w_q(buf0 ^ 1, BK, Q1{});
     HAFF_TRACE(1);
@@ -669,6 +686,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   // the epilogue reuses stage memory: every wave is done reading fragments (PP: the loop's last barrier says so)
   if constexpr (!PP) __builtin_amdgcn_s_barrier();
   HAFF_TRACE(2);
+  HAFF_TRACE2(0);
   // the buffer the last K-tile was read from takes the epilogue's staging images; the other one is idle: the next tile's
   // first K-tile goes there now (8-wave persistent form; the PP loop has requested AND waited for it already)
   const int ebuf = ((nk - 1) & 1) ^ buf0;
@@ -704,7 +722,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const bool nt_out = p.nt_out != 0;
 
   float bias_r[TN][4];
-  if (p.bias && n_wave_in + WNC <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
+  if (!p.bias) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias_r[ni][r] = 0.f;
+  } else if (PP && n0e + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+    const float* sBias = reinterpret_cast<const float*>(smem + 2 * STAGE_ELEMS) + wn * WNC;   // staged at the top of the tile
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) load4(sBias + ni * 16 + fh * 4, bias_r[ni]);
+  } else if (n_wave_in + WNC <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) load4(p.bias + n_wave_in + ni * 16 + fh * 4, bias_r[ni]);
   } else {
@@ -755,8 +782,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     // ALL = every row of the wave tile is written (no row map, not the ragged last M-tile): the loads and stores below are
     // then unconditional, which lets hipcc wait for a prefetched residual with a COUNTED vmcnt (behind an exec-masked
     // store it falls back to vmcnt(0): every pass would drain the previous pass's stores first).
-    auto reg_epilogue = [&](auto all_tag) {
+    // RES = a bf16 residual is added: a compile-time property of the instance so that the plain epilogue carries no wait at
+    // all (a register copy of a "maybe loaded" value made hipcc drain vmcnt — every store of the previous pass — once per
+    // pass, in the LDS-staged epilogue of rounds 1-2 as well) and the residual one waits with a counted vmcnt.
+    auto reg_epilogue = [&](auto all_tag, auto res_tag) {
     constexpr bool ALL = decltype(all_tag)::value;
+    constexpr bool RES = decltype(res_tag)::value && !OUT_F32;
     constexpr int NCH = SWIGLU ? TN / 2 : TN;   // 4-column chunks per lane per pass
     const int coff = 16 * (fh & 1) + 4 * (fh & 2);   // first of this lane's 8 columns inside a chunk pair (bf16 output)
     auto out_row = [&](int mi) -> int {
@@ -775,8 +806,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
                                                      32 * j + coff);
       }
     };
-    const bool pre = !OUT_F32 && p.resid;
-    if (pre) fetch_r(0);
+    if constexpr (RES) fetch_r(0);
+    HAFF_TRACE2(1);
     // ALL: the lane's output address is affine in the pass index — one 64-bit base per tile and a scalar stride per pass
     // instead of a 64-bit multiply-add chain per store (the epilogue is instruction-bound: two waves per SIMD, ~60 VALU
     // per pass before this)
@@ -843,19 +874,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
             haff_f32x4 q = {val[c][0], val[c][1], val[c][2], val[c][3]};
             float* dst = ALL ? reinterpret_cast<float*>(const_cast<char*>(c_lane) + mi * c_pass) + 16 * c
                              : reinterpret_cast<float*>(p.C) + (long)orow * p.ldc + o;
-            if (nt_out) __builtin_nontemporal_store(q, reinterpret_cast<haff_f32x4*>(dst));
-            else *reinterpret_cast<haff_f32x4*>(dst) = q;
+            *reinterpret_cast<haff_f32x4*>(dst) = q;
           }
         }
       } else {
         uint4 rcur[NCH / 2 > 0 ? NCH / 2 : 1];
+        if constexpr (RES) {
 #pragma unroll
-        for (int j = 0; j < NCH / 2; ++j) rcur[j] = rnext[j];
-        if (pre && mi + 1 < TM) fetch_r(mi + 1);
+          for (int j = 0; j < NCH / 2; ++j) rcur[j] = rnext[j];
+          if (mi + 1 < TM) fetch_r(mi + 1);
+        }
 #pragma unroll
         for (int j = 0; j < NCH / 2; ++j) {
           haff_u32x4 q;
-          if (p.resid) {   // the residual is added in fp32: trade fp32 registers, add, round once
+          if constexpr (RES) {   // the residual is added in fp32: trade fp32 registers, add, round once
             float v8[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -884,16 +916,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
           if (ALL || orow >= 0) {
             bf16_t* dst = ALL ? reinterpret_cast<bf16_t*>(const_cast<char*>(c_lane) + mi * c_pass) + 32 * j
                               : reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n_wave_out + 32 * j + coff;
-            if (nt_out) __builtin_nontemporal_store(q, reinterpret_cast<haff_u32x4*>(dst));
-            else *reinterpret_cast<haff_u32x4*>(dst) = q;
+            // plain stores: a lane writes HALF a 128-B line here and the other half with its next store; the L2 merges
+            // them, a non-temporal store would send each half to memory on its own (measured -2...-8 %)
+            *reinterpret_cast<haff_u32x4*>(dst) = q;
           }
 #endif
         }
       }
+      HAFF_TRACE2(2 + mi);
     }
     };   // reg_epilogue
-    if (!p.row_map && m_wave + WROWS <= p.M) reg_epilogue(std::true_type{});
-    else reg_epilogue(std::false_type{});
+    const bool all_rows = !p.row_map && m_wave + WROWS <= p.M;
+    if (!OUT_F32 && p.resid) {
+      if (all_rows) reg_epilogue(std::true_type{}, std::true_type{});
+      else reg_epilogue(std::false_type{}, std::true_type{});
+    } else {
+      if (all_rows) reg_epilogue(std::true_type{}, std::false_type{});
+      else reg_epilogue(std::false_type{}, std::false_type{});
+    }
   } else
 #endif
   {
@@ -1049,7 +1089,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   HAFF_TRACE(4);
 #endif
   if (!has_next) break;
+  HAFF_TRACE2(10);
   if constexpr (PP) __builtin_amdgcn_s_barrier();   // every wave is past its epilogue: its staging buffer takes K-tile 1
+  HAFF_TRACE2(11);
   tile = tile_next;
   buf0 = ebuf ^ 1;
   first_tile = false;
