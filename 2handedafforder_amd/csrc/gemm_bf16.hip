@@ -8,34 +8,50 @@
 //   Llama q/k/v/o/gate/up/down/lm_head (transformers LlamaDecoderLayer, called at llava_llama.py:93-105)
 //   mm_projector (llava_arch.py:35), text_hidden_fcs (LISA.py:95-101), SAM decoder linears (transformer.py:206-209)
 //
-// Design (gfx950): two tiles of one kernel template — 256x256x64 with 8 waves (2x4, 128x64 per wave; one
-// workgroup per CU, 128 KiB LDS) for anything that fills the chip with it, 128x128x64 with 4 waves (2x2, 64x64
-// per wave; two workgroups per CU) for small / ragged problems, K tails and the batched entry point. MFMA is
-// v_mfma_f32_16x16x32_bf16. Both operands are staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round trip);
-// the LDS image is lane-linear and the XOR swizzle (chunk ^= row&7) is applied on the per-lane SOURCE address and
-// again on the ds_read_b128 address, which makes the fragment reads bank-conflict free.
-// Double-buffered, ONE workgroup barrier per K-tile, and the MFMA stream is software-pipelined across that
-// barrier (see the K loop). The MFMA is issued "swapped" (W rows as the A operand, activation rows as the B
-// operand): each lane then holds 4 CONSECUTIVE output columns of one output row, so SwiGLU pairs (gate, up) land
-// in the same lane and the epilogue's LDS image is written with 16-B stores.
-// Epilogue: per 16-row pass the wave writes (+bias, activation) to a wave-private fp32 LDS image and reads it
-// back as whole 128-B row segments (+residual, row map) -> 16-B global stores. The activation is resolved once
-// per pass (wave-uniform switch, straight-line per-element code) and every global load of the epilogue is issued
-// ahead of the stores it would otherwise queue behind.
-// Workgroup ids are remapped XCD-aware (ids that share an XCD get neighbouring tiles) and grouped 8 M-tiles
-// deep so the 4 MiB per-XCD L2 holds the A and W panels the concurrently running tiles share.
+// Design (gfx950): two tiles of one kernel template — 256x256x64 with 8 waves (2x4, 128x64 per wave; one persistent
+// workgroup per CU, 130 KiB LDS) for anything that fills the chip with it, 128x128x64 with 4 waves (2x2, 64x64 per wave; two
+// workgroups per CU) for small / ragged problems, K tails and the batched entry point. MFMA is v_mfma_f32_16x16x32_bf16.
+// Both operands are staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round trip); the LDS image is lane-linear and
+// the XOR swizzle (chunk ^= row&7) is applied on the per-lane SOURCE address and again on the ds_read_b128 address, which
+// makes the fragment reads bank-conflict free (SQ_LDS_BANK_CONFLICT = 0).
+// The 8-wave tile runs a PING-PONG RING LOOP (round 3): its two wave groups sit one workgroup barrier apart, so on every
+// SIMD one wave multiplies (32 MFMAs on fragments it holds in registers) while its partner reads its next fragments from
+// LDS and issues its share of the operand requests; a K-tile is requested as four 16 KiB quarters spread over the loop, up
+// to two K-tiles ahead, and the one wait per K-tile is a COUNTED s_waitcnt vmcnt(4) — the request stream never drains and
+// runs on across the tile boundary into the workgroup's next tile. (Rounds 1-2 drained it with vmcnt(0) once per K-tile
+// because a counted wait had once been blamed for stale data; tools/probes/vmcnt_order_probe.hip and
+// tools/vmcnt_forensics.py show LDS-DMA leaves vmcnt in issue order and that failure was a write-after-read race.)
+// The MFMA is issued "swapped" (W rows as the A operand, activation rows as the B operand): each lane then holds 4
+// CONSECUTIVE output columns of one output row, so SwiGLU pairs (gate, up) land in the same lane.
+// Epilogue: interior tiles leave from registers — one v_permlane16_swap per register pairs two neighbouring 4-column
+// chunks into 16-B stores, four lanes cover 64 contiguous bytes of a row, the residual is prefetched one pass ahead behind
+// counted waits and the bias rides in as one more LDS-DMA a K loop earlier. Ragged / unaligned tiles go through a
+// wave-private fp32 LDS image and leave as whole 128-B row segments.
+// Workgroup ids are remapped XCD-aware (ids that share an XCD get neighbouring tiles) and grouped up to 8 M-tiles deep so
+// the 4 MiB per-XCD L2 holds the A and W panels the concurrently running tiles share (read hit rate 87 % measured).
 #include <type_traits>
 
 #include <cstdlib>
 #include "haff_common.h"
 
+// Tuning hooks (ablation switches HAFF_EXP_*, phase traces HAFF_GEMM_TRACE / _TRACE2, A/B switches HAFF_EPI_LDS /
+// HAFF_GEMM_NO_NT / HAFF_GEMM_GELU_SCALAR, environment overrides of the raster) exist only in builds made with
+// -DHAFF_TUNING (tools/build_gemm_variant.sh); the product library carries none of them and reads no environment.
+#ifndef HAFF_TUNING
+#undef HAFF_EXP_NODMA
+#undef HAFF_EXP_NOREAD
+#undef HAFF_EXP_NOSTORE
+#undef HAFF_EXP_NOEPI
+#undef HAFF_EXP_SAMETILE
+#undef HAFF_GEMM_TRACE
+#undef HAFF_GEMM_TRACE2
+#undef HAFF_EPI_LDS
+#undef HAFF_GEMM_NO_NT
+#undef HAFF_GEMM_GELU_SCALAR
+#endif
+
 namespace {
 
-// wave priority experiments (tools/gemm_variant.py): 3 = the held-back MFMAs right after the barrier run at priority 3,
-// so the first wave through the barrier is not starved by its SIMD neighbour still streaming the previous tile (+1-3 %)
-#ifndef HAFF_GEMM_PRIO
-#define HAFF_GEMM_PRIO 3
-#endif
 constexpr int BK = 64;
 
 
@@ -192,16 +208,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //   <128,128,2,2>: 256 threads, 64 KiB LDS, 2 workgroups/CU  — small / ragged problems
 //   <256,256,2,4>: 512 threads, 128 KiB LDS, 1 workgroup/CU  — half the L2->LDS bytes per MFMA (the 128^2 tile needs
 //                  ~64 B/clk/CU from L2 at full MFMA rate, more than the ~56 B/clk/CU the L2 can deliver)
-template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU, bool PP = false>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
-  static_assert(!PP || (BM == 256 && BN == 256 && WM == 2 && WN == 4), "the ping-pong ring loop is the 8-wave 256x256 tile");
+  constexpr bool PP = (WM * WN == 8);   // the 8-wave tile runs the persistent ping-pong ring loop
+  static_assert((BM == 256 && BN == 256 && WM == 2 && WN == 4) || (BM == 128 && BN == 128 && WM == 2 && WN == 2), "two tiles");
   constexpr int NTHREADS = 64 * WM * WN;
   constexpr int A_ELEMS = BM * BK, W_ELEMS = BN * BK;
   constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;
   constexpr int NA = BM * 8 / NTHREADS, NW = BN * 8 / NTHREADS;  // 16-B chunks per thread per K-tile
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;             // 16x16 MFMA tiles per wave
   constexpr int WNC = BN / WN;                                    // columns per wave: 64, or 128 for the 4-wave 256^2 tile
-  static_assert(WNC == 64 || WNC == 128, "wave tile width");
+  static_assert(WNC == 64, "wave tile width");
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS + (PP ? 512 : 0)];  // [buf][A | W] (+ PP: the tile's bias)
 
   const int tid = threadIdx.x;
@@ -390,7 +407,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   };
 
   int buf0 = 0;           // LDS buffer that holds K-tile 0 of the current tile
-  bool first_tile = true;
   if constexpr (PP) {     // K-tile 0 of the first tile; later tiles get theirs from the K loop of the tile before
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -403,7 +419,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   int m0e = m0, n0e = n0;                       // this tile's origin (the PP loop moves m0 / n0 on to the next tile)
   const int tile_next = tile + (int)gridDim.x;
-  const bool has_next = (WM * WN == 8) && tile_next < nwg;
+  const bool has_next = PP && tile_next < nwg;
+  const bool pf_next = has_next && nk >= 2;   // the K loop requests the next tile's K-tile 0 (a single-K-tile product cannot: its
+                                              // requests would have to go out before its own loop starts; see the loop's end)
   // K loop, software-pipelined ACROSS the workgroup barrier. One barrier per K-tile: after it every wave's share of
   // tile kt+1 has landed and every wave is done reading tile kt-1's buffer, so the DMA of tile kt+2 may overwrite it
   // and has a whole K-tile of MFMAs to land. The second half of k-step 1's MFMAs (operands already in registers) is
@@ -462,23 +480,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         }
       }
     };
-#ifndef HAFF_PP_HEAD
-#define HAFF_PP_HEAD 0
-#endif
-    constexpr int HEAD = HAFF_PP_HEAD;   // MFMAs of a cluster issued BEFORE the barrier that opens its slot (they touch no LDS)
-    // one 64x32 quadrant over the K-tile: 16 MFMAs, [first, last) of them issued here
-    auto quad = [&](const bf16x8 (&wq)[2][2], auto ni0, auto mi0, auto first, auto last) {
-      constexpr int N0 = decltype(ni0)::value, M0 = decltype(mi0)::value, F = decltype(first)::value, L = decltype(last)::value;
+    // one 64x32 quadrant of the wave tile over the whole K-tile: 16 MFMAs, operands in registers
+    auto quad = [&](const bf16x8 (&wq)[2][2], auto ni0, auto mi0) {
+      constexpr int N0 = decltype(ni0)::value, M0 = decltype(mi0)::value;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int idx = (ks * 4 + t) * 2 + j;
-            if (idx >= F && idx < L)
-              acc[N0 + j][M0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks][j], pa[ks][t], acc[N0 + j][M0 + t], 0, 0, 0);
-          }
+          for (int j = 0; j < 2; ++j)
+            acc[N0 + j][M0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks][j], pa[ks][t], acc[N0 + j][M0 + t], 0, 0, 0);
     };
     auto slot_barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
@@ -492,23 +503,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     using I0 = std::integral_constant<int, 0>;
     using I2 = std::integral_constant<int, 2>;
     using I4 = std::integral_constant<int, 4>;
-    using I16 = std::integral_constant<int, 16>;
-    using IHD = std::integral_constant<int, HEAD>;
     // W quarters of K-tile 1 (the buffer was the previous tile's epilogue staging; the barrier behind that epilogue, or
     // the one behind the first tile's prologue, has passed)
     // the tile's 256 bias values ride along as ONE more DMA instruction (wave 0), a whole K loop ahead of the epilogue that
     // reads them from LDS: a global load issued there sat in front of pass 0 with its full latency exposed, once per tile
     if (p.bias && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && wave == 0)
       __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + n0 + lane * 4), (lptr_t)(smem + 2 * STAGE_ELEMS), 16, 0, 0);
-    stage_w_q(buf0 ^ 1, BK, Q0{});
-    stage_w_q(buf0 ^ 1, BK, Q1{});
+    if (nk > 1) {
+      stage_w_q(buf0 ^ 1, BK, Q0{});
+      stage_w_q(buf0 ^ 1, BK, Q1{});
+    }
     HAFF_TRACE(1);
     if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = (kt & 1) ^ buf0;
-      const bool a_next = (kt + 1 < nk) || has_next;
+      const bool a_next = (kt + 1 < nk) || pf_next;
       const int a_k0 = (kt + 1 < nk) ? (kt + 1) * BK : 0;
-      const bool w_next = (kt + 2 < nk) || (kt + 2 == nk && has_next);
+      const bool w_next = (kt + 2 < nk) || (kt + 2 == nk && pf_next);
       const int w_k0 = (kt + 2 < nk) ? (kt + 2) * BK : 0;
 #ifdef HAFF_EXP_NODMA     // timing experiments only (results are wrong): no operand requests / no fragment reads in the loop
 #define PP_DMA(x) do {} while (0)
@@ -528,19 +539,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         PP_DMA(stage_a_q(cur ^ 1, a_k0, Q0{}));
         PP_DMA(stage_a_q(cur ^ 1, a_k0, Q1{}));
       }
-      // ---- multiply slot A: quadrants (A lo, W lo), (A lo, W hi); the first HEAD MFMAs go out BEFORE the barrier that opens
-      // the slot, beside the last MFMAs of the SIMD partner's cluster, so the matrix pipe does not idle over the barrier ----
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads are DONE before the barrier (WAR)
-      __builtin_amdgcn_sched_barrier(0);
+      close_load();
+      // ---- multiply slot A: quadrants (A lo, W lo), (A lo, W hi) ----
       __builtin_amdgcn_s_setprio(1);
-      quad(pwl, I0{}, I0{}, I0{}, IHD{});
-      slot_barrier();
-      quad(pwl, I0{}, I0{}, IHD{}, I16{});
-      quad(pwh, I2{}, I0{}, I0{}, I16{});
+      quad(pwl, I0{}, I0{});
+      quad(pwh, I2{}, I0{});
       __builtin_amdgcn_s_setprio(0);
       slot_barrier();
       // ---- load slot B: A hi; requests for the W quarters of K-tile kt+2; the wait for K-tile kt+1 ----
-      if (kt + 2 == nk && has_next) {   // from here on the staging coordinates are the next tile's
+      if (kt + 2 == nk && pf_next) {   // from here on the staging coordinates are the next tile's
         tile_origin(tile_next, m0, n0);
         stage_coords(m0, n0);
       }
@@ -552,113 +559,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      close_load();
       // ---- multiply slot B: quadrants (A hi, W hi), (A hi, W lo) ----
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      quad(pwh, I2{}, I4{}, I0{}, IHD{});
-      slot_barrier();
-      quad(pwh, I2{}, I4{}, IHD{}, I16{});
-      quad(pwl, I0{}, I4{}, I0{}, I16{});
+      quad(pwh, I2{}, I4{});
+      quad(pwl, I0{}, I4{});
       __builtin_amdgcn_s_setprio(0);
       if (!(wm == 1 && kt == nk - 1)) slot_barrier();   // group 1 gives back the barrier it took at the top
     }
-  } else if constexpr (WM * WN == 8) {
-#ifndef HAFF_GEMM_HEAD
-#define HAFF_GEMM_HEAD (TM / 2)
-#endif
-    constexpr int HEAD = HAFF_GEMM_HEAD;
-    if (first_tile) stage(buf0, 0);   // later tiles: requested under the previous tile's epilogue
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();     // K-tile 0 landed; every wave is past its previous epilogue (its LDS staging is free)
-    HAFF_TRACE(1);
-    // SIMD partners (waves w and w+4) issue their share of the next tile's DMA at different points after the barrier:
-    // a wave's 8 DMA instructions take ~340 ns to issue (the CU accepts requests at the rate memory serves them;
-    // -DHAFF_GEMM_TRACE slots 5/6) and it issues no MFMA meanwhile. Waves 0-3 issue before their fragment reads, waves
-    // 4-7 after their held-back MFMAs, so one partner's issue stall sits under the other's reads and MFMAs
-    // (+2.5...+7 % per shape, tools/gemm_variant.py; both partners right after the barrier idled the matrix pipe;
-    // moving the late group's issue into the middle of the next K-tile's MFMA stream instead cost 10-18 %).
-    const bool late = wave >= 4;
-    if (nk > 1) stage(buf0 ^ 1, BK);
-    read_frags(buf0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = (kt & 1) ^ buf0;
-#ifdef HAFF_GEMM_TRACE
-      if (kt == 5) HAFF_TRACE(7);
-#endif
-#ifndef HAFF_EXP_NOREAD   // timing experiments only (results are wrong): drop the LDS fragment reads / the DMA of the loop
-      read_frags(cur, 1);
-#endif
-      mfma_rows(0, 0, TM);
-
-      mfma_rows(1, 0, HEAD);
-      // k-step-1 reads trickle in between the k-step-0 MFMA groups (lgkmcnt is 4 bits: keep <= 15 reads outstanding)
-#pragma unroll
-      for (int g = 0; g < TM; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, (TN + TM + TM - 1) / TM, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, TN * HEAD, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < nk) {
-#if HAFF_GEMM_PRIO >= 4
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt+1 landed; my reads of tile kt are done
-        __builtin_amdgcn_s_barrier();
-#if HAFF_GEMM_PRIO == 1
-        __builtin_amdgcn_s_setprio(3);   // the wave issuing the next tile's DMA / first reads goes ahead of MFMA streams
-#endif
-#ifdef HAFF_GEMM_TRACE
-        if (kt == 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); HAFF_TRACE(5); }
-#endif
-#ifndef HAFF_EXP_NODMA
-        if (!late && kt + 2 < nk) stage(cur, (kt + 2) * BK);
-#endif
-#ifdef HAFF_GEMM_TRACE
-        if (kt == 4) HAFF_TRACE(6);
-#endif
-#ifndef HAFF_EXP_NOREAD
-        read_frags(cur ^ 1, 0);
-#endif
-#if HAFF_GEMM_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#if HAFF_GEMM_PRIO == 2
-      __builtin_amdgcn_s_setprio(2);
-#elif HAFF_GEMM_PRIO >= 3
-      __builtin_amdgcn_s_setprio(3);
-#endif
-      mfma_rows(1, HEAD, TM);
-#ifndef HAFF_EXP_NODMA
-      if (late && kt + 2 < nk)
-#else
-      if (false)
-#endif
-      {   // the partner issued its share before its fragment reads; this wave after its tail MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        stage(cur, (kt + 2) * BK);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#if HAFF_GEMM_PRIO == 2 || HAFF_GEMM_PRIO == 3
-      __builtin_amdgcn_s_setprio(0);
-#elif HAFF_GEMM_PRIO == 4
-      __builtin_amdgcn_s_setprio(1);
-#elif HAFF_GEMM_PRIO == 5
-      __builtin_amdgcn_s_setprio(2);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
   } else {
-    // 4-wave tile: two workgroups per CU cover for each other. One barrier per K-tile, and ONLY vmcnt(0) waits:
-    // tile kt+1's DMA is issued at the top of iteration kt (its buffer was last read in iteration kt-1, which ended with
-    // the barrier), has the whole MFMA phase to land, and is waited for in full before the barrier that publishes it.
-    // (The previous form issued it the same way but waited with a COUNTED vmcnt(8) for "the older tile": LDS-DMA
-    // operations do not retire in issue order when some hit L2 and others go to HBM, so under memory contention the
-    // count was reached with a piece of the older tile still in flight — rare stale 8-row x 32-deep fragments, found as
-    // run-to-run differences once a second HIP stream was active)
+    // 4-wave tile: two workgroups per CU cover for each other. One barrier per K-tile: tile kt+1's DMA is issued at the top
+    // of iteration kt (its buffer was last read in iteration kt-1, which ended with the barrier), has the whole MFMA phase
+    // to land, and is waited for in full before the barrier that publishes it. The explicit lgkmcnt(0) BEFORE that barrier
+    // is what round 1's form lacked: hipcc had sunk the wait for the last two ds_read_b128 below its end-of-iteration
+    // barrier, so a fast wave could request the next tile into a buffer a slow wave was still reading — a write-after-read
+    // race that showed as rare wrong fragments beside a second stream (tools/vmcnt_forensics.py).
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -687,16 +602,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   if constexpr (!PP) __builtin_amdgcn_s_barrier();
   HAFF_TRACE(2);
   HAFF_TRACE2(0);
-  // the buffer the last K-tile was read from takes the epilogue's staging images; the other one is idle: the next tile's
-  // first K-tile goes there now (8-wave persistent form; the PP loop has requested AND waited for it already)
+  // the buffer the last K-tile was read from takes the LDS-staged epilogue's images (ragged tiles); the other one holds the
+  // next tile's first K-tile, which the ring loop has requested AND waited for already
   const int ebuf = ((nk - 1) & 1) ^ buf0;
-  if constexpr (!PP) {
-    if (has_next) {
-      tile_origin(tile_next, m0, n0);
-      stage_coords(m0, n0);
-      stage(ebuf ^ 1, 0);
-    }
-  }
 
   // ---- epilogue, staged through LDS so global traffic is whole 128-B row segments ----
   // lane holds D[n = 4*fh + reg][m = fr] of each 16x16 tile -> (+bias, act) -> fp32 LDS image [16 rows][WCOLS],
@@ -1090,11 +998,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #endif
   if (!has_next) break;
   HAFF_TRACE2(10);
-  if constexpr (PP) __builtin_amdgcn_s_barrier();   // every wave is past its epilogue: its staging buffer takes K-tile 1
+  if constexpr (PP) {
+    __builtin_amdgcn_s_barrier();   // every wave is past its epilogue: its staging buffer takes K-tile 1
+    if (!pf_next) {                 // single-K-tile products: the next tile's only K-tile is requested and awaited here
+      tile_origin(tile_next, m0, n0);
+      stage_coords(m0, n0);
+      stage(ebuf ^ 1, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
   HAFF_TRACE2(11);
   tile = tile_next;
   buf0 = ebuf ^ 1;
-  first_tile = false;
   }   // tile loop
 }
 
@@ -1450,21 +1366,25 @@ static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
 
 }  // namespace
 
-template <int BM, int BN, int WM, int WN, bool PP = false>
+template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   int gx = tiles;
-  if (WM * WN == 8) {   // persistent 8-wave tile: one workgroup per CU (HAFF_GEMM_PERSIST: other cap, 0 = one tile each)
-    static const int cap = [] { const char* e = getenv("HAFF_GEMM_PERSIST"); return e ? atoi(e) : 256; }();
+  if (WM * WN == 8) {   // persistent 8-wave tile: one workgroup per CU
+    int cap = 256;
+#ifdef HAFF_TUNING       // HAFF_GEMM_PERSIST: other cap, 0 = one tile per workgroup
+    static const int cap_env = [] { const char* e = getenv("HAFF_GEMM_PERSIST"); return e ? atoi(e) : 256; }();
+    cap = cap_env;
+#endif
     if (cap > 0 && gx > cap) gx = cap;
   }
   dim3 grid(gx, nbatch), block(64 * WM * WN);
   if (p.swiglu) {
-    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, PP>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true, PP>), grid, block, 0, s, p);
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
   } else {
-    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false, PP>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false, PP>), grid, block, 0, s, p);
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
   }
   return haff_check_launch();
 }
@@ -1528,8 +1448,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   }
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
   const bool big_ok = (K % BK == 0) && ((long)(a_map ? a_rows : M) * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
-  if (tile_cfg == 3 && big_ok) return launch_gemm<256, 256, 2, 2>(p, s);
-  bool big = (tile_cfg == 2 || tile_cfg == 4) && big_ok;
+  bool big = tile_cfg == 2 && big_ok;
   if (tile_cfg == 0 && big_ok) {
     // Pick the tile by wave-quantisation efficiency (tiles / slots rounded up) times the measured per-tile
     // advantage of the 256^2 kernel (tools/gemm_bench.py: ~1.2x at equal quantisation): 128^2 runs 2
@@ -1551,20 +1470,19 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
     else if (K >= 5120 && tn <= 32) p.group_m = 2;
     else if (tn <= 16) p.group_m = 4;
   }
+#ifdef HAFF_TUNING
   {   // A/B override of the raster group depth (tools/gemm_variant.py)
     static const int gm_env = [] { const char* e = getenv("HAFF_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
     if (gm_env > 0) p.group_m = gm_env;
   }
+#endif
 #ifndef HAFF_GEMM_NO_NT
   p.nt_out = (long)M * (swiglu ? N / 2 : N) * (out_f32 ? 4 : 2) >= (64L << 20);
 #endif
-  // the ping-pong ring loop needs two K-tiles; tile_cfg 4 keeps the one-barrier-per-K-tile loop of rounds 1-2 for A/B runs
-  if (big && tile_cfg != 4 && K >= 2 * BK) return launch_gemm<256, 256, 2, 4, true>(p, s);
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
 
-// tile_cfg: 0 = auto, 1 = force 128x128, 2 = force 256x256 (8 waves, ping-pong ring loop), 3 = force 256x256 (4 waves),
-// 4 = force 256x256 (8 waves, the drained double-buffer loop of rounds 1-2) (for A/B measurements)
+// tile_cfg: 0 = auto, 1 = force the 128x128 tile, 2 = force the 256x256 tile (tests and A/B measurements)
 extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                                   const float* bias, const void* resid, long ldr, const int* row_map,
                                   int M, int N, int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {

@@ -144,12 +144,12 @@ def test_gemm_bf16_split_k_swiglu(dev, M, N, K):
     _close(plain, y, 2e-3, "split-K wide plain")
 
 
-@pytest.mark.parametrize("tile_cfg", [1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 1003, 256), (300, 520, 64), (1111, 256, 1280)])
+@pytest.mark.parametrize("tile_cfg", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 1003, 256), (300, 520, 64), (1111, 256, 1280), (5000, 4500, 64)])
 def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
-    """Every tile of the template (128^2 / 4 waves, 256^2 / 8 waves with the ping-pong ring loop (2) and with the drained
-    double-buffer loop (4), 256^2 / 4 waves with 128-column wave tiles) through every epilogue feature, ragged edges
-    included; the auto heuristic only picks the big tiles on large problems."""
+    """Both tiles of the template (128^2 / 4 waves; 256^2 / 8 waves with the ping-pong ring loop) through every epilogue
+    feature, ragged edges included (K = 64: the single-K-tile path of the ring loop, with and without a next tile); the auto
+    heuristic only picks the big tile on large problems."""
     ops = _ops()
     x = _rand((M, K), dev, torch.bfloat16, 11)
     w = _rand((N, K), dev, torch.bfloat16, 12, K ** -0.5)
@@ -742,7 +742,7 @@ def test_upscale_mask_and_resize(dev, dtype):
     assert torch.equal(th, ((crop > 0).to(torch.uint8) * 255))
 
 
-@pytest.mark.parametrize("tile_cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile_cfg", [1, 2])
 @pytest.mark.parametrize("M", [592, 4400])
 def test_gemm_stable_beside_second_stream(dev, tile_cfg, M):
     """Regression for the LDS staging races of the tile loops: a GEMM on structured operands (K-tile kt of
@@ -786,7 +786,6 @@ def test_gemm_ring_loop_across_tiles(dev, M, N, K):
     got = ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=2)
     _close(got, y, 2e-3, "ring loop f32 out")
     assert torch.equal(got, ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=1)), "ring loop vs 128x128 tile"
-    assert torch.equal(got, ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=4)), "ring loop vs drained loop"
     if M * N < 100_000_000:
         resid = _rand((M, N), dev, torch.bfloat16, 24)
         amap = torch.randperm(M, device=dev).to(torch.int32)
