@@ -65,9 +65,13 @@ def load_hf_dir(path):
     return sd
 
 
-def load_state_dict(version_dir, clip_dir=None, sam_ckpt=None, for_training=False, seed=0):
+def load_state_dict(version_dir, clip_dir=None, sam_ckpt=None, for_training=False, seed=0, cfg=None):
     """Reference-keyed state dict for LisaMI355 from on-disk checkpoints. for_training: a plain LLaVA base is completed
-    the way the reference's fine-tune entrypoint does it (complete_for_training)."""
+    the way the reference's fine-tune entrypoint does it (complete_for_training). cfg: the geometry of the model about to
+    be built, when the caller has adjusted what config.json says (train_ds.py: --out_dim, a vocabulary grown to
+    len(tokenizer)); default: config_from_dir(version_dir)."""
+    if cfg is None:
+        cfg = config_from_dir(version_dir)
     sd = load_hf_dir(version_dir)
     if clip_dir is not None:
         for k, v in load_hf_dir(clip_dir).items():
@@ -81,8 +85,8 @@ def load_state_dict(version_dir, clip_dir=None, sam_ckpt=None, for_training=Fals
             else:
                 sd.setdefault("model.visual_model." + k, v)
     if for_training:
-        complete_for_training(sd, config_from_dir(version_dir), seed)
-    missing = [k for k in hw.all_shapes(config_from_dir(version_dir)) if k not in sd and "post_layernorm" not in k]
+        complete_for_training(sd, cfg, seed)
+    missing = [k for k in hw.all_shapes(cfg) if k not in sd and "post_layernorm" not in k]
     if missing:
         raise KeyError(f"{len(missing)} tensors missing from the checkpoint, e.g. {missing[:4]}")
     return sd
@@ -107,6 +111,8 @@ def complete_for_training(sd, cfg, seed=0):
             extra = torch.randn((want - have, sd[k].shape[1]), generator=g) * 0.02
             sd[k] = torch.cat([sd[k].float(), extra], 0).to(sd[k].dtype)
             created.append(f"{k}[{have}:{want}]")
+        elif have > want:   # resize_token_embeddings(len(tokenizer)) also shrinks a padded vocabulary
+            sd[k] = sd[k][:want].contiguous()
     for k, shape in shapes.items():
         if k in sd:
             continue

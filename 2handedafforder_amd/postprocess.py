@@ -72,6 +72,11 @@ def inference_planes(mask_logits, taxonomy, side, thresholds=THRESHOLDS):
 
 
 def chat_plane(mask_logits, taxonomy, side, on_value=100):
-    """One hand of one prompt, chat.py rule: (mask > 0) * 100, zeros when the gate closes. Returns uint8 [H,W]."""
-    return ops.gate_threshold_masks(mask_logits.contiguous(), [0.0], on_value, taxonomy.reshape(-1)[:4].float().contiguous(),
-                                    1 if side == "left" else 0)[0]
+    """One hand of one prompt, chat.py rule: (mask > 0) * 100, zeros when the gate closes. Returns uint8 [H,W].
+    The gate is the reference's: torch.argmax over the WHOLE per-frame taxonomy tensor [n_prompts, 4] flattened
+    (chat.py:231,243) — index 1 blanks the left hand, index 0 the right one, any other index (>= 4 can only happen with more
+    than one [SEG] in the answer) blanks neither. One host read of an index per frame; chat is interactive, not the hot path."""
+    k = int(torch.argmax(taxonomy.reshape(-1)))
+    if k == (1 if side == "left" else 0):
+        return torch.zeros(mask_logits.shape[-2:], dtype=torch.uint8, device=mask_logits.device)
+    return ops.gate_threshold_masks(mask_logits.contiguous(), [0.0], on_value, None, 1 if side == "left" else 0)[0]

@@ -284,9 +284,11 @@ def main(argv):
         cfg.im_start_idx = tokenizer("<im_start>", add_special_tokens=False).input_ids[0]
         cfg.im_end_idx = tokenizer("<im_end>", add_special_tokens=False).input_ids[0]
         cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
-        cfg.llm.vocab = max(cfg.llm.vocab, len(tokenizer))
+        # the vocabulary of the model being built is the tokenizer's (train_ds.py:231-233: resize_token_embeddings(len(tokenizer))),
+        # whatever config.json's vocab_size says about added tokens (a base that already carries 32003 rows stays 32003)
+        cfg.llm.vocab = len(tokenizer)
         sd = checkpoint.load_state_dict(args.version, args.vision_tower, args.vision_pretrained, for_training=True,
-                                        seed=args.seed)
+                                        seed=args.seed, cfg=cfg)
     model = LisaTrainable(cfg, sd, dtype=dtype, device=device, lora_r=args.lora_r, lora_alpha=args.lora_alpha,
                           lora_dropout=args.lora_dropout, ce_loss_weight=args.ce_loss_weight,
                           dice_loss_weight=args.dice_loss_weight, bce_loss_weight=args.bce_loss_weight, seed=args.seed)

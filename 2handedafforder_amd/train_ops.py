@@ -117,11 +117,13 @@ class GradBucketReducer:
         items = sorted(named_params, key=lambda kv: _ready_rank(kv[0]))
         self.buckets = []          # each: {"flat", "names", "pending", "n", "work"}
         self.bucket_of = {}
-        cur = None
-        for name, p in items:
+        open_bucket = {}           # ONE open bucket per dtype: bf16 matrices and fp32 vectors alternate in state-dict order,
+        for name, p in items:      # and a bucket per dtype CHANGE would be a bucket (an all-reduce) per tensor
             nbytes = p.numel() * p.element_size()
-            if cur is None or cur["dtype"] != p.dtype or cur["bytes"] + nbytes > bucket_bytes and cur["bytes"] > 0:
+            cur = open_bucket.get(p.dtype)
+            if cur is None or (cur["bytes"] + nbytes > bucket_bytes and cur["bytes"] > 0):
                 cur = {"dtype": p.dtype, "bytes": 0, "params": [], "names": []}
+                open_bucket[p.dtype] = cur
                 self.buckets.append(cur)
             cur["params"].append(p)
             cur["names"].append(name)

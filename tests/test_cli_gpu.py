@@ -114,6 +114,15 @@ def test_output_gating_is_bit_exact(dev):
             gl, gr, _ = chat.render_outputs(np.zeros(orig + (3,), np.uint8), left[0][0], right[0][0], t)
             rl, rr = O.chat_output_planes(left[0].cpu(), right[0].cpu(), t.cpu())
             assert np.array_equal(gl, rl) and np.array_equal(gr, rr), (orig, t_class)
+        # two [SEG] prompts in one answer: chat.py takes the argmax of the FLATTENED [2, 4] tensor (an index >= 4 blanks neither
+        # hand; index 1 / 0 of the first prompt decide otherwise) — the first row alone would gate differently
+        for flat_arg in (0, 1, 5, 4):
+            t2 = torch.full((2, 4), 0.1, device=dev)
+            t2.view(-1)[flat_arg] = 0.9
+            t2[0, 1 if flat_arg >= 4 else 3] += 0.05     # the first row's own argmax points elsewhere
+            gl, gr, _ = chat.render_outputs(np.zeros(orig + (3,), np.uint8), left[0][0], right[0][0], t2)
+            rl, rr = O.chat_output_planes(left[0].cpu(), right[0].cpu(), t2.cpu())
+            assert np.array_equal(gl, rl) and np.array_equal(gr, rr), (orig, "flat", flat_arg)
     # device-side taxonomy gate of the kernel itself (ties -> first maximum, like torch.argmax)
     x = torch.randn((64, 65), device=dev)
     for tax, blank, open_ in (([0.4, 0.4, 0.1, 0.1], 0, False), ([0.4, 0.4, 0.1, 0.1], 1, True), ([0.1, 0.2, 0.35, 0.35], 2, False)):

@@ -266,3 +266,29 @@ def test_bench_multi_rank_path_dry_run_with_stub_model():
     assert line["ms_per_step"] >= 50.0 and line["ms_per_step"] < 120.0
     assert abs(line["value"] - 2 * 5 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
     assert line["cpu_baseline"] is None and line["config"]["stub"] is True
+
+
+def test_bucket_layout_with_alternating_dtypes():
+    """LisaTrainable keeps matrices in bf16 and biases / norm vectors in fp32, alternating in state-dict order: buckets are
+    filled per dtype (one open bucket each), so the count is ~ total bytes / bucket bytes per dtype, not one per tensor."""
+    from haff import train_ops as T
+    named = []
+    for i in range(40):
+        named.append((f"model.visual_model.mask_decoder_left.blk{i}.weight", torch.nn.Parameter(torch.zeros(256, 256, dtype=torch.bfloat16))))
+        named.append((f"model.visual_model.mask_decoder_left.blk{i}.bias", torch.nn.Parameter(torch.zeros(256, dtype=torch.float32))))
+    named.append(("lm_head.weight", torch.nn.Parameter(torch.zeros(2000, 256, dtype=torch.bfloat16))))
+    bucket = 1 << 20
+    red = T.GradBucketReducer(named, bucket_bytes=bucket)
+    by_dtype = {}
+    for b in red.buckets:
+        by_dtype.setdefault(b["dtype"], []).append(b)
+        assert all(p.dtype == b["dtype"] for p in b["params"])
+        assert sum(p.numel() for p in b["params"]) == b["flat"].numel()
+    bf16_bytes = (40 * 256 * 256 + 2000 * 256) * 2
+    assert len(by_dtype[torch.float32]) == 1                      # 40 KiB of biases: one bucket
+    assert len(by_dtype[torch.bfloat16]) <= bf16_bytes // bucket + 2
+    assert len(red.buckets) <= 8, len(red.buckets)                # (81 tensors gave 80 buckets before)
+    for name, p in named:                                         # every gradient is a view into its bucket
+        assert p.grad is not None and p.grad.shape == p.shape
+        b = red.buckets[red.bucket_of[id(p)]]
+        assert p.grad.untyped_storage().data_ptr() == b["flat"].untyped_storage().data_ptr()
