@@ -186,10 +186,18 @@ def parity_vs_oracle(device):
         f32, b16 = out[cfg_name]["fp32"], out[cfg_name]["bf16"]
         if f32["mask_iou_vs_oracle"] < 0.999 or f32["mask_logit_max_err_rel"] > 1e-3 or not f32["token_ids_equal"] or not f32["greedy_token_ids_equal"]:
             fails.append(f"{cfg_name}/fp32")
-        if b16["mask_iou_vs_oracle"] < 0.98 or b16["mask_logit_max_err_rel"] > 2e-2 or not b16["token_ids_equal"]:
+        if (b16["mask_iou_vs_oracle"] < 0.98 or b16["mask_logit_max_err_rel"] > 1e-2 or not b16["token_ids_equal"]
+                or not b16["greedy_token_ids_equal"]):
             fails.append(f"{cfg_name}/bf16")
     out["gate"] = {"fp32": "IoU >= 0.999, logits within 1e-3, forced and free-running greedy tokens identical",
-                   "bf16": "IoU >= 0.98 (floor of a bf16-rounded embedding: iou_floor_*), logits within 2e-2, forced tokens identical",
+                   "bf16": "IoU >= 0.98, logits within 1e-2 of the logit scale (measured 3.7e-3 / 4.7e-3: ~2x), forced and "
+                           "free-running greedy tokens identical",
+                   "bf16_meets_iou_0.999_target": False,
+                   "bf16_target_note": "BASELINE's IoU >= 0.999 is met by the fp32 mode only; on random-init weights no bf16 "
+                                       "pipeline can meet it (iou_floor_*: the exact pipeline with ONE bf16 rounding of the embedding "
+                                       "is already below it; the oracle with bf16 roundings at this path's kernel boundaries "
+                                       "(oracle.bf16_points) sits at the same distance from the exact forward as the HIP path: "
+                                       "tools/parity_points.py)",
                    "failed": fails}
     return out
 

@@ -24,6 +24,33 @@ import torch.nn.functional as F
 IMAGE_TOKEN_INDEX = -200  # utils/utils.py:8
 N_IMG_PAD = 255           # LISA.py:461 — 256 CLIP patch embeddings replace one sentinel
 
+# ---- bf16-points mode (test infrastructure for the bf16 throughput path) ------------------------------------------
+# The reference's own bf16 run (`--precision bf16`, model.bfloat16()) rounds every op's output to bf16. The HIP path rounds
+# at FEWER points — once per fused kernel: a Linear's output after its fused bias / activation / residual, a norm's output,
+# the attention probabilities handed to the P.V product, the attention output — and accumulates in fp32 everywhere. With
+# `with bf16_points():` this oracle rounds at exactly those points (fp32 arithmetic in between; the SAM neck's last conv,
+# the prompt encoder, both mask decoders, text_hidden_fcs and postprocess stay fp32 like LisaMI355(fp32_tail=True)), so the
+# bf16 HIP path can be held to a few 1e-3 of the logit scale instead of the 6e-2 the distance to the exact fp32 forward
+# needs. Default OFF: every golden fixture and every fp32 comparison sees the exact fp32 restatement.
+_BF16_POINTS = False
+
+
+class bf16_points:
+    def __enter__(self):
+        global _BF16_POINTS
+        self._old, _BF16_POINTS = _BF16_POINTS, True
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16_POINTS
+        _BF16_POINTS = self._old
+        return False
+
+
+def _r(x):
+    """One kernel boundary of the bf16 path: round to bf16 (no-op in the exact mode)."""
+    return x.to(torch.bfloat16).to(torch.float32) if _BF16_POINTS else x
+
 
 def _lin(sd, name, x):
     """nn.Linear with optional bias."""
@@ -73,24 +100,24 @@ def sam_attention(sd, pfx, x, num_heads):
     """image_encoder.py:235-260 with add_decomposed_rel_pos :354-392 (bias from the UNSCALED q)."""
     B, H, W, C = x.shape
     hd = C // num_heads
-    qkv = _lin(sd, pfx + ".qkv", x).reshape(B, H * W, 3, num_heads, -1).permute(2, 0, 3, 1, 4)
+    qkv = _r(_lin(sd, pfx + ".qkv", x)).reshape(B, H * W, 3, num_heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.reshape(3, B * num_heads, H * W, -1).unbind(0)
     attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
-    Rh = get_rel_pos(H, H, sd[pfx + ".rel_pos_h"])
-    Rw = get_rel_pos(W, W, sd[pfx + ".rel_pos_w"])
+    Rh = _r(get_rel_pos(H, H, sd[pfx + ".rel_pos_h"]))   # (the tables are bf16 MFMA operands in the kernels)
+    Rw = _r(get_rel_pos(W, W, sd[pfx + ".rel_pos_w"]))
     r_q = q.reshape(B * num_heads, H, W, hd)
     rel_h = torch.einsum("bhwc,hkc->bhwk", r_q, Rh)
     rel_w = torch.einsum("bhwc,wkc->bhwk", r_q, Rw)
     attn = (attn.view(-1, H, W, H, W) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(-1, H * W, H * W)
-    attn = attn.softmax(dim=-1)
-    x = (attn @ v).view(B, num_heads, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
-    return _lin(sd, pfx + ".proj", x)
+    attn = _r(attn.softmax(dim=-1))
+    x = _r(attn @ v).view(B, num_heads, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
+    return _lin(sd, pfx + ".proj", x)   # (+ bias + shortcut before the one rounding: sam_block)
 
 
 def sam_block(sd, pfx, x, num_heads, window):
     """image_encoder.py:177-193; window partition pads with zeros AFTER norm1 (:179-183, :276-288)."""
     shortcut = x
-    x = _ln(sd, pfx + ".norm1", x, 1e-6)
+    x = _r(_ln(sd, pfx + ".norm1", x, 1e-6))
     if window > 0:
         B, H, W, C = x.shape
         ph, pw = (window - H % window) % window, (window - W % window) % window
@@ -101,16 +128,16 @@ def sam_block(sd, pfx, x, num_heads, window):
     if window > 0:
         x = x.view(B, Hp // window, Wp // window, window, window, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, -1)
         x = x[:, :H, :W, :]
-    x = shortcut + x
-    h = _ln(sd, pfx + ".norm2", x, 1e-6)
-    h = _lin(sd, pfx + ".mlp.lin2", F.gelu(_lin(sd, pfx + ".mlp.lin1", h)))  # common.py:13-26
-    return x + h
+    x = _r(shortcut + x)
+    h = _r(_ln(sd, pfx + ".norm2", x, 1e-6))
+    h = _lin(sd, pfx + ".mlp.lin2", _r(F.gelu(_lin(sd, pfx + ".mlp.lin1", h))))  # common.py:13-26
+    return _r(x + h)
 
 
 def sam_image_encoder(sd, pfx, x, cfg, taps=None):
     """ImageEncoderViT.forward (image_encoder.py:110-125). x [B,3,S,S] -> [B,out_chans,S/16,S/16]."""
-    x = F.conv2d(x, sd[pfx + ".patch_embed.proj.weight"], sd[pfx + ".patch_embed.proj.bias"], stride=cfg.patch)
-    x = x.permute(0, 2, 3, 1) + sd[pfx + ".pos_embed"]
+    x = _r(F.conv2d(_r(x), sd[pfx + ".patch_embed.proj.weight"], sd[pfx + ".patch_embed.proj.bias"], stride=cfg.patch))
+    x = _r(x.permute(0, 2, 3, 1) + _r(sd[pfx + ".pos_embed"]))
     if taps is not None:
         taps["patch_embed"] = x.clone()
     for i in range(cfg.depth):
@@ -119,9 +146,9 @@ def sam_image_encoder(sd, pfx, x, cfg, taps=None):
         if taps is not None:
             taps[f"block{i}"] = x.clone()
     x = x.permute(0, 3, 1, 2)
-    x = F.conv2d(x, sd[pfx + ".neck.0.weight"])
-    x = _ln2d(sd, pfx + ".neck.1", x)
-    x = F.conv2d(x, sd[pfx + ".neck.2.weight"], padding=1)
+    x = _r(F.conv2d(x, sd[pfx + ".neck.0.weight"]))
+    x = _r(_ln2d(sd, pfx + ".neck.1", x))
+    x = F.conv2d(x, sd[pfx + ".neck.2.weight"], padding=1)   # fp32 from here on (the decoder tail's input)
     x = _ln2d(sd, pfx + ".neck.3", x)
     return x
 
@@ -236,25 +263,25 @@ def sam_postprocess_masks(masks, img_size, input_size, original_size):
 def clip_vision_features(sd, pfx, x, cfg):
     """hidden_states[select_layer][:, 1:] of CLIPVisionModel (feature_select, clip_encoder.py:31-39)."""
     vm = pfx + ".vision_model"
-    p = F.conv2d(x, sd[vm + ".embeddings.patch_embedding.weight"], stride=cfg.patch).flatten(2).transpose(1, 2)
+    p = _r(F.conv2d(_r(x), sd[vm + ".embeddings.patch_embedding.weight"], stride=cfg.patch)).flatten(2).transpose(1, 2)
     cls = sd[vm + ".embeddings.class_embedding"].expand(x.shape[0], 1, -1)
-    h = torch.cat([cls, p], dim=1) + sd[vm + ".embeddings.position_embedding.weight"][None]
-    h = _ln(sd, vm + ".pre_layrnorm", h, cfg.eps)
+    h = _r(torch.cat([cls, p], dim=1) + sd[vm + ".embeddings.position_embedding.weight"][None])
+    h = _r(_ln(sd, vm + ".pre_layrnorm", h, cfg.eps))
     n_run = cfg.layers + 1 + cfg.select_layer if cfg.select_layer < 0 else cfg.select_layer
     hd = cfg.hidden // cfg.heads
     for i in range(n_run):
         L = f"{vm}.encoder.layers.{i}"
         r = h
-        y = _ln(sd, L + ".layer_norm1", h, cfg.eps)
+        y = _r(_ln(sd, L + ".layer_norm1", h, cfg.eps))
         B, N, C = y.shape
-        q = (_lin(sd, L + ".self_attn.q_proj", y) * hd ** -0.5).view(B, N, cfg.heads, hd).transpose(1, 2)
-        k = _lin(sd, L + ".self_attn.k_proj", y).view(B, N, cfg.heads, hd).transpose(1, 2)
-        v = _lin(sd, L + ".self_attn.v_proj", y).view(B, N, cfg.heads, hd).transpose(1, 2)
-        a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v
-        h = r + _lin(sd, L + ".self_attn.out_proj", a.transpose(1, 2).reshape(B, N, C))
-        y = _lin(sd, L + ".mlp.fc1", _ln(sd, L + ".layer_norm2", h, cfg.eps))
-        y = y * torch.sigmoid(1.702 * y)  # quick_gelu
-        h = h + _lin(sd, L + ".mlp.fc2", y)
+        q = (_r(_lin(sd, L + ".self_attn.q_proj", y)) * hd ** -0.5).view(B, N, cfg.heads, hd).transpose(1, 2)
+        k = _r(_lin(sd, L + ".self_attn.k_proj", y)).view(B, N, cfg.heads, hd).transpose(1, 2)
+        v = _r(_lin(sd, L + ".self_attn.v_proj", y)).view(B, N, cfg.heads, hd).transpose(1, 2)
+        a = _r(_r(torch.softmax(q @ k.transpose(-1, -2), dim=-1)) @ v)
+        h = _r(r + _lin(sd, L + ".self_attn.out_proj", a.transpose(1, 2).reshape(B, N, C)))
+        y = _lin(sd, L + ".mlp.fc1", _r(_ln(sd, L + ".layer_norm2", h, cfg.eps)))
+        y = _r(y * torch.sigmoid(1.702 * y))  # quick_gelu (fused into fc1's epilogue: one rounding)
+        h = _r(h + _lin(sd, L + ".mlp.fc2", y))
     return h[:, 1:]
 
 
@@ -287,12 +314,12 @@ def llama_forward(sd, x, cfg, cache=None, taps=None):
     cos, sin = _rope(pos, hd, cfg.rope_theta)
     for i in range(cfg.layers):
         L = f"model.layers.{i}"
-        h = _rms(x, sd[L + ".input_layernorm.weight"], cfg.rms_eps)
-        q = F.linear(h, sd[L + ".self_attn.q_proj.weight"]).view(B, T, cfg.heads, hd).transpose(1, 2)
-        k = F.linear(h, sd[L + ".self_attn.k_proj.weight"]).view(B, T, cfg.heads, hd).transpose(1, 2)
-        v = F.linear(h, sd[L + ".self_attn.v_proj.weight"]).view(B, T, cfg.heads, hd).transpose(1, 2)
-        q = q * cos + _rot_half(q) * sin
-        k = k * cos + _rot_half(k) * sin
+        h = _r(_rms(x, sd[L + ".input_layernorm.weight"], cfg.rms_eps))
+        q = _r(F.linear(h, sd[L + ".self_attn.q_proj.weight"])).view(B, T, cfg.heads, hd).transpose(1, 2)
+        k = _r(F.linear(h, sd[L + ".self_attn.k_proj.weight"])).view(B, T, cfg.heads, hd).transpose(1, 2)
+        v = _r(F.linear(h, sd[L + ".self_attn.v_proj.weight"])).view(B, T, cfg.heads, hd).transpose(1, 2)
+        q = _r(q * cos + _rot_half(q) * sin)   # (the RoPE kernel rewrites q and the cached k in bf16)
+        k = _r(k * cos + _rot_half(k) * sin)
         if cache is not None:
             if cache[i] is not None:
                 k = torch.cat([cache[i][0], k], dim=2)
@@ -302,14 +329,14 @@ def llama_forward(sd, x, cfg, cache=None, taps=None):
         Tk = k.shape[2]
         mask = torch.arange(Tk)[None, :] > (torch.arange(T)[:, None] + (Tk - T))
         s = s.masked_fill(mask, float("-inf"))
-        a = torch.softmax(s.float(), dim=-1) @ v
-        x = x + F.linear(a.transpose(1, 2).reshape(B, T, H), sd[L + ".self_attn.o_proj.weight"])
-        h = _rms(x, sd[L + ".post_attention_layernorm.weight"], cfg.rms_eps)
-        g = F.silu(F.linear(h, sd[L + ".mlp.gate_proj.weight"])) * F.linear(h, sd[L + ".mlp.up_proj.weight"])
-        x = x + F.linear(g, sd[L + ".mlp.down_proj.weight"])
+        a = _r(_r(torch.softmax(s.float(), dim=-1)) @ v)
+        x = _r(x + F.linear(a.transpose(1, 2).reshape(B, T, H), sd[L + ".self_attn.o_proj.weight"]))
+        h = _r(_rms(x, sd[L + ".post_attention_layernorm.weight"], cfg.rms_eps))
+        g = _r(F.silu(F.linear(h, sd[L + ".mlp.gate_proj.weight"])) * F.linear(h, sd[L + ".mlp.up_proj.weight"]))
+        x = _r(x + F.linear(g, sd[L + ".mlp.down_proj.weight"]))
         if taps is not None:
             taps[f"layer{i}"] = x.clone()
-    return _rms(x, sd["model.norm.weight"], cfg.rms_eps)
+    return _r(_rms(x, sd["model.norm.weight"], cfg.rms_eps))
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -318,7 +345,7 @@ def llama_forward(sd, x, cfg, cache=None, taps=None):
 def encode_images(sd, cfg, images_clip):
     """encode_images (llava_arch.py:93-96): CLIP patch features -> Linear projector (:35)."""
     f = clip_vision_features(sd, "model.vision_tower.vision_tower", images_clip, cfg.clip)
-    return _lin(sd, "model.mm_projector", f)
+    return _r(_lin(sd, "model.mm_projector", f))
 
 
 def splice_embeddings(sd, input_ids, image_features):

@@ -207,7 +207,7 @@ def test_full_width_llama_layer_matches_oracle(dev, width, mode):
     got = torch.cat(got, 1).float().cpu()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"llama {width} {mode}: hidden rel err {err:.3e}")
-    assert err <= (2e-4 if mode == "f32" else 2.5e-2)
+    assert err <= (2e-4 if mode == "f32" else 1.5e-2)   # bf16 measured 6.3e-3 (13B) ... 6.8e-3 (7B)
 
 
 @pytest.mark.parametrize("width", ["7b", "13b"])
@@ -282,7 +282,7 @@ def test_full_width_clip_layer_and_projector_match_oracle(dev, mode):
                         sd["model.mm_projector.bias"].to(dev, torch.float32)).float().cpu()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"clip-L {mode}: projected features rel err {err:.3e}")
-    assert got.shape == ref.shape == (2, 256, cfg.llm.hidden) and err <= (2e-4 if mode == "f32" else 2.5e-2)
+    assert got.shape == ref.shape == (2, 256, cfg.llm.hidden) and err <= (2e-4 if mode == "f32" else 1.2e-2)   # bf16 measured 5.0e-3
 
 
 # ---- configs[3]: fine-tune step at 7B width ---------------------------------------------------------------------------

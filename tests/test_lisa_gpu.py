@@ -58,6 +58,12 @@ def test_evaluate_matches_oracle(dev, cfg_name, mode):
     with torch.no_grad():
         ref_ids, ref_l, ref_r, ref_t = O.lisa_evaluate(sd, cfg, images_clip, images, ids, resize, orig,
                                                        max_new_tokens=forced.shape[1], forced_answer=forced, use_cache=False)
+        if mode == "bf16":
+            # the oracle with bf16 roundings at the HIP path's kernel boundaries (fp32 arithmetic between them): its own
+            # distance to the exact forward is the noise floor of ANY implementation with this storage format
+            with O.bf16_points():
+                _, pts_l, pts_r, _ = O.lisa_evaluate(sd, cfg, images_clip, images, ids, resize, orig,
+                                                     max_new_tokens=forced.shape[1], forced_answer=forced, use_cache=True)
     dtype = torch.float32 if mode == "f32" else torch.bfloat16
     model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
     out_ids, left, right, tax = model.evaluate(images_clip.to(dev), images.to(dev), ids.to(dev), resize, orig,
@@ -77,11 +83,20 @@ def test_evaluate_matches_oracle(dev, cfg_name, mode):
                 safe = ref.abs() > 1e-3
                 assert torch.equal((g > 0)[safe], (ref > 0)[safe])
             else:
-                assert err <= 6e-2 * scale, f"{name} logits rel err {err / scale}"
-                assert iou >= 0.97
+                # measured on MI355X (round 3): err / scale 5.7e-3 ... 7.2e-3, IoU 0.9949 ... 0.9979 on these seeds; the bounds
+                # are ~2x that, so a kernel that loses one more bit (let alone a 10x regression) turns this red. The
+                # bf16-points oracle is just as far from the exact forward (5e-3 ... 8.4e-3): the path is at the floor of
+                # its storage format, and it must stay within 3x of that floor measured on the same inputs.
+                pts = (pts_l if name == "left" else pts_r)[i]
+                floor = (pts - ref).abs().max().item()
+                print(f"    bf16-points oracle vs exact: {floor / scale:.3e} of scale; HIP vs bf16-points: "
+                      f"{(g - pts).abs().max().item() / scale:.3e}")
+                assert err <= 1.5e-2 * scale, f"{name} logits rel err {err / scale}"
+                assert err <= 3.0 * floor + 2e-3 * scale, f"{name}: {err / scale:.3e} vs floor {floor / scale:.3e}"
+                assert iou >= 0.985
         terr = (tax[i].cpu() - ref_t[i]).abs().max().item()
         print(f"{cfg_name}/{mode} frame{i} taxonomy err {terr:.3e}")
-        assert terr <= (1e-4 if mode == "f32" else 3e-2)
+        assert terr <= (1e-4 if mode == "f32" else 1e-3)   # measured 1.1e-4 ... 2.4e-4 in bf16 mode
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
@@ -92,7 +107,7 @@ def test_stages_match_oracle(dev, mode):
     from oracle import lisa_oracle as O
     cfg, sd, images, images_clip, ids, forced = _setup("mid", mode)
     dtype = torch.float32 if mode == "f32" else torch.bfloat16
-    tol = 2e-4 if mode == "f32" else 5e-2
+    tol = 2e-4 if mode == "f32" else 2e-2   # bf16 measured: 4.9e-3 (CLIP) ... 9.8e-3 (SAM block 3)
     model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
 
     def rel(got, ref):
@@ -219,16 +234,16 @@ def test_sam_vith_width_windowed_blocks(dev):
     for i in range(3):
         r = (taps_c[f"block{i}"] - taps_ref[f"block{i}"]).abs().max().item() / taps_ref[f"block{i}"].abs().max().item()
         print(f"vit-h width block{i} rel {r:.3e}")
-        assert r <= 5e-2
+        assert r <= 2e-2          # measured 7.9e-3 ... 9.8e-3
     print(f"compact vs padded {d_cp:.3e}, compact vs oracle {d_ref:.3e}")
-    assert d_cp <= 2e-2 and d_ref <= 1e-1
+    assert d_cp <= 1e-3 and d_ref <= 1.5e-2   # measured 0 (bit-identical) and 6.3e-3
     # norms folded into qkv / lin1 (row statistics + GEMM epilogue) against the same oracle
     with torch.no_grad():
         enc.compact_windows, enc.fold_norms = True, True
         out_f = enc(images.to(dev)).float().cpu()
     d_f = (out_f - ref_cl).abs().max().item() / scale
     print(f"folded norms vs oracle {d_f:.3e}")
-    assert d_f <= 1e-1 and (out_f - out_c).abs().max().item() / scale <= 5e-2
+    assert d_f <= 1.5e-2 and (out_f - out_c).abs().max().item() / scale <= 1.5e-2   # measured 7.1e-3
 
 
 def test_decode_graphs_match_eager(dev):
