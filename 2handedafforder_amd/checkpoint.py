@@ -74,9 +74,16 @@ def load_state_dict(version_dir, clip_dir=None, sam_ckpt=None, for_training=Fals
         cfg = config_from_dir(version_dir)
     sd = load_hf_dir(version_dir)
     if clip_dir is not None:
-        for k, v in load_hf_dir(clip_dir).items():
+        clip_sd = load_hf_dir(clip_dir)
+        # hub / transformers 4.x files carry the tower as "vision_model.*" (inside a full CLIPModel: text_model.* and the
+        # projections are ignored, as CLIPVisionModel.from_pretrained does, clip_encoder.py:25); a bare CLIPVisionModel saved by
+        # transformers 5.x has the same tensors without that prefix
+        bare = not any(k.startswith("vision_model.") for k in clip_sd)
+        for k, v in clip_sd.items():
             if k.startswith("vision_model."):
                 sd["model.vision_tower.vision_tower." + k] = v
+            elif bare and k.split(".")[0] in ("embeddings", "pre_layrnorm", "encoder", "post_layernorm"):
+                sd["model.vision_tower.vision_tower.vision_model." + k] = v
     if sam_ckpt is not None:
         for k, v in _load_file(sam_ckpt).items():
             if k.startswith("mask_decoder."):

@@ -410,5 +410,13 @@ class LisaMI355:
         cfg = checkpoint.config_from_dir(pretrained_model_name_or_path)
         if seg_token_idx is not None:
             cfg.seg_token_idx = int(seg_token_idx)
-        sd = checkpoint.load_state_dict(pretrained_model_name_or_path, vision_tower, sam_checkpoint)
+        sd = checkpoint.load_state_dict(pretrained_model_name_or_path, vision_tower, sam_checkpoint, cfg=cfg)
+        # the vocabulary is what the checkpoint's embedding holds (a merged 2HAff model carries the three added rows,
+        # train_ds.py:231-233); config.json's vocab_size is only a hint (config_from_dir's modulo rule fits 32003, not every size)
+        rows = sd["model.embed_tokens.weight"].shape[0]
+        if rows != cfg.llm.vocab:
+            cfg.llm.vocab = rows
+            cfg.im_start_idx, cfg.im_end_idx = rows - 2, rows - 1
+            if seg_token_idx is None:
+                cfg.seg_token_idx = rows - 3
         return cls(cfg, sd, dtype=torch_dtype, device=device, **kw)

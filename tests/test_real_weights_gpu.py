@@ -114,3 +114,52 @@ def test_train_merge_serve_on_checkpoint_files(dev, tmp_path, capsys, monkeypatc
     written = [th for th in (0.1, 0.2, 0.3, 0.5, 0.7) for side in ("left", "right")
                if os.path.exists(f"{tmp_path / 'vis'}{th}/kitchen/clip0/aff_{side}.png")]
     assert len(written) in (5, 10)
+
+
+def test_from_pretrained_on_files_written_by_transformers_matches_the_oracle(dev, tmp_path):
+    """f1 without the circle: the Llama shards + index + config.json and the CLIP directory under tests/golden/ were written by
+    transformers' own save_pretrained (oracle/make_golden_files.py, build container); the tensors no third-party writer exists
+    for (mm_projector, text_hidden_fcs, visual_model.* — a LISAForCausalLM cannot be constructed offline) join them as one
+    more safetensors shard written with the safetensors library, listed in HF's own index file. LisaMI355.from_pretrained on
+    that directory must serve exactly what the CPU oracle computes from the seeded state dict: fp32 logits within 1e-3, the
+    same masks, the same tokens."""
+    import shutil
+    from safetensors.torch import save_file
+    import haff  # noqa: F401
+    from haff import config as hcfg, lisa, weights as hw
+    from oracle import lisa_oracle as O
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cfg = hcfg.tiny()
+    sd = hw.make_state_dict(cfg, 41)
+    d = tmp_path / "merged"
+    shutil.copytree(os.path.join(gold, "hf_llama_tiny"), d)
+    extra = {k: v.contiguous() for k, v in sd.items()
+             if k.startswith("model.visual_model.") or k.startswith("model.text_hidden_fcs.") or k.startswith("model.mm_projector.")}
+    save_file(extra, str(d / "model-extra.safetensors"))
+    idx = json.load(open(d / "model.safetensors.index.json"))
+    idx["weight_map"].update({k: "model-extra.safetensors" for k in extra})
+    json.dump(idx, open(d / "model.safetensors.index.json", "w"))
+    c = json.load(open(d / "config.json"))
+    c["haff_geometry"] = {"name": cfg.name, "sam": {k: getattr(cfg.sam, k) for k in ("img_size", "patch", "embed_dim", "depth", "heads", "window", "global_idx")},
+                          "clip": {k: getattr(cfg.clip, k) for k in ("image", "patch", "hidden", "layers", "heads", "mlp")}}
+    json.dump(c, open(d / "config.json", "w"))       # (vocab_size stays what transformers wrote: 323, no modulo-3 hint)
+    model = lisa.LisaMI355.from_pretrained(str(d), vision_tower=os.path.join(gold, "hf_clip_tiny"), torch_dtype=torch.float32, device=dev)
+    assert model.cfg.llm.vocab == cfg.llm.vocab and model.cfg.seg_token_idx == cfg.seg_token_idx
+    rng = np.random.default_rng(3)
+    S = cfg.sam.img_size
+    images = torch.from_numpy(rng.standard_normal((2, 3, S, S), dtype=np.float32))
+    clip = torch.from_numpy(rng.standard_normal((2, 3, 224, 224), dtype=np.float32))
+    ids = torch.tensor([[cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx, 9, 8, 7, 6]]).expand(2, -1).contiguous()
+    forced = torch.tensor([[5, cfg.seg_token_idx, cfg.eos_token_id]]).expand(2, -1).contiguous()
+    sizes, orig = [(S, S)] * 2, [(S, S), (150, 200)]
+    with torch.no_grad():
+        r_ids, r_l, r_r, r_t = O.lisa_evaluate(sd, cfg, clip, images, ids, sizes, orig, max_new_tokens=3, forced_answer=forced, use_cache=True)
+    o_ids, left, right, tax = model.evaluate(clip.to(dev), images.to(dev), ids.to(dev), sizes, orig, max_new_tokens=3, forced_answer=forced)
+    assert torch.equal(o_ids.cpu(), r_ids)
+    for got, ref in list(zip(left, r_l)) + list(zip(right, r_r)):
+        g = got.cpu()
+        assert (g - ref).abs().max().item() <= 1e-3
+        safe = ref.abs() > 1e-3
+        assert torch.equal((g > 0)[safe], (ref > 0)[safe])
+    for got, ref in zip(tax, r_t):
+        assert (got.cpu() - ref).abs().max().item() <= 1e-4
