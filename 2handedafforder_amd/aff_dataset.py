@@ -7,15 +7,21 @@ and `masks = {aff_left: [contour, ...], aff_right: [...], original_size: (h, w)}
 masks re-drawn from the contours, the question/answer templates of :29-46, one llava_v1 conversation, CLIP and SAM
 preprocessing, and the 11/12-tuple that `collate_fn` (utils/dataset.py:30-169 = train_ds.collate_fn here) consumes.
 
-Differences, both forced by this image (parity unpinned): contours are filled with PIL's polygon rasteriser instead of
-`cv2.drawContours(..., FILLED)` (identical interior, boundary pixels may differ by one), and the local h5/json layout
-(`_load_from_local`, :152-183) needs h5py, which is not installed — `from_local` raises with that message.
+`AffValDataset` mirrors `AffDatasetVal` (:350-544): the benchmark folder walk (`<root>/<video>/<frame>/{inpainting.png,
+aff_left.png, aff_right.png, annotation.json}`, a missing hand is an all-zero mask, frames without an image / annotation /
+any mask are skipped), the same 12-tuple with `inference=True`.
+
+Contours are filled by `cvlite.draw_contours_filled`, a restatement of `cv2.drawContours(..., FILLED)` from OpenCV's published
+sources (this image has no cv2; tests/test_cvlite_cpu.py holds hand-derived fixtures — parity with cv2 itself is unpinned).
+The local h5/json layout (`_load_from_local`, :152-183) needs h5py, which is not installed — `from_local` raises with that
+message.
 """
 import random
 
 import numpy as np
 import torch
 
+from . import cvlite
 from . import preprocess
 from . import prompt as hprompt
 
@@ -29,20 +35,9 @@ ANSWER_LIST = ["It is [SEG].", "Sure, [SEG].", "Sure, it is [SEG].", "Sure, the 
 
 
 def recreate_mask_from_contours(contours, shape):
-    """aff_dataset.py:340-346: binary uint8 mask of `shape` = (h, w) with every contour filled."""
-    from PIL import Image, ImageDraw
-    h, w = int(shape[0]), int(shape[1])
-    img = Image.new("L", (w, h), 0)
-    draw = ImageDraw.Draw(img)
-    for contour in contours or []:
-        pts = np.asarray(contour, dtype=np.int64).reshape(-1, 2)
-        if len(pts) == 1:
-            draw.point([tuple(pts[0])], fill=1)
-        elif len(pts) == 2:
-            draw.line([tuple(p) for p in pts], fill=1)
-        elif len(pts) > 2:
-            draw.polygon([tuple(p) for p in pts], fill=1, outline=1)
-    return np.array(img, dtype=np.uint8)
+    """aff_dataset.py:340-346: binary uint8 mask of `shape` = (h, w) with every contour filled
+    (`cv2.drawContours(mask, [np.array(contour, np.int32)], -1, 1, thickness=cv2.FILLED)` per contour)."""
+    return cvlite.draw_contours_filled(shape, contours, 1)
 
 
 def _taxonomy_vector(t):
@@ -121,3 +116,70 @@ class AffRecordsDataset(torch.utils.data.Dataset):
         out = (None, image_t, image_clip, [conv.get_prompt()], torch.from_numpy(left).unsqueeze(0),
                torch.from_numpy(right).unsqueeze(0), taxonomy, label, resize, [question], [text])
         return out + (self.inference,)
+
+
+class AffValDataset(torch.utils.data.Dataset):
+    """AffDatasetVal (aff_dataset.py:350-544): the ActAffordance-style benchmark folders as validation samples."""
+
+    def __init__(self, base_image_dir, cfg, seed=None):
+        self.cfg = cfg
+        self.images, self.affs_left, self.affs_right, self.narrations, self.taxonomies = self.load_data_from_nested_folders(base_image_dir)
+        self.size = len(self.images)
+        self.rng = random.Random(seed)
+
+    def __len__(self):
+        return self.size
+
+    @staticmethod
+    def load_data_from_nested_folders(root_folder):
+        """:457-544. Two directory levels; a leaf needs inpainting.png, annotation.json and at least one of aff_left.png /
+        aff_right.png (the missing hand becomes zeros of the other's shape). Masks are read as 8-bit grayscale
+        (cv2.imread(..., IMREAD_GRAYSCALE): identical to PIL's "L" for the single-channel PNGs the benchmark ships)."""
+        import json
+        import os
+        from PIL import Image
+        images, lefts, rights, narrations, taxonomies = [], [], [], [], []
+        for l1 in os.listdir(root_folder):
+            p1 = os.path.join(root_folder, l1)
+            if not os.path.isdir(p1):
+                continue
+            for l2 in os.listdir(p1):
+                p2 = os.path.join(p1, l2)
+                if not os.path.isdir(p2):
+                    continue
+                files = set(os.listdir(p2))
+                has_l, has_r = "aff_left.png" in files, "aff_right.png" in files
+                if "inpainting.png" not in files or "annotation.json" not in files or not (has_l or has_r):
+                    continue
+                images.append(np.array(Image.open(os.path.join(p2, "inpainting.png"))))
+                left = np.array(Image.open(os.path.join(p2, "aff_left.png")).convert("L")) if has_l else None
+                right = np.array(Image.open(os.path.join(p2, "aff_right.png")).convert("L")) if has_r else None
+                lefts.append(left if left is not None else np.zeros_like(right))
+                rights.append(right if right is not None else np.zeros_like(left))
+                with open(os.path.join(p2, "annotation.json")) as f:
+                    ann = json.load(f)
+                narrations.append(ann.get("narration", ""))
+                taxonomies.append(ann.get("taxonomy", ""))
+        return images, lefts, rights, narrations, taxonomies
+
+    def __getitem__(self, idx):
+        idx = self.rng.randint(0, self.size - 1)                         # :394 — the reference draws a random sample here too
+        text, image, taxonomy = self.narrations[idx], self.images[idx], self.taxonomies[idx]
+        if image.ndim == 2:
+            image = np.stack([image] * 3, -1)
+        image = np.ascontiguousarray(image[..., :3]).astype(np.uint8)
+        left, right = self.affs_left[idx], self.affs_right[idx]
+        label = {"left": torch.from_numpy((left == 0).astype(np.int64) * 255),
+                 "right": torch.from_numpy((right == 0).astype(np.int64) * 255)}
+        cfg = self.cfg
+        image_clip = preprocess.clip_preprocess(torch.from_numpy(image.copy()), cfg.clip.image)
+        resized = preprocess.resize_longest_side(torch.from_numpy(image.copy()), cfg.sam.img_size)
+        resize = tuple(resized.shape[:2])
+        image_t = preprocess.sam_preprocess(resized, cfg.sam.img_size)
+        question = self.rng.choice(SHORT_QUESTION_LIST).format(class_name=text.lower())
+        answer = self.rng.choice(ANSWER_LIST)
+        conv = hprompt.conv_llava_v1()
+        conv.append_message(conv.roles[0], question)
+        conv.append_message(conv.roles[1], answer)
+        return (None, image_t, image_clip, [conv.get_prompt()], torch.from_numpy(left).unsqueeze(0),
+                torch.from_numpy(right).unsqueeze(0), taxonomy, label, resize, [question], [text], True)

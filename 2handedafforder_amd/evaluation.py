@@ -7,11 +7,12 @@ takes the union of both hands on each side (a missing hand counts as empty, :243
 threshold folders are swept and the best-IoCM one is reported together with the mean over thresholds (:321-343).
 
 Exact restatements: `calculate_iou` (:26-41), `calculate_iocm` (:97-114), the union / missing-hand rules, the
-averaging and threshold selection, the CLI flags. Approximation (no OpenCV in this image, parity unpinned): the
-reference resizes predictions with `cv2.resize` (bilinear, no antialias -> here `F.interpolate(bilinear,
-align_corners=False)`), and feeds `directed_hausdorff` the vertices of the FIRST external contour OpenCV returns
-(`findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)[0][0]`, :9-24); here every boundary pixel of the mask is used, which
-is an upper bound of that point set. Visualisation overlays (:43-95) are not reproduced.
+averaging and threshold selection, the CLI flags, and `calculate_hausdorff` (:9-24) on the point set the reference uses: the
+vertices of the FIRST external contour OpenCV returns (`findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)[0][0]`, first contour
+only) — through `cvlite.find_contours_external`, a restatement of OpenCV's border follower (no cv2 in this image: fixtures
+hand-derived, tests/test_cvlite_cpu.py; parity with cv2 itself unpinned). Approximation: the reference resizes predictions with
+`cv2.resize` (bilinear, no antialias -> here `F.interpolate(bilinear, align_corners=False)`). Visualisation overlays (:43-95) are
+not reproduced.
 """
 import argparse
 import os
@@ -37,31 +38,23 @@ def calculate_iocm(benchmark_mask, comparison_mask):
     return float(inter) / float(area) if area != 0 else 0.0
 
 
-def boundary_points(mask):
-    """(x, y) coordinates of the mask pixels that touch the background (4-neighbourhood) or the image border."""
-    m = np.asarray(mask, dtype=bool)
-    if not m.any():
-        return np.zeros((0, 2), dtype=np.float64)
-    p = np.pad(m, 1, constant_values=False)
-    interior = p[:-2, 1:-1] & p[2:, 1:-1] & p[1:-1, :-2] & p[1:-1, 2:]
-    ys, xs = np.nonzero(m & ~interior)
-    return np.stack([xs, ys], axis=1).astype(np.float64)
-
-
 def calculate_hausdorff(mask1, mask2):
-    """calculate_iou.py:9-24 on boundary pixels: (directed mask2->mask1, symmetric). Empty prediction -> the image
-    diagonal for both; empty benchmark -> 0 for both (the reference's early returns)."""
+    """calculate_iou.py:9-24: (directed mask2 -> mask1, symmetric) Hausdorff distance between the CHAIN_APPROX_SIMPLE vertices of
+    the first external contour of each mask. Empty prediction (mask2) -> the image diagonal for both; empty benchmark -> 0."""
     from scipy.spatial.distance import directed_hausdorff
+    from . import cvlite
     shp = mask1.shape
-    p1, p2 = boundary_points(mask1), boundary_points(mask2)
-    if len(p2) == 0:
+    c1 = cvlite.find_contours_external(np.asarray(mask1).astype(np.uint8))
+    c2 = cvlite.find_contours_external(np.asarray(mask2).astype(np.uint8))
+    if len(c2) == 0:
         d = float(np.sqrt(shp[0] ** 2 + shp[1] ** 2))
         return d, d
-    if len(p1) == 0:
-        return 0.0, 0.0
+    if len(c1) == 0:
+        return 0, 0
+    p1 = c1[0].reshape(-1, 2).astype(np.float64)      # np.vstack(contours[0]).squeeze(), a single point kept 2-D
+    p2 = c2[0].reshape(-1, 2).astype(np.float64)
     d21 = directed_hausdorff(p2, p1)[0]
-    d12 = directed_hausdorff(p1, p2)[0]
-    return float(d21), float(max(d12, d21))
+    return float(d21), float(max(directed_hausdorff(p1, p2)[0], d21))
 
 
 def _read_gray(path):

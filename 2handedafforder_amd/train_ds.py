@@ -63,6 +63,9 @@ def parse_args(args):
     p.add_argument("--beta1", default=0.9, type=float)
     p.add_argument("--beta2", default=0.95, type=float)
     p.add_argument("--no_eval", action="store_true", default=False)
+    p.add_argument("--benchmark_dir", default="", type=str,
+                   help="validation folders <root>/<video>/<frame>/{inpainting.png, aff_left.png, aff_right.png, annotation.json} "
+                        "(AffDatasetVal, train_ds.py:121,330-336 of the reference); empty: validate on held-out training records")
     p.add_argument("--eval_only", action="store_true", default=False)
     p.add_argument("--vision_pretrained", default="PATH_TO_SAM_ViT-H", type=str)
     p.add_argument("--out_dim", default=256, type=int)
@@ -327,6 +330,11 @@ def main(argv):
         else:
             train_ds = AffRecordsDataset.from_hf(args.dataset_dir, cfg, seed=args.seed + 1000 * rank)
             val_ds = AffRecordsDataset.from_hf(args.dataset_dir, cfg, samples_per_epoch=args.val_samples, inference=True, seed=777)
+    if not args.synthetic and args.benchmark_dir and os.path.isdir(args.benchmark_dir) and not args.no_eval:
+        AffValDataset = sys.modules[AffRecordsDataset.__module__].AffValDataset   # the reference's validation set (train_ds.py:330-336)
+        val_ds = AffValDataset(args.benchmark_dir, cfg, seed=777)
+        if rank == 0:
+            print(f"Training with {len(train_ds)} examples and validating with {len(val_ds)} examples.")
     total_steps = args.epochs * args.steps_per_epoch
     if args.eval_only:
         iou, iocm = validate(model, val_ds, tokenizer, args, rank, world, device)
