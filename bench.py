@@ -300,6 +300,99 @@ def base_line(fps, world, steps, warmup, ms_per_step, workload, B, extra_cfg):
             "dtype": "bf16", "data": "synthetic", "config": cfg, "frames_per_s_per_gpu": fps / world}
 
 
+def make_train_batch(cfg, b, n_ids, mask_hw, device, seed=0):
+    """One synthetic 2HANDS micro-batch in collate_fn's layout (utils/dataset.py:152-169): b conversations of n_ids ids (n_ids + 255
+    expanded tokens), one [SEG] each, left / right masks of mask_hw, soft taxonomy targets."""
+    g = torch.Generator().manual_seed(seed)
+    S = cfg.sam.img_size
+    hi = min(cfg.llm.vocab, cfg.seg_token_idx) - 1
+    ids = torch.randint(3, hi, (b, n_ids), generator=g)
+    ids[:, 0], ids[:, 1], ids[:, 2], ids[:, 3] = cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx
+    ids[:, n_ids - 3], ids[:, n_ids - 1] = cfg.seg_token_idx, cfg.eos_token_id
+    labels = ids.clone()
+    labels[:, :n_ids - 8] = -100
+    return dict(images=torch.randn((b, 3, S, S), generator=g).to(device, torch.bfloat16),
+                images_clip=torch.randn((b, 3, cfg.clip.image, cfg.clip.image), generator=g).to(device, torch.bfloat16),
+                input_ids=ids.to(device), labels=labels.to(device), attention_masks=torch.ones_like(ids, dtype=torch.bool).to(device),
+                offset=torch.arange(b + 1).to(device),
+                masks_list_left=[(torch.rand((1,) + mask_hw, generator=g) > 0.5).float().to(device) for _ in range(b)],
+                masks_list_right=[(torch.rand((1,) + mask_hw, generator=g) > 0.5).float().to(device) for _ in range(b)],
+                label_list=[{"left": torch.zeros(mask_hw), "right": torch.zeros(mask_hw)} for _ in range(b)], resize_list=[(S, S)] * b,
+                taxonomies_list=torch.eye(4)[torch.arange(b) % 4].to(device), inference=False)
+
+
+def train_main(args):
+    """--mode train: BASELINE.json configs[3] — LoRA fine-tune (train_ds.py path), bf16, 8 synthetic 2HANDS samples per GPU per
+    step (global batch 64 on 8 GPUs), 96-id conversations (351 expanded tokens), 1024^2 masks. A step = forward + backward of
+    one micro-batch, the all-reduce of the trainable set's gradients (GradBucketReducer: RCCL when N > 1, launched from backward
+    hooks) and the fused clip + AdamW update — nothing skipped. value = samples/s over all ranks."""
+    from haff import train_ops as T
+    from haff.train_model import LisaTrainable
+    rank, world, local_rank = hdist.init_from_env("nccl")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
+    sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
+    model = LisaTrainable(cfg, sd, dtype=torch.bfloat16, device=device)
+    del sd
+    torch.cuda.empty_cache()
+    b = args.batch if args.batch != 64 else 8
+    batch = make_train_batch(cfg, b, args.train_ids, (args.train_mask, args.train_mask), device, seed=1234 + rank)
+    named = list(model.named_parameters())
+    states = {k: T.AdamWState(p) for k, p in named}
+    reducer = T.GradBucketReducer(named)
+    losses = []
+
+    def step():
+        reducer.zero()
+        reducer.begin(sync=True)
+        out = model(**batch)
+        out["loss"].backward()
+        reducer.finish()
+        norm = float(T.grad_norm(reducer.grads()))      # the step's one host read (clip_grad_norm's scalar, train_ds.py:381)
+        gscale = min(1.0, 1.0 / (norm + 1e-6))
+        for k, p in named:
+            T.adamw_step(states[k], p.grad, lr=3e-4, gscale=gscale, param_lp=p.data)
+        losses.append(out["loss"].detach())
+    for _ in range(args.warmup):
+        step()
+    elapsed = hdist.timed_steps(step, args.steps, device)
+    ms_per_step = 1e3 * elapsed / args.steps
+    sps = world * b * args.steps / elapsed
+    if rank == 0:
+        with GemmMeter() as meter:
+            step()
+        n_launch, gemm_ms, gemm_fl, gemm_bytes = meter.summary()
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        n_train = sum(p.numel() for _, p in named)
+        line = {"metric": "LoRA fine-tune samples/sec (train_ds.py path), bf16", "value": sps, "unit": "samples/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "BASELINE.json configs[3]: %s LoRA fine-tune (r=8 on q/v_proj + embed_tokens, lm_head, text_hidden_fcs, "
+                                       "both mask decoders: %.0f M trainable), %d samples/step/GPU, %d-id conversations (%d expanded tokens), "
+                                       "%dx%d masks, forward + backward + gradient all-reduce + AdamW" %
+                                       (cfg.name, n_train / 1e6, b, args.train_ids, args.train_ids + 255, args.train_mask, args.train_mask),
+                           "samples_per_step_per_gpu": b,
+                           "parallelism": "sample-sharded DDP x%d (all-reduce of %.2f GB of bf16/fp32 gradients per step in %d buckets)" %
+                                          (world, sum(f.numel() * f.element_size() for f in reducer.grads()) / 1e9, len(reducer.buckets))},
+                "samples_per_s_per_gpu": sps / world,
+                "loss_first_last": [float(losses[0]), float(losses[-1])],
+                "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (every haff_gemm_bf16 launch with M > 64 of the step: forward, dX and dW products)",
+                             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                             "traffic": None, "launches_per_step": n_launch, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
+                             "flops_per_launch_avg": gemm_fl / max(n_launch, 1), "algorithmic_bytes_per_launch_avg": gemm_bytes / max(n_launch, 1),
+                             "gemm_share_of_step": gemm_ms / ms_per_step,
+                             "executed_gemm_flop_per_sample": meter.total_gemm_flop() / b},
+                "cpu_baseline": None,
+                "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def stub_main(args):
     """The N-rank control path of this file with the model replaced by a sleep (CPU, gloo): same rendezvous, same
     fence | K steps | fence | max-over-ranks, same single JSON line from rank 0, same teardown."""
@@ -339,6 +432,10 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer: BASELINE configs[2] (the headline metric); train: configs[3], one LoRA fine-tune step per step")
+    ap.add_argument("--train-ids", type=int, default=96)
+    ap.add_argument("--train-mask", type=int, default=1024)
     ap.add_argument("--stub-step-ms", type=float, default=None,
                     help="TEST ONLY (tests/test_dist_gloo.py): replace the model by a sleep of this many ms and rendezvous "
                          "over gloo on the CPU, to exercise the multi-rank fence / timing / reporting path without GPUs")
@@ -348,6 +445,8 @@ def main(argv=None):
         return stub_main(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.mode == "train":
+        return train_main(args)
     rank, world, local_rank = hdist.init_from_env("nccl")  # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

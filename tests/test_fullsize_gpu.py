@@ -130,3 +130,55 @@ def test_full_size_13b_batch8_config(dev):
     model.decode_graphs = False
     c = run()
     assert all(torch.equal(x, y) for x, y in zip(a, c)), "hipGraph decode differs from eager decode (13B)"
+
+
+def test_full_depth_7b_finetune_step_properties(dev):
+    """BASELINE.json configs[3] at its REAL geometry — 32-layer Llama-7B + ViT-H + CLIP-L, LoRA r=8 on q/v_proj + embed_tokens,
+    lm_head, text_hidden_fcs and both mask decoders trainable, 8 samples per micro-batch, 96-id conversations (351 expanded
+    tokens), 1024^2 masks, bf16 — through properties the size leaves testable (the oracle's autograd cannot run it in a test;
+    tests/test_configs_gpu.py::test_finetune_forward_backward_at_7b_width checks the arithmetic at full width, depth 1):
+      * all six losses finite; the bucket layout is flat per dtype (a handful of buckets, 0.59 GB of gradients);
+      * the same step from the same state is bitwise repeatable (loss AND every gradient bucket);
+      * three optimizer steps lower the loss."""
+    import haff  # noqa: F401
+    from bench import make_train_batch
+    from haff import checkpoint, config as hcfg, train_ops as T
+    from haff.train_model import LisaTrainable
+    cfg = hcfg.haff_7b()
+    sd = checkpoint.synthetic_state_dict(cfg, 1234, dev, torch.bfloat16)
+    model = LisaTrainable(cfg, sd, dtype=torch.bfloat16, device=dev)
+    del sd
+    torch.cuda.empty_cache()
+    batch = make_train_batch(cfg, 8, 96, (1024, 1024), dev, seed=3)
+    named = list(model.named_parameters())
+    n_train = sum(p.numel() for _, p in named)
+    assert 285e6 < n_train < 305e6, n_train                       # SURVEY 8(a17): 294 M trainable at 7B
+    reducer = T.GradBucketReducer(named)
+    gbytes = sum(f.numel() * f.element_size() for f in reducer.grads())
+    assert len(reducer.buckets) <= 16 and 0.55e9 < gbytes < 0.70e9, (len(reducer.buckets), gbytes)
+    states = {k: T.AdamWState(p) for k, p in named}
+
+    def fwd_bwd():
+        reducer.zero()
+        reducer.begin(sync=True)
+        out = model(**batch)
+        out["loss"].backward()
+        reducer.finish()
+        return out
+    out = fwd_bwd()
+    for k in ("loss", "ce_loss", "taxonomy_ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss"):
+        assert bool(torch.isfinite(out[k]).all()), k
+    g0 = [f.clone() for f in reducer.grads()]
+    l0 = out["loss"].detach().clone()
+    assert all(bool(torch.isfinite(f.float()).all()) for f in g0) and any(bool((f != 0).any()) for f in g0)
+    out = fwd_bwd()                                                # same weights, same batch: bit for bit
+    assert torch.equal(out["loss"].detach(), l0), "loss not repeatable"
+    assert all(torch.equal(a, b) for a, b in zip(reducer.grads(), g0)), "gradients not repeatable"
+    losses = [float(l0)]
+    for _ in range(3):
+        norm = float(T.grad_norm(reducer.grads()))
+        for k, p in named:
+            T.adamw_step(states[k], p.grad, lr=3e-4, gscale=min(1.0, 1.0 / (norm + 1e-6)), param_lp=p.data)
+        losses.append(float(fwd_bwd()["loss"]))
+    print("7B full-depth fine-tune losses:", ["%.4f" % v for v in losses], "peak HBM %.1f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30))
+    assert losses[-1] < losses[0], losses

@@ -28,22 +28,9 @@ def main():
     model = LisaTrainable(cfg, sd, dtype=torch.bfloat16, device=dev)
     del sd
     torch.cuda.empty_cache()
-    b, L, S = args.batch, args.ids, cfg.sam.img_size
-    g = torch.Generator().manual_seed(0)
-    hi = min(cfg.llm.vocab, cfg.seg_token_idx) - 1
-    ids = torch.randint(3, hi, (b, L), generator=g)
-    ids[:, 0], ids[:, 1], ids[:, 2], ids[:, 3] = cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx
-    ids[:, L - 3], ids[:, L - 1] = cfg.seg_token_idx, cfg.eos_token_id
-    labels = ids.clone()
-    labels[:, :L - 8] = -100
-    hw = (args.mask, args.mask)
-    batch = dict(images=torch.randn((b, 3, S, S), generator=g).to(dev, torch.bfloat16),
-                 images_clip=torch.randn((b, 3, 224, 224), generator=g).to(dev, torch.bfloat16), input_ids=ids.to(dev),
-                 labels=labels.to(dev), attention_masks=torch.ones_like(ids, dtype=torch.bool).to(dev), offset=torch.arange(b + 1).to(dev),
-                 masks_list_left=[(torch.rand((1,) + hw, generator=g) > 0.5).float().to(dev) for _ in range(b)],
-                 masks_list_right=[(torch.rand((1,) + hw, generator=g) > 0.5).float().to(dev) for _ in range(b)],
-                 label_list=[{"left": torch.zeros(hw), "right": torch.zeros(hw)} for _ in range(b)], resize_list=[(S, S)] * b,
-                 taxonomies_list=torch.eye(4)[torch.arange(b) % 4].to(dev), inference=False)
+    b = args.batch
+    import bench
+    batch = bench.make_train_batch(cfg, b, args.ids, (args.mask, args.mask), dev)
     states = {k: T.AdamWState(p) for k, p in model.named_parameters()}
     print("trainable params %.1f M, HBM allocated %.1f GB" % (sum(p.numel() for p in model.parameters()) / 1e6,
                                                                torch.cuda.memory_allocated() / 2 ** 30), flush=True)
