@@ -138,7 +138,8 @@ def test_full_depth_7b_finetune_step_properties(dev):
     tokens), 1024^2 masks, bf16 — through properties the size leaves testable (the oracle's autograd cannot run it in a test;
     tests/test_configs_gpu.py::test_finetune_forward_backward_at_7b_width checks the arithmetic at full width, depth 1):
       * all six losses finite; the bucket layout is flat per dtype (a handful of buckets, 0.59 GB of gradients);
-      * the same step from the same state is bitwise repeatable (loss AND every gradient bucket);
+      * the same step from the same state and the same dropout seed repeats to summation noise (fp32 atomics in the loss sums,
+        bias column sums, bilinear adjoint and embedding scatter make the last bits order-dependent: stated, not hidden);
       * three optimizer steps lower the loss."""
     import haff  # noqa: F401
     from bench import make_train_batch
@@ -158,7 +159,8 @@ def test_full_depth_7b_finetune_step_properties(dev):
     assert len(reducer.buckets) <= 16 and 0.55e9 < gbytes < 0.70e9, (len(reducer.buckets), gbytes)
     states = {k: T.AdamWState(p) for k, p in named}
 
-    def fwd_bwd():
+    def fwd_bwd(seed=7):
+        torch.manual_seed(seed)             # the LoRA dropout masks (p = 0.05) come from torch's device generator
         reducer.zero()
         reducer.begin(sync=True)
         out = model(**batch)
@@ -171,9 +173,26 @@ def test_full_depth_7b_finetune_step_properties(dev):
     g0 = [f.clone() for f in reducer.grads()]
     l0 = out["loss"].detach().clone()
     assert all(bool(torch.isfinite(f.float()).all()) for f in g0) and any(bool((f != 0).any()) for f in g0)
-    out = fwd_bwd()                                                # same weights, same batch: bit for bit
-    assert torch.equal(out["loss"].detach(), l0), "loss not repeatable"
-    assert all(torch.equal(a, b) for a, b in zip(reducer.grads(), g0)), "gradients not repeatable"
+    out = fwd_bwd()                                                # same weights, same batch, same dropout masks
+    # NOT bit for bit: the loss sums (BCE / dice partials), the bias column sums, the bilinear adjoint, the embedding-row scatter and
+    # the gradient norm accumulate with fp32 atomics (train.hip), whose order varies from run to run. What is held: the loss to
+    # fp32 summation noise, every gradient tensor to a small fraction of its own scale.
+    dl = abs(float(out["loss"]) - float(l0)) / abs(float(l0))
+    worst = ("", 0.0)
+    for b_, ref in zip(reducer.buckets, g0):
+        off = 0
+        floor_ = 1e-3 * ref.float().abs().max().item()   # (a key-projection bias has a mathematically ZERO gradient: softmax is
+        for name_, p_ in zip(b_["names"], b_["params"]):   # shift-invariant; its numerical value is noise, compared on the bucket's scale)
+            n_ = p_.numel()
+            a_, r_ = b_["flat"][off:off + n_].float(), ref[off:off + n_].float()
+            rel_ = (a_ - r_).abs().max().item() / max(r_.abs().max().item(), floor_)
+            if name_.endswith("k_proj.bias"):   # exactly-zero gradient in exact arithmetic: what is stored is the rounding residue of
+                rel_ = 0.0                      # a cancelling atomic sum over 4096 keys x prompts; nothing to repeat
+            if rel_ > worst[1]:
+                worst = (name_, rel_)
+            off += n_
+    print(f"repeat run: loss rel diff {dl:.2e}; worst gradient tensor {worst[0]} rel diff {worst[1]:.2e}")
+    assert dl <= 1e-5 and worst[1] <= 5e-2, (dl, worst)   # measured 0 and 1.45e-2 (layer-0 LoRA B: 32 bf16 layers below the loss)
     losses = [float(l0)]
     for _ in range(3):
         norm = float(T.grad_norm(reducer.grads()))
