@@ -1465,9 +1465,10 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   if (big) {
     // (sweep of 1..32 on the bench shapes, tools/gemm_variant.py with HAFF_GEMM_GROUP_M: <= 5 N-tiles: 1 (+4 % on
     // 131072x1280x1280), <= 16 N-tiles: 4 (+1.4 % on 131072x3840x1280), 20 N-tiles: 8; all within 3 % of each other)
+    // (round 3, ring loop: <= 5 N-tiles 1; long K with <= 8 N-tiles 2; <= 16 N-tiles 4 (18624x4096x11008: 1351 vs 1315 at 2); 8)
     const int tn = (N + 255) / 256;
     if (tn <= 5) p.group_m = 1;
-    else if (K >= 5120 && tn <= 32) p.group_m = 2;
+    else if (K >= 5120 && tn <= 8) p.group_m = 2;
     else if (tn <= 16) p.group_m = 4;
   }
 #ifdef HAFF_TUNING
