@@ -23,6 +23,8 @@
 // both terms up in an LDS copy (windows, S<=32).
 #include "haff_common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct AttnArgs {
@@ -480,6 +482,496 @@ int launch_attn(const AttnArgs& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// SAM global attention (image_encoder.py:235-260 at 64x64 tokens, d = 80, decomposed rel-pos), 8-wave ping-pong form.
+//
+// Why a second kernel: in attn_fwd_kernel every wave runs  QK MFMAs -> softmax VALU -> PV MFMAs  back to back and the two
+// waves a SIMD holds mostly march in step (one barrier per KV tile), so the matrix pipe idles through the softmax and the
+// VALU through the MFMAs: 36 % MFMA-busy + 44 % VALU-busy, serialised (profiles/r2_pmc_attn_global.csv). Here a workgroup
+// is 8 waves = two groups of 4 (group g = wave >> 2; waves w and w+4 share a SIMD), 256 queries, and the groups run ONE
+// SLOT apart, two barriers per KV tile:
+//
+//     slot        group 0                       group 1
+//     2t+1        PV(t-1) + QK(t)   [MFMA]      softmax(t-1)      [VALU]
+//     2t+2        softmax(t)        [VALU]      PV(t-1) + QK(t)   [MFMA]
+//
+// so each SIMD always has one wave on the matrix pipe and one on the VALU. K/V tiles come in by LDS-DMA
+// (global_load_lds_dwordx4, slot-linear image: K rows 11 x 16 B = 10 data chunks + 1 pad chunk, V rows 10 chunks — the
+// window kernel's layout; the pad chunk re-reads chunk 0 of its row and is never consumed), four stages each; the request /
+// wait schedule is written out at `tile` below.
+// rel_h of the workgroup's 256 queries (256 x 64 fp32, contiguous in the table) is copied to LDS once: the tile loop then
+// holds no global load except the DMA, so the counted waits are exactly the ones written here.
+// The softmax denominator comes out of one extra MFMA per (k-step, q-tile) against a register fragment of ones (the same
+// bf16-rounded probabilities the numerator sums; attn_fwd_kernel's LSUM did this through a ones-column staged in LDS).
+//
+// Measured (32 frames x 16 heads, tools/attn_variant.py, profiles/r3_attn_pp_ablate.txt): 3.41 ms against 4.18 ms for
+// attn_fwd_kernel on the same box (0.81x; 806 vs 657 TFLOP/s of useful work). What bounds it now is the SIMD's single vector
+// issue port, which the two co-resident waves share: the MFMA slot's 48 MFMAs take ~1150 cycles, not 768, because the
+// partner's exponentials / conversions / DMA requests are issued between them (an 8-cycle v_exp_f32 in flight delays the next
+// MFMA; s_setprio cannot preempt it); without the DMA requests the launch takes 2.90 ms, without the exponentials 2.87 ms.
+// Ten forms were timed on the way (header of profiles/r3_attn_pp_ablate.txt): reading next slot's fragments in the VALU slot
+// made THAT slot the long one (24 LDS reads against the other group's: 3.9-4.1 ms); a per-tile cross-lane maximum with an
+// eager rescale cost 14 % (rescales fired on 60 % of the tiles of random data); joined rescale arms make hipcc copy all 72
+// accumulator / score registers on the common path.
+constexpr int PPQ = 256;                         // queries per workgroup
+constexpr int PP_D = 80, PP_CPR = PP_D / 8;      // head dim, 16-B chunks per row
+constexpr int PP_KSTR = (PP_CPR + 1) * 16, PP_VSTR = PP_CPR * 16;
+constexpr int PP_KBYTES = KT * PP_KSTR, PP_VBYTES = KT * PP_VSTR;
+constexpr int PP_KINS = PP_KBYTES / 1024, PP_VINS = PP_VBYTES / 1024;   // DMA instructions (64 lanes x 16 B) per tile
+constexpr int PP_NST = 4;
+constexpr int PP_RSTR = KT + 1;                  // rel_h row stride in floats (odd: 16 query lanes -> 16 banks)
+constexpr int PP_LDS = PP_NST * (PP_KBYTES + PP_VBYTES) + PPQ * PP_RSTR * 4;   // stages, rel_h
+constexpr float PP_LAZY = 40.f;                  // log2 units a score may exceed the softmax reference before the reference is moved
+static_assert(PP_KBYTES % 1024 == 0 && PP_VBYTES % 1024 == 0, "whole DMA instructions per tile");
+static_assert(PP_LDS <= 160 * 1024, "LDS");
+
+#if defined(HAFF_TUNING) && defined(HAFF_PP_TRACE)
+// cycle stamps of waves 0 and 4 of the first 256 workgroups, KV tiles 16..19: [wg][group][tile][8]
+__device__ unsigned long long haff_pp_trace_buf[256 * 2 * 4 * 8];
+#define PP_STAMP(i) do { if ((tid & 255) == 0 && blockIdx.x < 256 && kt >= 16 && kt < 20) \
+    haff_pp_trace_buf[((blockIdx.x * 2 + grp) * 4 + (kt - 16)) * 8 + (i)] = clock64(); } while (0)
+#else
+#define PP_STAMP(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
+  constexpr int NKD = 3, ND = 5;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+  float* sRh = reinterpret_cast<float*>(smem_raw + PP_NST * (PP_KBYTES + PP_VBYTES));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int fr = lane & 15, fh = lane >> 4;
+  const int nqb = p.Nq / PPQ;
+  const int nbh = p.B * p.H;
+  int bh_id, qblk;
+  {
+    const int id = blockIdx.x;   // same XCD-aware decode as attn_fwd_kernel
+    if ((nbh & 7) == 0) {
+      bh_id = (id & 7) + 8 * (id / (8 * nqb));
+      qblk = (id >> 3) % nqb;
+    } else {
+      bh_id = id / nqb;
+      qblk = id - bh_id * nqb;
+    }
+  }
+  const int b = bh_id / p.H, h = bh_id - b * p.H;
+  const int q0 = qblk * PPQ;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
+  const bf16_t* kb = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
+  const long bh = (long)b * p.H + h;
+  const int nkt = p.Nk / KT;
+
+  // ---- DMA plan: combined instruction index n = wave + 8 i (n < 11: K, else V), lane -> slot -> source byte offset ----
+  constexpr int NINS = PP_KINS + PP_VINS;   // 21
+  unsigned d_off[3];
+  const unsigned v_minus_k = (unsigned)((p.v - p.k) * 2);   // bytes; host checked: same for every (batch, head), >= 0
+  int n_kins = 0, n_vins = 0;                                // this wave's instructions per K tile / per V tile
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int n = wave + 8 * i;
+    unsigned off = 0;
+    if (n < PP_KINS) {
+      const int g = n * 64 + lane, row = g / (PP_CPR + 1), c = g - row * (PP_CPR + 1);
+      off = (unsigned)(row * p.k_st * 2) + (c < PP_CPR ? c * 16 : 0);
+      ++n_kins;
+    } else if (n < NINS) {
+      const int g = (n - PP_KINS) * 64 + lane, row = g / PP_CPR, c = g - row * PP_CPR;
+      off = v_minus_k + (unsigned)(row * p.v_st * 2) + c * 16;
+      ++n_vins;
+    }
+    d_off[i] = off;
+  }
+  const unsigned k_step = (unsigned)(KT * p.k_st * 2), v_step = (unsigned)(KT * p.v_st * 2);
+  const unsigned ldsK0 = (unsigned)(uintptr_t)(lds_ptr)smem_raw;
+  const unsigned ldsV0 = ldsK0 + PP_NST * PP_KBYTES;
+  // this wave's share of K tile kt_k and V tile kt_v (each skipped when past the end); returns the instructions issued
+  auto issue = [&](int kt_k, int kt_v) -> int {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int n = wave + 8 * i;   // wave-uniform
+      if (n < PP_KINS) {
+        if (kt_k < nkt) {
+          const unsigned m0v = ldsK0 + (kt_k % PP_NST) * PP_KBYTES + n * 1024;
+          const unsigned off = d_off[i] + kt_k * k_step;
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(kb), "s"(m0v) : "memory");
+        }
+      } else if (n < NINS) {
+        if (kt_v < nkt) {
+          const unsigned m0v = ldsV0 + (kt_v % PP_NST) * PP_VBYTES + (n - PP_KINS) * 1024;
+          const unsigned off = d_off[i] + kt_v * v_step;
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(kb), "s"(m0v) : "memory");
+        }
+      }
+    }
+    return (kt_k < nkt ? n_kins : 0) + (kt_v < nkt ? n_vins : 0);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, nkt);
+  if (grp == 1) issue(3, 2);   // group 1 requests one tile further ahead (see the slot schedule at `tile`)
+
+  // ---- rel_h of the 256 queries -> LDS (log2 domain) ----
+  {
+    const float* rh = p.relh + (bh * p.Nq + q0) * KT;   // [256][64] contiguous
+#pragma unroll
+    for (int i = 0; i < PPQ * KT / 4 / 512; ++i) {
+      const int e = (tid + i * 512) * 4;
+      const float4 f = *reinterpret_cast<const float4*>(rh + e);
+      float* dst = sRh + (e >> 6) * PP_RSTR + (e & 63);
+      dst[0] = f.x * LOG2E; dst[1] = f.y * LOG2E; dst[2] = f.z * LOG2E; dst[3] = f.w * LOG2E;
+    }
+  }
+  // ---- Q fragments (pre-scaled, as attn_fwd_kernel) and rel_w registers ----
+  const float sl2 = p.scale * LOG2E;
+  bf16x8 qf[2][NKD];
+  float relw_r[2][4][4];
+  int qloc[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qloc[qt] = wave * 32 + qt * 16 + fr;
+    const int qi = q0 + qloc[qt];
+#pragma unroll
+    for (int kd = 0; kd < NKD; ++kd) {
+      const int col = kd * 32 + fh * 8;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (col < PP_D) {
+        float qv[8];
+        load8(qb + (long)qi * p.q_st + col, qv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] *= sl2;
+        r.x = pack_bf16x2(qv[0], qv[1]); r.y = pack_bf16x2(qv[2], qv[3]);
+        r.z = pack_bf16x2(qv[4], qv[5]); r.w = pack_bf16x2(qv[6], qv[7]);
+      }
+      qf[qt][kd] = __builtin_bit_cast(bf16x8, r);
+    }
+    const float* rw = p.relw + (bh * p.Nq + qi) * KT;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float4 f = *reinterpret_cast<const float4*>(rw + 16 * t + 4 * fh);
+      relw_r[qt][t][0] = f.x * LOG2E; relw_r[qt][t][1] = f.y * LOG2E;
+      relw_r[qt][t][2] = f.z * LOG2E; relw_r[qt][t][3] = f.w * LOG2E;
+    }
+  }
+  f32x4 oacc[ND][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // row sums: one more MFMA per (k-step, q-tile) against a register fragment of ones — the issue port is what this kernel is
+  // bound by, and 32 f32 adds per tile cost it four times what 4 MFMAs do; every row of lacc[qt] holds the same sums
+  const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float m_run[2] = {0.f, 0.f};
+  bf16x8 pf[2][2];
+
+  auto fence_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // rel_h copy written, the first K / V tiles landed
+  fence_barrier();
+
+  // lane-constant LDS offsets: K fragment rows, V transposed-read rows, the lane's rel_h rows. Stage bases are compile-time
+  // (the tile loop is unrolled over the 4 stages), so every LDS address below is one VGPR + an immediate.
+  const int tr_q = fr >> 2, tr_p = fr & 3;
+  // third k-step of the score MFMA covers columns 64..95: lanes fh >= 2 (columns 80..95, where Q is zero) re-read the real
+  // chunks 8 / 9 — whatever they multiply has to be FINITE, and the bytes behind a row's 10 chunks are not always
+  const unsigned k_lane01 = fr * PP_KSTR + fh * 16;
+  const unsigned k_lane2 = fr * PP_KSTR + (fh < 2 ? 8 + fh : 6 + fh) * 16;
+  const unsigned v_lane = (4 * fh + tr_q) * PP_VSTR + 8 * tr_p;
+  const float* rh_lane0 = sRh + qloc[0] * PP_RSTR;
+  const float* rh_lane1 = sRh + qloc[1] * PP_RSTR;
+
+  // LDS -> fragment loads. Stage bases are compile-time, so each is one ds_read with an immediate offset.
+  auto load_v = [&](auto stage, auto ks_tag, bf16x8 (&vf)[ND]) {   // V^T fragments of k-step ks (keys 32ks .. 32ks+31)
+    constexpr int ST = decltype(stage)::value, ks = decltype(ks_tag)::value;
+    const unsigned char* v0 = smem_raw + PP_NST * PP_KBYTES + ST * PP_VBYTES + v_lane + (32 * ks) * PP_VSTR;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_ptr)(v0 + 32 * dt));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_ptr)(v0 + 32 * dt + 16 * PP_VSTR));
+      vf[dt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto load_k = [&](auto stage, auto kd_tag, bf16x8 (&kf)[4]) {    // K fragments of head-dim step kd, the 4 key tiles
+    constexpr int ST = decltype(stage)::value, kd = decltype(kd_tag)::value;
+    const unsigned char* k0 = smem_raw + ST * PP_KBYTES + (kd < 2 ? k_lane01 + kd * 64 : k_lane2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(k0 + 16 * t * PP_KSTR);
+  };
+  auto mma_pv = [&](auto ks_tag, const bf16x8 (&vf)[ND]) {   // O^T += V^T . P^T for k-step ks
+    constexpr int ks = decltype(ks_tag)::value;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      oacc[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf[0][ks], oacc[dt][0], 0, 0, 0);
+      oacc[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf[1][ks], oacc[dt][1], 0, 0, 0);
+    }
+    lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0][ks], lacc[0], 0, 0, 0);
+    lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1][ks], lacc[1], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  auto phase = [&]() { __builtin_amdgcn_sched_barrier(0); };
+
+  // One KV tile = the MFMA slot (PV of the previous tile, then this tile's scores), then the VALU slot (requests, softmax).
+  // In the MFMA slot only ONE wave per SIMD feeds the matrix pipe (its partner is in the VALU slot), so an LDS read waited
+  // for right before its MFMA is latency nobody covers (first form of this kernel: 1430 cycles to issue 48 MFMAs,
+  // profiles/r3_attn_pp_trace.txt). Every fragment is therefore read at least one phase before the MFMAs that consume it,
+  // and the first 56 registers' worth already in the VALU slot BEFORE, where the wave has issue slots to spare:
+  //   VALU slot kt:   requests | softmax(kt) -> P | reads V[kt] (both k-steps), K[kt+1] kd0 | score init for kt+1
+  //   MFMA slot kt+1: PV ks0 | reads K kd1, PV ks1 | reads K kd2, QK kd0 | QK kd1 | QK kd2
+  // Requests: tile pair X = (K[X+1], V[X]) is first read in group 0's VALU slot X, so it must have landed — every wave's
+  // share — by the barrier in front of that slot. Group 0 requests its share in its VALU slot X-2 and waits for it at the end
+  // of its MFMA slot X (one newer batch may stay in flight); group 1 — whose slots are the odd ones — requests in its VALU
+  // slot X-3 and waits at the end of its VALU slot X-1 (two newer batches in flight). The stages those requests overwrite
+  // (K[X-3], V[X-4]) were last read two or more barriers earlier by both groups.
+  bf16x8 vf0[ND], vf1[ND], kf0[4];
+  f32x4 sacc[4][2];
+  auto batch_cnt = [&](int x) { return (x + 1 < nkt ? n_kins : 0) + (x < nkt ? n_vins : 0); };
+  auto wait_vm = [&](int n) {   // wave-uniform n: at most n of my requests still in flight
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
+  };
+  // score accumulators start at  rel_w + rel_h - m_run  (log2 domain)
+  auto init_scores = [&](float rh0, float rh1) {
+    const float rhv0 = rh0 - m_run[0], rhv1 = rh1 - m_run[1];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sacc[t][0] = f32x4{relw_r[0][t][0] + rhv0, relw_r[0][t][1] + rhv0, relw_r[0][t][2] + rhv0, relw_r[0][t][3] + rhv0};
+      sacc[t][1] = f32x4{relw_r[1][t][0] + rhv1, relw_r[1][t][1] + rhv1, relw_r[1][t][2] + rhv1, relw_r[1][t][3] + rhv1};
+    }
+  };
+  auto tile = [&](int kt, auto stage, auto first_tag) {
+    constexpr int ST = decltype(stage)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    using PrevStage = std::integral_constant<int, (ST + PP_NST - 1) % PP_NST>;
+    PP_STAMP(0);
+    // ================= MFMA slot =================
+    bf16x8 kf1[4], kf2[4];
+    __builtin_amdgcn_s_setprio(1);
+#if !(defined(HAFF_TUNING) && defined(HAFF_PP_NOMFMA))
+    auto qk = [&](auto kd_tag, const bf16x8 (&kf)[4]) {   // S^T += K . Q^T over head-dim step kd
+      constexpr int kd = decltype(kd_tag)::value;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sacc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf[0][kd], sacc[t][0], 0, 0, 0);
+        sacc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf[1][kd], sacc[t][1], 0, 0, 0);
+      }
+    };
+    // (sched_group_barrier: the phase's reads go out BEFORE its MFMAs — left alone, hipcc reuses the registers of the
+    // fragments being consumed for the ones being fetched and so sinks the reads behind the MFMAs. Alternating PV and QK
+    // steps to put 20 MFMAs between every read and its use measured no better: the slot's 48 MFMAs take ~1150 cycles
+    // instead of 768 because the partner wave's VALU / DMA instructions share the SIMD's issue port, not for LDS latency.)
+    if (!FIRST) {
+      load_v(PrevStage{}, I1{}, vf1);
+      load_k(stage, I0{}, kf0);
+      init_scores(rh_lane0[kt], rh_lane1[kt]);   // (adds in the shadow of the reads / the first MFMAs)
+      mma_pv(I0{}, vf0);
+      phase();
+      load_k(stage, I1{}, kf1);
+      mma_pv(I1{}, vf1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      phase();
+      load_k(stage, I2{}, kf2);
+      qk(I0{}, kf0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      phase();
+      qk(I1{}, kf1);
+      phase();
+      qk(I2{}, kf2);
+    } else {
+      load_k(stage, I0{}, kf0);
+      load_k(stage, I1{}, kf1);
+      load_k(stage, I2{}, kf2);
+      init_scores(rh_lane0[kt], rh_lane1[kt]);
+      qk(I0{}, kf0);
+      qk(I1{}, kf1);
+      qk(I2{}, kf2);
+    }
+#endif
+    __builtin_amdgcn_s_setprio(0);
+    PP_STAMP(1);
+    // my LDS reads are done (the stages go back to the DMA). Group 0: batch kt has landed (batch kt+1 may be in flight).
+    if (grp == 0) wait_vm(FIRST ? 0 : batch_cnt(kt + 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_STAMP(2);
+    fence_barrier();
+    PP_STAMP(3);
+    // ================= VALU slot =================
+    // (the two small LDS reads of this slot go first: LDS returns in order, a value read behind the 24 fragment reads
+    // below would be waited for behind all of them)
+#if !(defined(HAFF_TUNING) && defined(HAFF_PP_NODMA))
+    if (grp == 0) issue(kt + 3, kt + 2);
+    else issue(kt + 4, kt + 3);
+#endif
+    PP_STAMP(4);
+    // fragments for the MFMA slot behind the next barrier — V[kt] whole, K[kt+1] kd0 — requested NOW: they land under the
+    // softmax arithmetic below (issued behind it, this wave would sit in the issue stage until most of them had returned:
+    // 14 KB per wave, four waves at once, against the other group's reads)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      // Exponentials -> P^T fragments (k-step ks: slots j < 4 <- key tile 2ks, j >= 4 <- key tile 2ks+1). The exponentials
+      // only need a reference m_run that keeps them in RANGE, not the running maximum: the first tile sets it to that tile's
+      // maximum; later p = 2^(s - m_run) may exceed 1 (bf16 and fp32 carry an 8-bit exponent: exact arithmetic is unchanged up
+      // to rounding). Only when a score lands more than PP_LAZY above the reference is the reference moved: that pass takes
+      // the cross-lane maximum and rescales the accumulators.
+      auto exp_pack = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          float e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float sv = sacc[2 * ks + (j >> 2)][qt][j & 3];
+#if defined(HAFF_TUNING) && defined(HAFF_PP_NOSOFTMAX)
+            e[j] = sv;
+#else
+            e[j] = __builtin_amdgcn_exp2f(sv);
+#endif
+          }
+          uint4 u;
+          u.x = pack_bf16x2(e[0], e[1]); u.y = pack_bf16x2(e[2], e[3]);
+          u.z = pack_bf16x2(e[4], e[5]); u.w = pack_bf16x2(e[6], e[7]);
+          pf[qt][ks] = __builtin_bit_cast(bf16x8, u);
+        }
+      };
+      auto move_reference = [&]() {
+        float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+#pragma unroll
+        for (int t = 1; t < 4; ++t) {
+          mx = fmaxf(fmaxf(mx, sacc[t][qt][0]), sacc[t][qt][1]);
+          mx = fmaxf(fmaxf(mx, sacc[t][qt][2]), sacc[t][qt][3]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+        m_run[qt] += delta;
+        if (!FIRST) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          lacc[qt][0] *= alpha; lacc[qt][1] *= alpha; lacc[qt][2] *= alpha; lacc[qt][3] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) {
+            oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
+            oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[t][qt][r] -= delta;
+      };
+#if defined(HAFF_TUNING) && defined(HAFF_PP_NOSOFTMAX)
+      exp_pack();
+#else
+      if (FIRST) {
+        move_reference();
+        exp_pack();
+      } else {
+        // lane-local maximum of the lane's 16 scores (relative to m_run): 8 instructions, no cross-lane step
+        float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+#pragma unroll
+        for (int t = 1; t < 4; ++t) {
+          mx = fmaxf(fmaxf(mx, sacc[t][qt][0]), sacc[t][qt][1]);
+          mx = fmaxf(fmaxf(mx, sacc[t][qt][2]), sacc[t][qt][3]);
+        }
+        if (__any(mx > PP_LAZY)) move_reference();   // rare (never on SAM's logits)
+        exp_pack();
+      }
+#endif
+    }
+    phase();
+#if !(defined(HAFF_TUNING) && defined(HAFF_PP_NOMFMA))
+    load_v(stage, I0{}, vf0);   // the first fragments the next MFMA slot consumes; nothing behind them in this slot reads LDS
+#endif
+    PP_STAMP(5);
+    // group 1: batch kt+1 has landed (batches kt+2, kt+3 may be in flight) — group 0 reads it right behind this barrier
+    if (grp == 1) wait_vm((kt >= 1 ? batch_cnt(kt + 2) : 0) + batch_cnt(kt + 3));
+    fence_barrier();
+    PP_STAMP(6);
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  if (grp == 1) fence_barrier();   // group 1 runs one slot behind
+  tile(0, S0{}, std::true_type{});
+  tile(1, S1{}, std::false_type{});           // (the host admits nkt >= 2 only)
+  if (2 < nkt) tile(2, S2{}, std::false_type{});
+  if (3 < nkt) tile(3, S3{}, std::false_type{});
+  for (int kt = 4; kt < nkt; kt += 4) {
+    tile(kt, S0{}, std::false_type{});
+    if (kt + 1 < nkt) tile(kt + 1, S1{}, std::false_type{});
+    if (kt + 2 < nkt) tile(kt + 2, S2{}, std::false_type{});
+    if (kt + 3 < nkt) tile(kt + 3, S3{}, std::false_type{});
+  }
+  switch ((nkt - 1) & 3) {   // PV of the last tile (its first V fragments were read in the last VALU slot)
+    case 0: load_v(S0{}, I1{}, vf1); break;
+    case 1: load_v(S1{}, I1{}, vf1); break;
+    case 2: load_v(S2{}, I1{}, vf1); break;
+    default: load_v(S3{}, I1{}, vf1); break;
+  }
+  mma_pv(I0{}, vf0);
+  mma_pv(I1{}, vf1);
+  if (grp == 0) fence_barrier();   // the barrier group 1 took at the top
+
+  // ---- finalize: out[q][16dt + 4fh + r] = O^T / l ----
+  bf16_t* ob = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float inv = 1.0f / lacc[qt][0];
+    const long qi = q0 + qloc[qt];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      float v[4] = {oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv, oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv};
+      store4(ob + qi * p.o_st + 16 * dt + 4 * fh, v);
+    }
+  }
+}
+
+#if defined(HAFF_TUNING) && defined(HAFF_PP_TRACE)
+extern "C" int haff_pp_trace_read(void* dst, int n) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(haff_pp_trace_buf), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// host-side admission for attn_global_pp_kernel: whole tiles, the fused q|k|v row layout (V a fixed, non-negative
+// distance behind K, same strides), 32-bit source offsets
+static bool attn_global_pp_ok(const AttnArgs& p) {
+  if (p.d != PP_D || p.S != KT || (p.Nq % PPQ) || (p.Nk % KT) || p.Nk < 2 * KT || p.nk_rows) return false;
+  if (p.k_sb != p.v_sb || p.k_sh != p.v_sh || p.k_st != p.v_st || p.v < p.k) return false;
+  const long span = (p.v - p.k) * 2 + (long)p.Nk * p.k_st * 2;
+  if (span >= (1L << 31)) return false;
+  return (reinterpret_cast<uintptr_t>(p.k) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.v) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.relh) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.relw) & 15) == 0;
+}
+
+static int launch_attn_global_pp(const AttnArgs& p, hipStream_t s) {
+  // the attribute is per device and this entry point keeps no state: set it on every call (a host-side table write)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_global_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          PP_LDS) != hipSuccess)
+    return HAFF_ERR_LAUNCH;
+  dim3 grid((p.Nq / PPQ) * p.H * p.B), block(512);
+  hipLaunchKernelGGL(attn_global_pp_kernel, grid, block, PP_LDS, s, p);
+  return haff_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // KV-cached decode step (Nq == 1, d == 128, every key visible): HBM-bound, no matrix shape to it — one wave per
 // (batch, head) streams the K and V rows of that head once and does the two GEMVs on the VALU.
 // Lane = (g = lane>>4, c = lane&15): per iteration the wave reads 4 consecutive keys (one per 16-lane row g), lane
@@ -683,6 +1175,10 @@ static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
     }
     if (dp == 64) return mode == 2 ? launch_attn<64, 2, false>(p, s) : launch_attn<64, 1, false>(p, s);
     if (dp == 96 && mode == 2 && d == 80) {   // SAM global blocks
+#ifdef HAFF_TUNING
+      if (getenv("HAFF_ATTN_NO_PP")) return launch_attn<96, 2, false, 6, true, true>(p, s);
+#endif
+      if (attn_global_pp_ok(p)) return launch_attn_global_pp(p, s);
       if ((Nq % 128) == 0 && (Nk % KT) == 0 && !nk_rows) return launch_attn<96, 2, false, 6, true, true>(p, s);
       return launch_attn<96, 2, false, 6, true>(p, s);
     }
