@@ -381,6 +381,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const int nk = (p.K + BK - 1) / BK;
 
   f32x4 acc[TN][TM];  // [ni][mi]
+#if defined(HAFF_TUNING) && defined(HAFF_EXP_MFMA32)
+  f32x16 accw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accw[i][j] = 0.f;
+#endif
   bf16x8 wf[2][TN], af[2][TM];  // fragments of one K-tile: [32-deep k-step][16-row tile] (unused by the PP loop)
   bf16x8 pa[2][4], pwl[2][2], pwh[2][2];   // PP loop: one half of the A fragments, both halves of the W fragments
   auto read_frags = [&](int buf, int ks) {
@@ -491,6 +498,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
           for (int j = 0; j < 2; ++j)
             acc[N0 + j][M0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks][j], pa[ks][t], acc[N0 + j][M0 + t], 0, 0, 0);
     };
+#if defined(HAFF_TUNING) && defined(HAFF_EXP_MFMA32)
+    // timing experiment only (results are wrong): the same fragment reads feeding v_mfma_f32_32x32x16_bf16 — half as many
+    // MFMA instructions of twice the length, i.e. the matrix pipe as busy as before while the SIMD's issue port is held
+    // 8 of 32 cycles instead of 8 of 16
+    auto quad32 = [&](const bf16x8 (&wq)[2][2], auto ni0, auto mi0) {
+      constexpr int N0 = decltype(ni0)::value, M0 = decltype(mi0)::value;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            constexpr int dummy = 0;
+            const int idx = (N0 / 2) * 4 + (M0 / 4) * 2 + j;
+            accw[idx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][j], pa[ks][2 * j + tt], accw[idx], 0, 0, 0);
+          }
+    };
+#define quad quad32
+#endif
     auto slot_barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -598,6 +624,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       }
     }
   }
+#if defined(HAFF_TUNING) && defined(HAFF_EXP_MFMA32)
+#undef quad
+  if constexpr (PP) {   // keep the experiment's accumulators alive: hand them to the epilogue (garbage in, garbage out)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[(i >> 2) * 2 + (j >> 1)][(i & 3) * 2 + (j & 1)] = f32x4{accw[i][4 * j], accw[i][4 * j + 1], accw[i][4 * j + 2], accw[i][4 * j + 3]};
+  }
+#endif
   // the epilogue reuses stage memory: every wave is done reading fragments (PP: the loop's last barrier says so)
   if constexpr (!PP) __builtin_amdgcn_s_barrier();
   HAFF_TRACE(2);
