@@ -45,6 +45,8 @@ struct AttnArgs {
   // rotated here and appended to the caches by this kernel
   const bf16_t *knew, *vnew;
   const float* cos_sin;   // [Tmax][d] = cos(0..d/2) | sin(0..d/2)
+  // attn_global_pp_kernel<true>: the decomposed rel-pos TABLES (bf16 [2S-1][d]); rel_h / rel_w are computed in the prologue
+  const bf16_t *tab_h, *tab_w;
 };
 
 constexpr int QB = 128;   // queries per workgroup
@@ -533,6 +535,14 @@ __device__ unsigned long long haff_pp_trace_buf[256 * 2 * 4 * 8];
 #define PP_STAMP(i) do {} while (0)
 #endif
 
+// FUSED_REL: rel_h / rel_w do not arrive as fp32 [B*H][N][64] tables (1.07 GB written by haff_relpos_tables and read back
+// per 32-frame launch): the prologue computes them for the workgroup's 256 queries from the raw q rows and the two bf16
+// [127][80] parameter tables (add_decomposed_rel_pos, image_encoder.py:354-392: rel_h[q][kh] = q . Rh[qh - kh + 63],
+// rel_w[q][kw] = q . Rw[qw - kw + 63], UNSCALED q) with 54 MFMAs per wave — table rows on the MFMA's row side, the lane's
+// query on the column side, like the score MFMA. A wave's 32 queries share qh, so rel_h lands in its LDS rows by a plain
+// index flip; rel_w's row index depends on the query's own qw, so the products pass through a wave-private LDS scratch
+// (in the K/V stage area, before the first K/V request) indexed [query][kw] and come back as the 16 values a lane keeps.
+template <bool FUSED_REL>
 __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
   constexpr int NKD = 3, ND = 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -548,8 +558,15 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
   const int nbh = p.B * p.H;
   int bh_id, qblk;
   {
-    const int id = blockIdx.x;   // same XCD-aware decode as attn_fwd_kernel
-    if ((nbh & 7) == 0) {
+    const int id = blockIdx.x;   // XCD-aware decode: ids equal mod 8 share an L2; all query blocks of a (batch, head) on one XCD
+    if ((nbh & 15) == 0 && (p.H & 1) == 0) {
+      // ... and the two heads an XCD runs side by side (32 CUs = 2 x 16 query blocks) are NEIGHBOURS in the fused q|k|v row:
+      // a head's 160-B K (V) slice of a token row straddles 128-B lines it shares with the next head, which another XCD
+      // would fetch again (PMC: 1.62 GB fetched per 32-frame launch with heads x, x+8 paired, against 0.60 GB of q, k, v)
+      const int x = id & 7, seq = id / (8 * nqb);
+      bh_id = 16 * (seq >> 1) + 2 * x + (seq & 1);
+      qblk = (id >> 3) % nqb;
+    } else if ((nbh & 7) == 0) {
       bh_id = (id & 7) + 8 * (id / (8 * nqb));
       qblk = (id >> 3) % nqb;
     } else {
@@ -564,6 +581,11 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
   const long bh = (long)b * p.H + h;
   const int nkt = p.Nk / KT;
 
+  auto fence_barrier_early = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
   // ---- DMA plan: combined instruction index n = wave + 8 i (n < 11: K, else V), lane -> slot -> source byte offset ----
   constexpr int NINS = PP_KINS + PP_VINS;   // 21
   unsigned d_off[3];
@@ -608,23 +630,7 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
     }
     return (kt_k < nkt ? n_kins : 0) + (kt_v < nkt ? n_vins : 0);
   };
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, nkt);
-  if (grp == 1) issue(3, 2);   // group 1 requests one tile further ahead (see the slot schedule at `tile`)
-
-  // ---- rel_h of the 256 queries -> LDS (log2 domain) ----
-  {
-    const float* rh = p.relh + (bh * p.Nq + q0) * KT;   // [256][64] contiguous
-#pragma unroll
-    for (int i = 0; i < PPQ * KT / 4 / 512; ++i) {
-      const int e = (tid + i * 512) * 4;
-      const float4 f = *reinterpret_cast<const float4*>(rh + e);
-      float* dst = sRh + (e >> 6) * PP_RSTR + (e & 63);
-      dst[0] = f.x * LOG2E; dst[1] = f.y * LOG2E; dst[2] = f.z * LOG2E; dst[3] = f.w * LOG2E;
-    }
-  }
-  // ---- Q fragments (pre-scaled, as attn_fwd_kernel) and rel_w registers ----
+  // ---- Q fragments (pre-scaled, as attn_fwd_kernel) ----
   const float sl2 = p.scale * LOG2E;
   bf16x8 qf[2][NKD];
   float relw_r[2][4][4];
@@ -647,14 +653,105 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
       }
       qf[qt][kd] = __builtin_bit_cast(bf16x8, r);
     }
-    const float* rw = p.relw + (bh * p.Nq + qi) * KT;
+  }
+  if constexpr (FUSED_REL) {
+    constexpr int SCR = KT + 4;                       // scratch row stride in floats (16-B aligned rows)
+    static_assert(8 * 32 * SCR * 4 <= PP_NST * (PP_KBYTES + PP_VBYTES), "rel_w scratch fits the stage area");
+    float* scr = reinterpret_cast<float*>(smem_raw) + wave * 32 * SCR;
+    const int tok0 = q0 + wave * 32;                  // the wave's first query: 32 consecutive tokens of ONE grid row
+    const int qh = tok0 / KT, qwb = tok0 - qh * KT;   // qwb = 0 or 32
+    const int nrow = 2 * KT - 2;                      // last table row
+    bf16x8 qr[2][NKD];                                // raw q fragments (the reference multiplies the UNSCALED q)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float4 f = *reinterpret_cast<const float4*>(rw + 16 * t + 4 * fh);
-      relw_r[qt][t][0] = f.x * LOG2E; relw_r[qt][t][1] = f.y * LOG2E;
-      relw_r[qt][t][2] = f.z * LOG2E; relw_r[qt][t][3] = f.w * LOG2E;
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kd = 0; kd < NKD; ++kd) {
+        const int col = kd * 32 + fh * 8;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (col < PP_D) r = *reinterpret_cast<const uint4*>(qb + (long)(q0 + qloc[qt]) * p.q_st + col);
+        qr[qt][kd] = __builtin_bit_cast(bf16x8, r);
+      }
+    auto table_frag = [&](const bf16_t* tab, int row, int kd) {   // A operand: lane = (table row, d-chunk fh)
+      const int col = kd * 32 + fh * 8;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (col < PP_D) r = *reinterpret_cast<const uint4*>(tab + (long)min(row, nrow) * PP_D + col);
+      return __builtin_bit_cast(bf16x8, r);
+    };
+    // rel_h: table rows qh .. qh + 63 (4 tiles); lane (query fr, fh) register r of tile j holds row qh + 16j + 4fh + r,
+    // i.e. kh = 63 - 16j - 4fh - r
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kd = 0; kd < NKD; ++kd) {
+        const bf16x8 tf = table_frag(p.tab_h, qh + 16 * j + fr, kd);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qr[0][kd], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qr[1][kd], a1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kh = KT - 1 - 16 * j - 4 * fh - r;
+        sRh[qloc[0] * PP_RSTR + kh] = a0[r] * LOG2E;
+        sRh[qloc[1] * PP_RSTR + kh] = a1[r] * LOG2E;
+      }
+    }
+    // rel_w: q-tile qt holds qw = qwb + 16 qt + fr; table rows qwb + 16 qt + 16 j + (0..15), j = 0..4; register r of tile j
+    // is row qwb + 16 qt + 16 j + 4 fh + r, i.e. kw = 63 + fr - 16 j - 4 fh - r (kept when inside 0..63)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(table_frag(p.tab_w, qwb + 16 * qt + 16 * j + fr, kd), qr[qt][kd], a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kw = KT - 1 + fr - 16 * j - 4 * fh - r;
+          if (kw >= 0 && kw < KT) scr[(qt * 16 + fr) * SCR + kw] = a[r] * LOG2E;
+        }
+      }
+    }
+    // wave-private scratch: my lanes' writes are in LDS before my lanes' reads (explicit: LDS operations of one wave
+    // execute in order, but the compiler may not move the reads up, and round 1's fused kernel taught not to lean on
+    // un-waited same-wave traffic)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 f = *reinterpret_cast<const float4*>(scr + (qt * 16 + fr) * SCR + 16 * t + 4 * fh);
+        relw_r[qt][t][0] = f.x; relw_r[qt][t][1] = f.y; relw_r[qt][t][2] = f.z; relw_r[qt][t][3] = f.w;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fence_barrier_early();   // every wave is done with the scratch: the K/V requests below overwrite it
+  } else {
+    // ---- rel_h of the 256 queries -> LDS, rel_w -> registers (log2 domain), from the fp32 tables ----
+    const float* rh = p.relh + (bh * p.Nq + q0) * KT;   // [256][64] contiguous
+#pragma unroll
+    for (int i = 0; i < PPQ * KT / 4 / 512; ++i) {
+      const int e = (tid + i * 512) * 4;
+      const float4 f = *reinterpret_cast<const float4*>(rh + e);
+      float* dst = sRh + (e >> 6) * PP_RSTR + (e & 63);
+      dst[0] = f.x * LOG2E; dst[1] = f.y * LOG2E; dst[2] = f.z * LOG2E; dst[3] = f.w * LOG2E;
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const float* rw = p.relw + (bh * p.Nq + q0 + qloc[qt]) * KT;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 f = *reinterpret_cast<const float4*>(rw + 16 * t + 4 * fh);
+        relw_r[qt][t][0] = f.x * LOG2E; relw_r[qt][t][1] = f.y * LOG2E;
+        relw_r[qt][t][2] = f.z * LOG2E; relw_r[qt][t][3] = f.w * LOG2E;
+      }
     }
   }
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, nkt);
+  if (grp == 1) issue(3, 2);   // group 1 requests one tile further ahead (see the slot schedule at `tile`)
+
   f32x4 oacc[ND][2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -951,23 +1048,29 @@ extern "C" int haff_pp_trace_read(void* dst, int n) {
 #endif
 
 // host-side admission for attn_global_pp_kernel: whole tiles, the fused q|k|v row layout (V a fixed, non-negative
-// distance behind K, same strides), 32-bit source offsets
-static bool attn_global_pp_ok(const AttnArgs& p) {
+// distance behind K, same strides), 32-bit source offsets; fused_rel: rel-pos from the parameter tables in the prologue
+// (a wave's 32 queries must be consecutive tokens of one grid row: Nq == Nk == S*S)
+static bool attn_global_pp_ok(const AttnArgs& p, bool fused_rel) {
   if (p.d != PP_D || p.S != KT || (p.Nq % PPQ) || (p.Nk % KT) || p.Nk < 2 * KT || p.nk_rows) return false;
   if (p.k_sb != p.v_sb || p.k_sh != p.v_sh || p.k_st != p.v_st || p.v < p.k) return false;
   const long span = (p.v - p.k) * 2 + (long)p.Nk * p.k_st * 2;
   if (span >= (1L << 31)) return false;
-  return (reinterpret_cast<uintptr_t>(p.k) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.v) & 15) == 0 &&
-         (reinterpret_cast<uintptr_t>(p.relh) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.relw) & 15) == 0;
+  if ((reinterpret_cast<uintptr_t>(p.k) & 15) || (reinterpret_cast<uintptr_t>(p.v) & 15) || (reinterpret_cast<uintptr_t>(p.q) & 15))
+    return false;
+  if (fused_rel)
+    return p.Nq == KT * KT && p.Nk == KT * KT && p.tab_h && p.tab_w && (reinterpret_cast<uintptr_t>(p.tab_h) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(p.tab_w) & 15) == 0;
+  return (reinterpret_cast<uintptr_t>(p.relh) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.relw) & 15) == 0;
 }
 
+template <bool FUSED_REL>
 static int launch_attn_global_pp(const AttnArgs& p, hipStream_t s) {
   // the attribute is per device and this entry point keeps no state: set it on every call (a host-side table write)
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_global_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          PP_LDS) != hipSuccess)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_global_pp_kernel<FUSED_REL>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess)
     return HAFF_ERR_LAUNCH;
   dim3 grid((p.Nq / PPQ) * p.H * p.B), block(512);
-  hipLaunchKernelGGL(attn_global_pp_kernel, grid, block, PP_LDS, s, p);
+  hipLaunchKernelGGL(attn_global_pp_kernel<FUSED_REL>, grid, block, PP_LDS, s, p);
   return haff_check_launch();
 }
 
@@ -1178,7 +1281,7 @@ static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
 #ifdef HAFF_TUNING
       if (getenv("HAFF_ATTN_NO_PP")) return launch_attn<96, 2, false, 6, true, true>(p, s);
 #endif
-      if (attn_global_pp_ok(p)) return launch_attn_global_pp(p, s);
+      if (attn_global_pp_ok(p, false)) return launch_attn_global_pp<false>(p, s);
       if ((Nq % 128) == 0 && (Nk % KT) == 0 && !nk_rows) return launch_attn<96, 2, false, 6, true, true>(p, s);
       return launch_attn<96, 2, false, 6, true>(p, s);
     }
@@ -1204,6 +1307,29 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
                                    const float* relh, const float* relw, int S, void* stream) {
   return attention_bf16_impl(q, q_sb, q_sh, q_st, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, o_st, B, H, Nq, Nk, d,
                              scale, causal, q_pos0, relh, relw, S, nullptr, stream);
+}
+
+// SAM GLOBAL attention with the decomposed rel-pos bias computed inside the kernel (Attention.forward,
+// image_encoder.py:235-260, + add_decomposed_rel_pos :354-392 at q_size == k_size == S x S): replaces haff_relpos_tables_bf16 +
+// haff_attention_bf16 — no fp32 [B*H][N][S] tables are written or read. q/k/v/o: bf16 [B][H][S*S][d] views by strides, k and v in
+// one fused row layout (same strides, v behind k); tab_*: bf16 [2S-1][d]. Supported geometry: S == 64, d == 80 (ViT-H global
+// blocks); otherwise HAFF_ERR_UNSUPPORTED and the caller takes the two-kernel path.
+extern "C" int haff_global_attention_bf16(const void* q, long q_sb, long q_sh, long q_st,
+                                          const void* k, long k_sb, long k_sh, long k_st,
+                                          const void* v, long v_sb, long v_sh, long v_st,
+                                          void* o, long o_sb, long o_sh, long o_st,
+                                          int B, int H, int S, int d, float scale,
+                                          const void* tab_h, const void* tab_w, void* stream) {
+  if (B <= 0 || H <= 0 || S <= 0 || d <= 0 || !tab_h || !tab_w) return HAFF_ERR_BAD_ARG;
+  if ((q_st & 7) || (k_st & 7) || (v_st & 7) || (o_st & 3) || (q_sh & 7) || (k_sh & 7) || (v_sh & 7) || (o_sh & 3) ||
+      (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (o_sb & 3))
+    return HAFF_ERR_BAD_ARG;
+  AttnArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
+             reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
+             B, H, S * S, S * S, d, scale, 0, nullptr, nullptr, S, nullptr, nullptr, nullptr, nullptr,
+             reinterpret_cast<const bf16_t*>(tab_h), reinterpret_cast<const bf16_t*>(tab_w)};
+  if (!attn_global_pp_ok(p, true)) return HAFF_ERR_UNSUPPORTED;
+  return launch_attn_global_pp<true>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // KV-cached decode over RAGGED caches (batched prompts of different lengths): one query per (batch, head), batch b

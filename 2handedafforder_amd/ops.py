@@ -250,6 +250,33 @@ def window_attention(q, k, v, scale, tab_h, tab_w, S, out=None, grid=0, pad_toke
     return out
 
 
+def global_attention_supported(q, k, v, S):
+    """Geometry served by the fused global kernel (haff_global_attention_bf16): ViT-H global blocks, k|v in one row layout."""
+    return (q.dtype == torch.bfloat16 and S == 64 and q.shape[3] == 80 and q.shape[2] == S * S and k.shape[2] == S * S
+            and k.stride() == v.stride() and v.data_ptr() >= k.data_ptr()
+            and (v.data_ptr() - k.data_ptr()) + k.shape[2] * k.stride(2) * 2 < (1 << 31))
+
+
+def global_attention(q, k, v, scale, tab_h, tab_w, S, out=None):
+    """Fused SAM global attention + decomposed rel-pos (no rel-pos tables in HBM). q/k/v [B,H,S*S,d] strided views, tab_* fp32
+    [2S-1,d] (rounded to bf16 once and cached, as the reference's bf16 checkpoint stores them). Returns [B,S*S,H*d]."""
+    lib = load_library()
+    _req(q, "q")
+    B, H, N, d = q.shape
+    assert global_attention_supported(q, k, v, S) and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    th, tw = _bf16_table(tab_h), _bf16_table(tab_w)
+    if out is None:
+        out = torch.empty((B, N, H * d), dtype=q.dtype, device=q.device)
+    o4 = out.view(B, N, H, d).permute(0, 2, 1, 3)
+    rc = lib.haff_global_attention_bf16(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+                                        k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+                                        v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+                                        out.data_ptr(), o4.stride(0), o4.stride(1), o4.stride(2),
+                                        B, H, S, d, float(scale), th.data_ptr(), tw.data_ptr(), _stream())
+    check(rc, "haff_global_attention_bf16")
+    return out
+
+
 def layernorm(x, w, b, eps, in_map=None, out=None):
     """x [R,C]; optional gather map (int32 [R_out], <0 -> zero row)."""
     lib = load_library()

@@ -66,6 +66,7 @@ class SamEncoderHip:
         # the LayerNorm kernels (already at the HBM roofline) stay the default.
         self.fold_norms = False
         self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
+        self.fused_global = True      # global blocks: rel-pos inside the attention kernel (bf16, ViT-H geometry); False = tables
         # fp32 image embeddings out of the neck (bf16 mode): the last 3x3-conv GEMM writes its fp32 accumulators and the
         # final LayerNorm2d runs in fp32, so the decoder tail (LisaMI355.fp32_tail) starts from un-rounded embeddings.
         # One bf16 rounding of the embedding ALONE costs 0.0005-0.0014 of mask IoU on random weights (tools/parity_sim.py).
@@ -168,6 +169,8 @@ class SamEncoderHip:
                 v = q5[:, :, 2].permute(0, 2, 1, 3)
                 if not blk["global"] and ops.window_attention_supported(q, S):
                     a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
+                elif blk["global"] and self.fused_global and ops.global_attention_supported(q, k, v, S):
+                    a = ops.global_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
                 else:
                     relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
                     a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)

@@ -476,6 +476,8 @@ def main(argv=None):
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--fold-norms", action="store_true", help="SAM blocks: LayerNorm carried into the qkv / lin1 products (A/B)")
+    ap.add_argument("--tables-global", action="store_true",
+                    help="SAM global blocks: rel-pos as fp32 tables + the plain attention kernel instead of the fused kernel (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: skip the one real end-to-end CPU frame (~31 GB host RAM, ~1 min)")
     ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
@@ -506,6 +508,8 @@ def main(argv=None):
     if args.fold_norms:
         model.sam_encoder.fold_norms = True
     model.overlap_streams = not args.single_stream
+    if args.tables_global:
+        model.sam_encoder.fused_global = False
     del sd
     torch.cuda.empty_cache()
     B, S = args.batch, cfg.sam.img_size

@@ -127,6 +127,17 @@ int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, long q_st, c
                                const void* tab_h, const void* tab_w, int grid_h, int grid_w, long pad_token,
                                void* stream);
 
+/* fused SAM GLOBAL attention (the 4 global ViT-H blocks, 64 x 64 tokens): Attention.forward (image_encoder.py:235-260) +
+ * add_decomposed_rel_pos (:354-392), the rel-pos terms computed in the kernel's prologue from the parameter tables (replaces
+ * haff_relpos_tables_bf16 + haff_attention_bf16: no fp32 [B*H][N][S] tables cross HBM). q/k/v/o: bf16 [B][H][S*S][d] views by
+ * (batch, head, token) strides; k and v must share one row layout (same strides, v at a non-negative offset behind k — the
+ * fused qkv projection output); tab_*: bf16 [2S-1][d]. Supported geometry: S == 64, d == 80; otherwise
+ * HAFF_ERR_UNSUPPORTED (-2) and the caller takes the two-kernel path. */
+int haff_global_attention_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* k, long k_sb, long k_sh,
+                               long k_st, const void* v, long v_sb, long v_sh, long v_st, void* o, long o_sb,
+                               long o_sh, long o_st, int B, int H, int S, int d, float scale,
+                               const void* tab_h, const void* tab_w, void* stream);
+
 /* ---- row norms ----------------------------------------------------------------------------------------------
  * haff_layernorm: nn.LayerNorm / LayerNorm2d on channels-last rows (common.py:31-43; image_encoder.py:179,191;
  * transformer.py:134-144; CLIP layer norms). in_map (int32[rows], may be null): out row i normalises in row

@@ -504,6 +504,38 @@ def test_global_attention_pingpong_kernel(dev, B, H, Nq, Nk):
     assert torch.equal(got, ops.attention(q, k, v, d ** -0.5, relh=relh, relw=relw, S=S))
 
 
+@pytest.mark.parametrize("B,H", [(1, 16), (2, 3)])
+def test_global_attention_fused_relpos(dev, B, H):
+    """haff_global_attention_bf16 (rel_h / rel_w computed in the kernel's prologue from the bf16 parameter tables) against
+    (a) fp64 attention with the decomposed bias of image_encoder.py:354-392 on the same bf16 inputs, and (b) the two-kernel path
+    (haff_relpos_tables_bf16 + haff_attention_bf16): same bf16 products, fp32 sums in another order -> equal to fp32 rounding of
+    the bias, i.e. well inside one bf16 ulp of the output. Table values large enough that a wrong row / flipped index shows."""
+    ops = _ops()
+    S, d = 64, 80
+    N = S * S
+    qkv = _rand((B, N, 3, H, d), dev, torch.bfloat16, 80)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    th = _rand((2 * S - 1, d), dev, torch.float32, 81, 0.25)
+    tw = _rand((2 * S - 1, d), dev, torch.float32, 82, 0.25)
+    assert ops.global_attention_supported(q, k, v, S)
+    got = ops.global_attention(q, k, v, d ** -0.5, th, tw, S)
+    # (b) two-kernel path
+    rh, rw = ops.relpos_tables(q, th, tw, S)
+    two = ops.attention(q, k, v, d ** -0.5, relh=rh, relw=rw, S=S)
+    # (a) fp64 with the tables as the kernels see them (bf16-rounded), bias from the definition
+    thb, twb = th.to(torch.bfloat16).double(), tw.to(torch.bfloat16).double()
+    idx = torch.arange(S, device=dev)[:, None] - torch.arange(S, device=dev)[None, :] + (S - 1)     # [q coord][k coord]
+    q6 = q.double().reshape(B, H, S, S, d)
+    relh = torch.einsum("bhyxc,ykc->bhyxk", q6, thb[idx]).reshape(B * H, N, S)
+    relw = torch.einsum("bhyxc,xkc->bhyxk", q6, twb[idx]).reshape(B * H, N, S)
+    ref = _attn_ref(q, k, v, d ** -0.5, False, 0, relh, relw, S)
+    assert torch.isfinite(got.float()).all()
+    _close(got, ref, 2e-2, f"fused global attention B={B} H={H} vs fp64")
+    _close(rh.double(), relh, 1e-4, "rel_h tables vs definition")
+    assert (got.float() - two.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item(), "fused vs two-kernel path"
+    assert torch.equal(got, ops.global_attention(q, k, v, d ** -0.5, th, tw, S)), "repeat launch differs"
+
+
 @pytest.mark.parametrize("S,d", [(14, 80), (7, 32), (64, 80), (20, 80)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_relpos_tables(dev, dtype, S, d):
@@ -864,7 +896,12 @@ def test_kernels_stable_beside_second_stream(dev):
         k = kc.permute(0, 2, 1, 3)
         return ops.attention(q, k, k, 128 ** -0.5)
 
-    cases = {"window attention": win, "global attention + rel-pos tables": glob, "causal prefill attention": prefill,
+    def glob_fused():
+        v = qkv_g.view(2, 4096, 3, 16, 80).permute(2, 0, 3, 1, 4)
+        return ops.global_attention(v[0], v[1], v[2], 80 ** -0.5, t64[0], t64[1], 64)
+
+    cases = {"window attention": win, "global attention + rel-pos tables": glob, "fused global attention": glob_fused,
+             "causal prefill attention": prefill,
              "decode attention": decode, "weight-streaming GEMM M=64": lambda: ops.linear(xs, ws),
              "weight-streaming GEMM M=8": lambda: ops.linear(xs[:8], ws, resid=xs[:8]),
              "256x256 GEMM + GELU": lambda: ops.linear(xb, wb, bias=bias, act=1),

@@ -60,6 +60,9 @@ def main():
         t = timeit(lambda: ops.attention(q, k, v, d ** -0.5, causal=causal, q_pos0=Nk - Nq, relh=relh, relw=relw, S=S))
         fl = 4.0 * B * H * Nq * Nk * d * (0.5 if causal else 1.0)
         line += f" attn {t:8.1f} us  {fl / t / 1e6:7.1f} TF/s"
+        if S == 64 and ops.global_attention_supported(q, k, v, S):
+            tf = timeit(lambda: ops.global_attention(q, k, v, d ** -0.5, th, tw, S))
+            line += f" | fused rel-pos + attn {tf:8.1f} us  {fl / tf / 1e6:7.1f} TF/s"
         print(line, flush=True)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The SAM global-attention launch of the bench (32 frames x 16 heads, 4096 x 4096, d = 80, decomposed rel-pos) a few times —
-the target of rocprofv3 --pmc passes.  usage: attn_one.py [frames] [iters]"""
+the target of rocprofv3 --pmc passes.  usage: [FUSED=1] attn_one.py [frames] [iters]"""
 import os
 import sys
 
@@ -18,7 +18,11 @@ qkv = (torch.randn((B, N, 3, H, d), device=dev) * 0.5).to(torch.bfloat16)
 q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
 relh = torch.randn((B * H, N, S), device=dev) * 0.1
 relw = torch.randn((B * H, N, S), device=dev) * 0.1
+th, tw = torch.randn((2 * S - 1, d), device=dev) * 0.1, torch.randn((2 * S - 1, d), device=dev) * 0.1
 for _ in range(iters):
-    ops.attention(q, k, v, d ** -0.5, relh=relh, relw=relw, S=S)
+    if os.environ.get("FUSED"):     # haff_global_attention_bf16: rel-pos from the parameter tables inside the kernel
+        ops.global_attention(q, k, v, d ** -0.5, th, tw, S)
+    else:
+        ops.attention(q, k, v, d ** -0.5, relh=relh, relw=relw, S=S)
 torch.cuda.synchronize()
 print("done")
