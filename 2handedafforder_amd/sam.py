@@ -35,6 +35,15 @@ class SamEncoderHip:
         self.b_patch = _f32(sd[E + ".patch_embed.proj.bias"], dev)
         self.pos = sd[E + ".pos_embed"].reshape(g * g, C).to(dev, dtype).contiguous()
         self.blocks = []
+        # norm1 -> qkv and norm2 -> lin1 folded into the products (gamma into the weights, beta into the bias, per-row
+        # {mean, rstd} from haff_row_stats applied in the GEMM epilogue: haff_gemm_bf16_ln). Default ON for the bf16 ViT-H
+        # geometry since round 3 (the LayerNorm kernel's write + re-read of the normalised rows disappears: +0.5 % of the
+        # step on the ring-loop GEMM, profiles/r3_fold_norms_ab.txt; it measured neutral on round 2's epilogue);
+        # cfg.fold_norms = True / False forces it
+        fold = getattr(cfg, "fold_norms", None)
+        if fold is None:
+            fold = dtype == torch.bfloat16 and s.embed_dim == 1280 and s.window == 14
+        fold = bool(fold) and dtype == torch.bfloat16
         for i in range(s.depth):
             B = f"{E}.blocks.{i}"
             is_global = i in s.global_idx
@@ -50,7 +59,7 @@ class SamEncoderHip:
                 "w1": sd[B + ".mlp.lin1.weight"].to(dev, dtype).contiguous(), "b1": _f32(sd[B + ".mlp.lin1.bias"], dev),
                 "w2": sd[B + ".mlp.lin2.weight"].to(dev, dtype).contiguous(), "b2": _f32(sd[B + ".mlp.lin2.bias"], dev),
             }
-            if dtype == torch.bfloat16 and getattr(cfg, "fold_norms", False):
+            if fold:
                 blk["wqkv_f"], blk["sqkv"], blk["bqkv_f"] = ops.fold_norm(blk["wqkv"], blk["n1w"], blk["n1b"], blk["bqkv"])
                 blk["w1_f"], blk["s1"], blk["b1_f"] = ops.fold_norm(blk["w1"], blk["n2w"], blk["n2b"], blk["b1"])
             self.blocks.append(blk)
@@ -60,11 +69,7 @@ class SamEncoderHip:
         self.w_neck2 = sd[E + ".neck.2.weight"].permute(0, 2, 3, 1).reshape(s.out_chans, -1).to(dev, dtype).contiguous()
         self.neck3 = (_f32(sd[E + ".neck.3.weight"], dev), _f32(sd[E + ".neck.3.bias"], dev))
         self._maps = {}
-        # Optional: norm1 -> qkv and norm2 -> lin1 folded into the products (gamma into the weights, beta into the bias,
-        # per-row {mean, rstd} from haff_row_stats applied in the GEMM epilogue, haff_gemm_bf16_ln). Measured neutral
-        # (95.0 vs 95.2-96.5 frames/s): the statistics pass still reads x once and the epilogue pays for the fold, so
-        # the LayerNorm kernels (already at the HBM roofline) stay the default.
-        self.fold_norms = False
+        self.fold_norms = fold        # (see above; False = the LayerNorm kernels, needs no other change)
         self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
         self.fused_global = True      # global blocks: rel-pos inside the attention kernel (bf16, ViT-H geometry); False = tables
         # fp32 image embeddings out of the neck (bf16 mode): the last 3x3-conv GEMM writes its fp32 accumulators and the

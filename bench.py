@@ -475,7 +475,8 @@ def main(argv=None):
     ap.add_argument("--sam-chunk", type=int, default=32)
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
-    ap.add_argument("--fold-norms", action="store_true", help="SAM blocks: LayerNorm carried into the qkv / lin1 products (A/B)")
+    ap.add_argument("--fold-norms", action="store_true", help="(default since round 3 for the ViT-H geometry; kept for old command lines)")
+    ap.add_argument("--no-fold-norms", action="store_true", help="SAM blocks: LayerNorm kernels instead of the norm carried into the qkv / lin1 products (A/B)")
     ap.add_argument("--tables-global", action="store_true",
                     help="SAM global blocks: rel-pos as fp32 tables + the plain attention kernel instead of the fused kernel (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -510,6 +511,8 @@ def main(argv=None):
     model.overlap_streams = not args.single_stream
     if args.tables_global:
         model.sam_encoder.fused_global = False
+    if args.no_fold_norms:
+        model.sam_encoder.fold_norms = False
     del sd
     torch.cuda.empty_cache()
     B, S = args.batch, cfg.sam.img_size

@@ -51,9 +51,17 @@ def test_full_size_7b_properties(dev):
         return all(torch.equal(x, y) for x, y in zip(a[1] + a[2] + a[3], b[1] + b[2] + b[3])) and torch.equal(a[0], b[0])
     for _ in range(3):
         assert same(run(), base), "not deterministic"
-    model.sam_encoder.compact_windows = False
-    assert same(run(), base), "skipping the padded window rows changed the result"
-    model.sam_encoder.compact_windows = True
+    # compact (real tokens only) vs padded windows: bit-identical on the LayerNorm-kernel path both share (the padded path,
+    # kept for other geometries, has no norm-folded form; the ViT-H default folds norm1 / norm2 into the products)
+    enc = model.sam_encoder
+    folded, enc.fold_norms = enc.fold_norms, False
+    unfolded = run()
+    enc.compact_windows = False
+    assert same(run(), unfolded), "skipping the padded window rows changed the result"
+    enc.compact_windows, enc.fold_norms = True, folded
+    if folded:   # the folded path against the LayerNorm kernels: same algorithm, other rounding points
+        for a, b in zip(base[1] + base[2], unfolded[1] + unfolded[2]):
+            assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item() and _iou(a > 0, b > 0) >= 0.97
     model.decode_graphs = False
     assert same(run(), base), "hipGraph decode differs from eager decode"
     model.decode_graphs = True

@@ -219,6 +219,7 @@ def test_sam_vith_width_windowed_blocks(dev):
     images = torch.from_numpy(rng.standard_normal((2, 3, 1024, 1024), dtype=np.float32)).to(torch.bfloat16).float()
     cfg.sam.fold_norms = True        # also build the norm-folded weights (haff_gemm_bf16_ln path, checked below)
     enc = SamEncoderHip(sd, cfg.sam, torch.bfloat16, dev)
+    enc.fold_norms = False           # first the LayerNorm kernels; the folded path (the ViT-H default) is compared below
     with torch.no_grad():
         taps_c, taps_p, taps_ref = {}, {}, {}
         enc.compact_windows = True
