@@ -90,6 +90,12 @@ struct GemmArgs {
   const float* ssq_in;
   int ssq_n;
   float ssq_eps;
+  // LayerNorm statistics of the OUTPUT rows, emitted by the producer (8-wave tile, register epilogue with a bf16 residual,
+  // whole interior tiles only — haff_gemm_bf16_rowstats): wave (n-tile, wn) writes {sum, sum of squares} of its 64 output
+  // columns of row m to stat_out[m][stat_slots][2], slot = first column / 64; haff_row_stats_finalize adds the slots in
+  // order. The consumer product then needs no pass over the rows it normalises.
+  float* stat_out;
+  int stat_slots;
 };
 
 // Epilogue activations of the throughput (bf16) path. GELU matters for the K=1280 SAM MLP GEMM, whose epilogue touches
@@ -804,6 +810,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
           }
       }
       const int orow = out_row(mi);
+      float st1 = 0.f, st2 = 0.f;   // row statistics of the final values (RES && ALL && p.stat_out)
       if constexpr (OUT_F32) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -847,6 +854,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
               v8[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
             }
             q = haff_u32x4{pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]), pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7])};
+            if constexpr (ALL) {
+              if (p.stat_out) {   // (wave-uniform) the lane's 8 columns of this row; the row's other columns sit in 3 more lanes
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  st1 += v8[e];
+                  st2 = __builtin_fmaf(v8[e], v8[e], st2);
+                }
+              }
+            }
           } else {
             unsigned x0 = pack_bf16x2(val[2 * j][0], val[2 * j][1]), y0 = pack_bf16x2(val[2 * j + 1][0], val[2 * j + 1][1]);
             unsigned x1 = pack_bf16x2(val[2 * j][2], val[2 * j][3]), y1 = pack_bf16x2(val[2 * j + 1][2], val[2 * j + 1][3]);
@@ -865,6 +881,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
             *reinterpret_cast<haff_u32x4*>(dst) = q;
           }
 #endif
+        }
+      }
+      if constexpr (RES && ALL) {
+        if (p.stat_out) {   // the four lanes of a row (same fr, fh = 0..3) -> one {sum, sum of squares} per (row, wave)
+          st1 += __shfl_xor(st1, 16, 64);
+          st2 += __shfl_xor(st2, 16, 64);
+          st1 += __shfl_xor(st1, 32, 64);
+          st2 += __shfl_xor(st2, 32, 64);
+          if (fh == 0)
+            *reinterpret_cast<float2*>(p.stat_out + ((long)orow * p.stat_slots + (n_wave_out >> 6)) * 2) = float2{st1, st2};
         }
       }
       HAFF_TRACE2(2 + mi);
@@ -1581,6 +1607,33 @@ extern "C" int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, 
   if (!a_map || a_rows <= 0) return HAFF_ERR_BAD_ARG;
   return gemm_bf16_impl(A, lda, a_map, a_rows, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu,
                         0, stream);
+}
+
+// Residual product whose epilogue also emits the LayerNorm statistics of its OUTPUT rows (see GemmArgs::stat_out): proj and
+// lin2 of a SAM block (image_encoder.py:186-193: x = shortcut + proj(attn); x = x + mlp(norm2(x))) hand the row sums of the new
+// residual stream to haff_row_stats_finalize -> ln_stats of the next haff_gemm_bf16_ln, so neither a LayerNorm kernel nor a
+// statistics pass reads the stream again. C = A.W^T + bias + resid in bf16 (C may alias resid); a_map optional (gather on
+// the A side, as haff_gemm_bf16_gather). stat_out: f32 [M][N/64][2]. Needs whole 8-wave tiles: M % 256 == 0, N % 256 == 0,
+// K % 64 == 0; otherwise HAFF_ERR_UNSUPPORTED (the caller keeps haff_row_stats).
+extern "C" int haff_gemm_bf16_rowstats(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw,
+                                       void* C, long ldc, const float* bias, const void* resid, long ldr, int M, int N, int K,
+                                       float* stat_out, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !resid || !stat_out) return HAFF_ERR_BAD_ARG;
+  if ((K & 7) || (lda & 7) || (ldw & 7) || (ldc & 7) || (ldr & 7)) return HAFF_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(C) & 15) ||
+      (reinterpret_cast<uintptr_t>(resid) & 15) || (reinterpret_cast<uintptr_t>(stat_out) & 7))
+    return HAFF_ERR_BAD_ARG;
+  if ((M % 256) || (N % 256) || (K % BK) || (a_map && a_rows <= 0)) return HAFF_ERR_UNSUPPORTED;
+  if ((long)(a_map ? a_rows : M) * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return HAFF_ERR_UNSUPPORTED;
+  GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, ldc,
+             bias, resid, ldr, nullptr, a_map, 8, nullptr, nullptr, M, N, K, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  p.stat_out = stat_out;
+  p.stat_slots = N / 64;
+  const int tn = N / 256;   // raster depth: the rule of gemm_bf16_impl
+  if (tn <= 5) p.group_m = 1;
+  else if (K >= 5120 && tn <= 8) p.group_m = 2;
+  else if (tn <= 16) p.group_m = 4;
+  return launch_gemm<256, 256, 2, 4>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Product with a LayerNorm / RMSNorm folded in (see GemmArgs::ln_stats): the normalised activations never exist in

@@ -273,6 +273,33 @@ extern "C" int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const fl
                     : launch_norm<float, true>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s);
 }
 
+// {mean, rstd} from the per-wave partial sums haff_gemm_bf16_rowstats left: partials f32 [rows][slots][2] = {sum, sum of squares}
+// over 64 columns each, added in slot order (deterministic); C = the row length the sums cover.
+namespace {
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* part, float* stats, int rows, int slots, float inv_c,
+                                                                 float eps) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(part) + (long)r * slots;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < slots; ++i) {
+    const float2 v = p[i];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mean = s1 * inv_c;
+  const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+  reinterpret_cast<float2*>(stats)[r] = float2{mean, rsqrtf(var + eps)};
+}
+}  // namespace
+
+extern "C" int haff_row_stats_finalize(const float* partials, float* stats, int rows, int slots, int C, float eps, void* stream) {
+  if (rows <= 0 || slots <= 0 || C <= 0 || !partials || !stats) return HAFF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(row_stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     partials, stats, rows, slots, 1.0f / (float)C, eps);
+  return haff_check_launch();
+}
+
 // stats[rows][2] = {mean, rstd} of each row (rms != 0: {0, rsqrt(mean(x^2) + eps)} — LlamaRMSNorm). dtype: 0 = bf16,
 // 1 = f32. For haff_gemm_bf16_ln, which applies the normalisation inside the consumer product.
 extern "C" int haff_row_stats(const void* x, long ldx, float* stats, int rows, int C, float eps, int rms, int dtype,

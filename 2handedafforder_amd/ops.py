@@ -58,6 +58,36 @@ def row_stats(x, eps, rms=False):
     return stats
 
 
+def linear_rowstats_supported(M, N, K, dtype, min_tiles=256):
+    """Shapes whose residual product can emit the LayerNorm statistics of its output rows (haff_gemm_bf16_rowstats): whole
+    256 x 256 tiles, and (min_tiles) enough of them that the 8-wave tile is what linear() would launch anyway."""
+    return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= min_tiles
+
+
+def linear_rowstats(x, w, bias, resid, eps, out=None, a_map=None):
+    """out = x @ w.T + bias + resid (bf16; out may be resid) AND the {mean, rstd} of every OUTPUT row as fp32 [M, 2] — the
+    ln_stats of the next linear(..., ln_stats=): the producer's epilogue sums its own results, nobody reads the rows again."""
+    lib = load_library()
+    _req(x, "x")
+    M, K = x.shape
+    if a_map is not None:
+        assert a_map.dtype == torch.int32
+        M = a_map.numel()
+    N = w.shape[0]
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+    assert linear_rowstats_supported(M, N, K, x.dtype, 0) and resid is not None and resid.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device)
+    rc = lib.haff_gemm_bf16_rowstats(x.data_ptr(), x.stride(0), _p(a_map), x.shape[0], w.data_ptr(), w.stride(0), out.data_ptr(),
+                                     out.stride(0), _p(bias), resid.data_ptr(), resid.stride(0), M, N, K, part.data_ptr(), _stream())
+    check(rc, "haff_gemm_bf16_rowstats")
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    check(lib.haff_row_stats_finalize(part.data_ptr(), stats.data_ptr(), M, N // 64, N, float(eps), _stream()),
+          "haff_row_stats_finalize")
+    return out, stats
+
+
 def fold_norm(w, gamma, beta=None, bias=None):
     """Fold y = norm(x) * gamma + beta followed by y @ w.T + bias into the weights: returns (w_bf16 = bf16(w * gamma),
     colsum fp32 [N] of the ROUNDED folded weights, bias' = bias + w @ beta)."""

@@ -72,6 +72,8 @@ class SamEncoderHip:
         self.fold_norms = fold        # (see above; False = the LayerNorm kernels, needs no other change)
         self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
         self.fused_global = True      # global blocks: rel-pos inside the attention kernel (bf16, ViT-H geometry); False = tables
+        self.producer_stats = True    # folded norms: row statistics from the producing product's epilogue (batches whose proj /
+        #                               lin2 run on the 8-wave tile anyway; "force": any whole-tile batch); False = haff_row_stats
         # fp32 image embeddings out of the neck (bf16 mode): the last 3x3-conv GEMM writes its fp32 accumulators and the
         # final LayerNorm2d runs in fp32, so the decoder tail (LisaMI355.fp32_tail) starts from un-rounded embeddings.
         # One bf16 rounding of the embedding ALONE costs 0.0005-0.0014 of mask IoU on random weights (tools/parity_sim.py).
@@ -128,6 +130,11 @@ class SamEncoderHip:
         x = ops.linear(rows, self.w_patch, bias=self.b_patch)
         x = ops.add_bcast(x, self.pos, mod=N, out=x)
         scale = hd ** -0.5
+        # folded norms: {mean, rstd} of the rows of x, handed from the product that WROTE x (proj / lin2 epilogues sum their own
+        # results: ops.linear_rowstats) to the product that normalises it; None = take a statistics pass (ops.row_stats)
+        carry = self.fold_norms and self.producer_stats and \
+            ops.linear_rowstats_supported(x.shape[0], C, C, self.dtype, 0 if self.producer_stats == "force" else 256)
+        st = None
         for i, blk in enumerate(self.blocks):
             compact = (self.compact_windows and not blk["global"] and self.dtype == torch.bfloat16 and s.window == 14
                        and hd == 80)
@@ -143,7 +150,7 @@ class SamEncoderHip:
                 qkv = torch.empty((nb * ntok + 1, 3 * C), dtype=self.dtype, device=x.device)
                 if self.fold_norms:
                     ops.linear(x, blk["wqkv_f"], bias=blk["bqkv_f"], row_map=inv, out=qkv[:-1],
-                               ln_stats=ops.row_stats(x, 1e-6), ln_colsum=blk["sqkv"])
+                               ln_stats=st if st is not None else ops.row_stats(x, 1e-6), ln_colsum=blk["sqkv"])
                 else:
                     xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6)
                     ops.linear(xn, blk["wqkv"], bias=blk["bqkv"], row_map=inv, out=qkv[:-1])
@@ -154,13 +161,17 @@ class SamEncoderHip:
                 v = q5[:, :, 2].permute(0, 2, 1, 3)
                 a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=nb * ntok)
                 del qkv
-                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, a_map=inv, out=x)
+                if carry:
+                    _, st = ops.linear_rowstats(a.view(nb * ntok, C), blk["wproj"], blk["bproj"], x, 1e-6, out=x, a_map=inv)
+                else:
+                    ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, a_map=inv, out=x)
+                    st = None
             else:
                 if blk["global"]:
                     nb, ntok, S, row_map = B, N, g, None
                     if self.fold_norms:
-                        qkv = ops.linear(x, blk["wqkv_f"], bias=blk["bqkv_f"], ln_stats=ops.row_stats(x, 1e-6),
-                                         ln_colsum=blk["sqkv"])
+                        qkv = ops.linear(x, blk["wqkv_f"], bias=blk["bqkv_f"],
+                                         ln_stats=st if st is not None else ops.row_stats(x, 1e-6), ln_colsum=blk["sqkv"])
                     else:
                         qkv = ops.linear(ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6), blk["wqkv"], bias=blk["bqkv"])
                 else:
@@ -181,14 +192,22 @@ class SamEncoderHip:
                     a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
                     del relh, relw
                 del qkv
-                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
+                if carry and row_map is None:
+                    _, st = ops.linear_rowstats(a.view(nb * ntok, C), blk["wproj"], blk["bproj"], x, 1e-6, out=x)
+                else:
+                    ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
+                    st = None
             if self.fold_norms:
-                h = ops.linear(x, blk["w1_f"], bias=blk["b1_f"], act=ops.ACT_GELU, ln_stats=ops.row_stats(x, 1e-6),
-                               ln_colsum=blk["s1"])
+                h = ops.linear(x, blk["w1_f"], bias=blk["b1_f"], act=ops.ACT_GELU,
+                               ln_stats=st if st is not None else ops.row_stats(x, 1e-6), ln_colsum=blk["s1"])
             else:
                 h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6)
                 h = ops.linear(h, blk["w1"], bias=blk["b1"], act=ops.ACT_GELU)
-            ops.linear(h, blk["w2"], bias=blk["b2"], resid=x, out=x)
+            if carry:
+                _, st = ops.linear_rowstats(h, blk["w2"], blk["b2"], x, 1e-6, out=x)
+            else:
+                ops.linear(h, blk["w2"], bias=blk["b2"], resid=x, out=x)
+                st = None
             if taps is not None:
                 taps[f"block{i}"] = x.float().view(B, g, g, C).cpu()
         y = ops.linear(x, self.w_neck0)

@@ -476,6 +476,7 @@ def main(argv=None):
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--fold-norms", action="store_true", help="(default since round 3 for the ViT-H geometry; kept for old command lines)")
+    ap.add_argument("--no-producer-stats", action="store_true", help="folded norms: row statistics by haff_row_stats instead of the producing GEMM's epilogue (A/B)")
     ap.add_argument("--no-fold-norms", action="store_true", help="SAM blocks: LayerNorm kernels instead of the norm carried into the qkv / lin1 products (A/B)")
     ap.add_argument("--tables-global", action="store_true",
                     help="SAM global blocks: rel-pos as fp32 tables + the plain attention kernel instead of the fused kernel (A/B)")
@@ -513,6 +514,8 @@ def main(argv=None):
         model.sam_encoder.fused_global = False
     if args.no_fold_norms:
         model.sam_encoder.fold_norms = False
+    if args.no_producer_stats:
+        model.sam_encoder.producer_stats = False
     del sd
     torch.cuda.empty_cache()
     B, S = args.batch, cfg.sam.img_size

@@ -69,6 +69,14 @@ int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, long a_rows
 int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                       const void* resid, long ldr, const int* row_map, const float* ln_stats, const float* ln_colsum,
                       int M, int N, int K, int act, int out_f32, int swiglu, void* stream);
+/* residual product that also emits the LayerNorm statistics of its output rows (proj / lin2 of a SAM block,
+ * image_encoder.py:186-193): C = A.W^T + bias + resid (bf16; C may alias resid; a_map: optional A-side gather as in
+ * haff_gemm_bf16_gather); stat_out f32 [M][N/64][2] = {sum, sum of squares} of each 64-column slice of the fp32 results.
+ * haff_row_stats_finalize turns them into the {mean, rstd} rows haff_gemm_bf16_ln takes. Whole 256 x 256 tiles only
+ * (M % 256 == 0, N % 256 == 0, K % 64 == 0), else HAFF_ERR_UNSUPPORTED (-2): the caller keeps haff_row_stats. */
+int haff_gemm_bf16_rowstats(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, void* C,
+                            long ldc, const float* bias, const void* resid, long ldr, int M, int N, int K,
+                            float* stat_out, void* stream);
 /* parity-mode twin: everything f32. K % 4 == 0, lda/ldw % 4 == 0. */
 int haff_gemm_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, const float* bias,
                   const float* resid, long ldr, const int* row_map, int M, int N, int K, int act, int swiglu,
@@ -149,6 +157,9 @@ int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const float* w, int
                  void* stream);
 /* per-row {mean, rstd} only (rms != 0: {0, rsqrt(mean(x^2)+eps)}): stats f32 [rows][2]; dtype 0 = bf16, 1 = f32. */
 int haff_row_stats(const void* x, long ldx, float* stats, int rows, int C, float eps, int rms, int dtype, void* stream);
+
+/* stats[rows][2] = {mean, rstd} from haff_gemm_bf16_rowstats' partials f32 [rows][slots][2] (slots added in order); C = row length. */
+int haff_row_stats_finalize(const float* partials, float* stats, int rows, int slots, int C, float eps, void* stream);
 
 /* ---- data movement ------------------------------------------------------------------------------------------ */
 /* conv(k=s=P) rows: x [B][Cin][Hin][Win] -> out [B*gh*gw][Kp], column (c*P+ky)*P+kx, zero beyond Cin*P*P.

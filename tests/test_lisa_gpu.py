@@ -245,6 +245,16 @@ def test_sam_vith_width_windowed_blocks(dev):
     d_f = (out_f - ref_cl).abs().max().item() / scale
     print(f"folded norms vs oracle {d_f:.3e}")
     assert d_f <= 1.5e-2 and (out_f - out_c).abs().max().item() / scale <= 1.5e-2   # measured 7.1e-3
+    # ... with the row statistics handed on by the producing products' epilogues (proj / lin2: haff_gemm_bf16_rowstats; what
+    # batches of >= 4 frames run) instead of a statistics pass over the stored rows
+    with torch.no_grad():
+        enc.producer_stats = "force"
+        out_s = enc(images.to(dev)).float().cpu()
+        enc.producer_stats = False
+        out_n = enc(images.to(dev)).float().cpu()
+    d_s = (out_s - ref_cl).abs().max().item() / scale
+    print(f"folded norms + producer statistics vs oracle {d_s:.3e}, vs statistics pass {(out_s - out_n).abs().max().item() / scale:.3e}")
+    assert d_s <= 1.5e-2 and (out_s - out_n).abs().max().item() / scale <= 1.5e-2
 
 
 def test_decode_graphs_match_eager(dev):

@@ -504,6 +504,55 @@ def test_global_attention_pingpong_kernel(dev, B, H, Nq, Nk):
     assert torch.equal(got, ops.attention(q, k, v, d ** -0.5, relh=relh, relw=relw, S=S))
 
 
+@pytest.mark.parametrize("M,N,K,gather", [(2048, 1280, 1280, False), (1024, 1280, 5120, False), (1536, 1280, 1280, True)])
+def test_linear_rowstats(dev, M, N, K, gather):
+    """haff_gemm_bf16_rowstats: (1) the product + bias + residual is bit-identical to haff_gemm_bf16 on the 256 x 256 tile
+    (in place over the residual, with and without the A-side gather); (2) the {mean, rstd} it hands on equal the row statistics
+    of the stored rows (haff_row_stats of the bf16 output: the producer sums its fp32 values before rounding, so agreement is to
+    a few 1e-4 relative) and the fp64 definition; (3) repeat launches are bit-identical (slots are summed in order)."""
+    ops = _ops()
+    import haff.ops as hops
+    assert hops.linear_rowstats_supported(131072, N, K, torch.bfloat16) and not hops.linear_rowstats_supported(4096, N, K, torch.bfloat16)
+    x = _rand((M + 300 if gather else M, K), dev, torch.bfloat16, 90)
+    w = _rand((N, K), dev, torch.bfloat16, 91, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 92)
+    resid = _rand((M, N), dev, torch.bfloat16, 93, 3.0) + 2.0
+    a_map = None
+    if gather:
+        g = torch.Generator(device="cpu").manual_seed(94)
+        a_map = torch.randperm(M + 300, generator=g)[:M].to(torch.int32).to(dev)
+    ref = ops.linear(x, w, bias=bias, resid=resid, a_map=a_map, tile_cfg=0 if gather else 2)
+    lib = hops.load_library()
+    out = resid.clone()
+    part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=dev)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=dev)
+
+    def run():
+        out.copy_(resid)
+        rc = lib.haff_gemm_bf16_rowstats(x.data_ptr(), x.stride(0), a_map.data_ptr() if gather else None, x.shape[0], w.data_ptr(),
+                                         w.stride(0), out.data_ptr(), out.stride(0), bias.data_ptr(), out.data_ptr(), out.stride(0),
+                                         M, N, K, part.data_ptr(), None)
+        assert rc == 0
+        assert lib.haff_row_stats_finalize(part.data_ptr(), stats.data_ptr(), M, N // 64, N, 1e-6, None) == 0
+        torch.cuda.synchronize()
+        return out.clone(), stats.clone()
+    o1, s1 = run()
+    if gather:   # (the gather entry picks its tile by shape: same sums, possibly another order)
+        _close(o1, ref, 2.0 ** -7, "rowstats product vs haff_gemm_bf16_gather")
+    else:
+        assert torch.equal(o1, ref), "product differs from haff_gemm_bf16 on the same tile"
+    want = ops.row_stats(o1, 1e-6)
+    assert (s1[:, 0] - want[:, 0]).abs().max().item() <= 2e-3 * want[:, 0].abs().max().item() + 1e-4
+    assert ((s1[:, 1] - want[:, 1]).abs() / want[:, 1]).max().item() <= 2e-3
+    o64 = o1.double()
+    mean = o64.mean(1)
+    rstd = (o64.var(1, unbiased=False) + 1e-6).rsqrt()
+    assert (s1[:, 0].double() - mean).abs().max().item() <= 2e-3 * mean.abs().max().item() + 1e-4
+    assert ((s1[:, 1].double() - rstd).abs() / rstd).max().item() <= 2e-3
+    o2, s2 = run()
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+
+
 @pytest.mark.parametrize("B,H", [(1, 16), (2, 3)])
 def test_global_attention_fused_relpos(dev, B, H):
     """haff_global_attention_bf16 (rel_h / rel_w computed in the kernel's prologue from the bf16 parameter tables) against
