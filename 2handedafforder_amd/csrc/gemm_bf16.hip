@@ -96,6 +96,15 @@ struct GemmArgs {
   // order. The consumer product then needs no pass over the rows it normalises.
   float* stat_out;
   int stat_slots;
+  // Llama prefill q|k|v projection with RoPE and the KV-cache append in the epilogue (haff_gemm_bf16_qkv_rope; 8-wave tile,
+  // register epilogue, bf16, no residual). W's rows arrive PERMUTED inside every 256-row tile so that a lane holds column c
+  // of a head in col-block t and its rotate-half partner c + 64 in col-block t + 2 (natural tile column wn*64 + t*16 + i is
+  // logical column (wn>>1)*128 + (t>>1)*64 + (wn&1)*32 + (t&1)*16 + i). Tiles of the q block: rotated, stored to C (the q
+  // buffer, ldc); k block: rotated, stored to rope_k; v block: stored to rope_v; caches [B][rope_tmax][rope_hd], row (b, pos0 + t)
+  // for product row m = b * rope_t + t. rope_cs: f32 [rope_tmax][128] = cos(0..63) | sin(0..63).
+  const float* rope_cs;
+  void *rope_k, *rope_v;
+  int rope_t, rope_tmax, rope_pos0, rope_hd;
 };
 
 // Epilogue activations of the throughput (bf16) path. GELU matters for the K=1280 SAM MLP GEMM, whose epilogue touches
@@ -811,6 +820,35 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       }
       const int orow = out_row(mi);
       float st1 = 0.f, st2 = 0.f;   // row statistics of the final values (RES && ALL && p.stat_out)
+      // RoPE + KV-cache append (see GemmArgs::rope_cs): rotate the lane's (c, c + 64) pairs, pick the destination row
+      bf16_t* rope_dst = nullptr;
+      if constexpr (!RES && !SWIGLU && !OUT_F32) {
+        if (p.rope_cs) {   // wave-uniform
+          const int role = n0e / p.rope_hd;                               // 0 q, 1 k, 2 v: uniform over a 256-column tile
+          const int col0 = n0e - role * p.rope_hd + (wn >> 1) * 128 + (wn & 1) * 32 + coff;   // lane's first column, j = 0
+          const int m = (ALL || orow >= 0) ? orow : 0;
+          const int b = (int)(((float)m + 0.5f) * (1.0f / (float)p.rope_t));   // exact for m < 2^22 (checked on the host)
+          const int pos = p.rope_pos0 + (m - b * p.rope_t);
+          if (role < 2) {
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+              float c4[4], s4[4];
+              const float* csr = p.rope_cs + (long)pos * 128 + (wn & 1) * 32 + tb * 16 + 4 * fh;
+              load4(csr, c4);
+              load4(csr + 64, s4);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float x1 = val[tb][r], x2 = val[tb + 2][r];
+                val[tb][r] = x1 * c4[r] - x2 * s4[r];
+                val[tb + 2][r] = x2 * c4[r] + x1 * s4[r];
+              }
+            }
+          }
+          rope_dst = role == 0 ? reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + col0
+                               : reinterpret_cast<bf16_t*>(role == 1 ? p.rope_k : p.rope_v) +
+                                     ((long)b * p.rope_tmax + pos) * p.rope_hd + col0;
+        }
+      }
       if constexpr (OUT_F32) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -876,6 +914,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
           if (ALL || orow >= 0) {
             bf16_t* dst = ALL ? reinterpret_cast<bf16_t*>(const_cast<char*>(c_lane) + mi * c_pass) + 32 * j
                               : reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n_wave_out + 32 * j + coff;
+            if constexpr (!RES && !SWIGLU) {
+              if (rope_dst) dst = rope_dst + 64 * j;   // logical columns: block pair j = 1 is the rotate-half partner half
+            }
             // plain stores: a lane writes HALF a 128-B line here and the other half with its next store; the L2 merges
             // them, a non-temporal store would send each half to memory on its own (measured -2...-8 %)
             *reinterpret_cast<haff_u32x4*>(dst) = q;
@@ -1607,6 +1648,37 @@ extern "C" int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, 
   if (!a_map || a_rows <= 0) return HAFF_ERR_BAD_ARG;
   return gemm_bf16_impl(A, lda, a_map, a_rows, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu,
                         0, stream);
+}
+
+// Llama prefill q|k|v projection with rotate-half RoPE and the KV-cache append in the epilogue (transformers LlamaAttention.forward
+// reached from llava_llama.py:93-102: q, k = apply_rotary_pos_emb(q_proj(x), k_proj(x)); cache append) — replaces haff_gemm_bf16 +
+// haff_rope_cache on prefill-sized batches: q, k, v are never written un-rotated and read back (1.07 GB per layer at 64 x 291
+// rows). A [M = B*T][K]; Wp [3*H*d][K] = the fused q|k|v weights with the rows of every 256-row tile PERMUTED (see
+// GemmArgs::rope_cs; ops.rope_permute_rows builds it once); q_out [M][ldq] receives the rotated q (H*d columns);
+// kcache / vcache [B][Tmax][H*d] rows pos0 .. pos0+T-1 receive the rotated k and v; cos_sin f32 [Tmax][128].
+// d == 128, (H*d) % 256 == 0, K % 64 == 0, M < 2^22; otherwise HAFF_ERR_UNSUPPORTED.
+extern "C" int haff_gemm_bf16_qkv_rope(const void* A, long lda, const void* Wp, long ldw, void* q_out, long ldq, void* kcache,
+                                       void* vcache, const float* cos_sin, int B, int T, int Tmax, int pos0, int H, int d, int K,
+                                       void* stream) {
+  if (B <= 0 || T <= 0 || H <= 0 || K <= 0 || !q_out || !kcache || !vcache || !cos_sin || pos0 < 0 || pos0 + T > Tmax)
+    return HAFF_ERR_BAD_ARG;
+  if ((K & 7) || (lda & 7) || (ldw & 7) || (ldq & 7)) return HAFF_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(Wp) & 15) || (reinterpret_cast<uintptr_t>(q_out) & 15) ||
+      (reinterpret_cast<uintptr_t>(kcache) & 15) || (reinterpret_cast<uintptr_t>(vcache) & 15) || (reinterpret_cast<uintptr_t>(cos_sin) & 15))
+    return HAFF_ERR_BAD_ARG;
+  const long M = (long)B * T;
+  const int hd = H * d, N = 3 * hd;
+  if (d != 128 || (hd % 256) || (K % BK) || M >= (1L << 22)) return HAFF_ERR_UNSUPPORTED;
+  if (M * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return HAFF_ERR_UNSUPPORTED;
+  GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(Wp), ldw, q_out, ldq,
+             nullptr, nullptr, 0, nullptr, nullptr, 8, nullptr, nullptr, (int)M, N, K, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  p.rope_cs = cos_sin; p.rope_k = kcache; p.rope_v = vcache;
+  p.rope_t = T; p.rope_tmax = Tmax; p.rope_pos0 = pos0; p.rope_hd = hd;
+  const int tn = N / 256;
+  if (tn <= 5) p.group_m = 1;
+  else if (K >= 5120 && tn <= 8) p.group_m = 2;
+  else if (tn <= 16) p.group_m = 4;
+  return launch_gemm<256, 256, 2, 4>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Residual product whose epilogue also emits the LayerNorm statistics of its OUTPUT rows (see GemmArgs::stat_out): proj and

@@ -29,6 +29,8 @@ _PROTOS = {
                           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_row_stats": [c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_row_stats_finalize": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
+    "haff_gemm_bf16_qkv_rope": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_bf16_rowstats": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                 c_long, c_int, c_int, c_int, c_void_p, c_void_p],
     "haff_gemm_f32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,

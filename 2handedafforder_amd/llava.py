@@ -127,6 +127,10 @@ class LlamaHip:
         self.carry_rms = dtype == torch.bfloat16 and self.hd == 128 and l.hidden % 128 == 0 and l.ffn % 128 == 0
         self._folded = None
         self._cs = None
+        # Prefill-sized batches (>= 4096 rows): RoPE and the KV-cache append ride in the q|k|v projection's epilogue
+        # (ops.qkv_rope): the weights get a second, row-permuted copy on first use (+3.2 GB at 7B, +6.3 GB at 13B of 288)
+        self.fused_qkv_rope = True    # ("force": any prefill; False: haff_gemm_bf16 + haff_rope_cache)
+        self._wqkv_rope = None
 
     def _cos_sin(self, tmax):
         if self._cs is None or self._cs.shape[0] < tmax:
@@ -154,13 +158,20 @@ class LlamaHip:
         assert pos0 + T <= cache["tmax"]
         cs = self._cos_sin(cache["tmax"])
         x = x.reshape(B * T, H).clone() if not x.is_contiguous() else x.reshape(B * T, H)
+        fused = self.fused_qkv_rope and T > 1 and \
+            ops.qkv_rope_supported(B * T, nh, hd, H, self.dtype, 1 if self.fused_qkv_rope == "force" else 4096)
+        if fused and self._wqkv_rope is None:
+            self._wqkv_rope = [ops.rope_permute_rows(L["wqkv"]) for L in self.layers]
         for li, L in enumerate(self.layers):
             h = ops.rmsnorm(x, L["n1"], l.rms_eps)
-            qkv = ops.linear(h, L["wqkv"])
             kc, vc = cache["k"][li], cache["v"][li]
-            ops.rope_cache(qkv, kc, vc, cs, B, T, nh, nh, hd, pos0)
             tk = pos0 + T
-            q = qkv.view(B, T, 3, nh, hd)[:, :, 0].permute(0, 2, 1, 3)
+            if fused:
+                q = ops.qkv_rope(h, self._wqkv_rope[li], kc, vc, cs, B, T, nh, hd, pos0).view(B, T, nh, hd).permute(0, 2, 1, 3)
+            else:
+                qkv = ops.linear(h, L["wqkv"])
+                ops.rope_cache(qkv, kc, vc, cs, B, T, nh, nh, hd, pos0)
+                q = qkv.view(B, T, 3, nh, hd)[:, :, 0].permute(0, 2, 1, 3)
             k = kc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)[:, :, :tk]
             v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)[:, :, :tk]
             a = ops.attention(q, k, v, hd ** -0.5, causal=T > 1, q_pos0=tk - T)

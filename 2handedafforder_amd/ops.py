@@ -64,6 +64,18 @@ def linear_rowstats_supported(M, N, K, dtype, min_tiles=256):
     return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= min_tiles
 
 
+def rowstats_gemm(x, w, bias, resid, out, a_map=None):
+    """The product of linear_rowstats alone (one haff_gemm_bf16_rowstats launch): returns the partial sums fp32 [M, N/64, 2]."""
+    lib = load_library()
+    M = a_map.numel() if a_map is not None else x.shape[0]
+    N, K = w.shape
+    part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device)
+    rc = lib.haff_gemm_bf16_rowstats(x.data_ptr(), x.stride(0), _p(a_map), x.shape[0], w.data_ptr(), w.stride(0), out.data_ptr(),
+                                     out.stride(0), _p(bias), resid.data_ptr(), resid.stride(0), M, N, K, part.data_ptr(), _stream())
+    check(rc, "haff_gemm_bf16_rowstats")
+    return part
+
+
 def linear_rowstats(x, w, bias, resid, eps, out=None, a_map=None):
     """out = x @ w.T + bias + resid (bf16; out may be resid) AND the {mean, rstd} of every OUTPUT row as fp32 [M, 2] — the
     ln_stats of the next linear(..., ln_stats=): the producer's epilogue sums its own results, nobody reads the rows again."""
@@ -78,14 +90,46 @@ def linear_rowstats(x, w, bias, resid, eps, out=None, a_map=None):
     assert linear_rowstats_supported(M, N, K, x.dtype, 0) and resid is not None and resid.dtype == torch.bfloat16
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device)
-    rc = lib.haff_gemm_bf16_rowstats(x.data_ptr(), x.stride(0), _p(a_map), x.shape[0], w.data_ptr(), w.stride(0), out.data_ptr(),
-                                     out.stride(0), _p(bias), resid.data_ptr(), resid.stride(0), M, N, K, part.data_ptr(), _stream())
-    check(rc, "haff_gemm_bf16_rowstats")
+    part = rowstats_gemm(x, w, bias, resid, out, a_map)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
     check(lib.haff_row_stats_finalize(part.data_ptr(), stats.data_ptr(), M, N // 64, N, float(eps), _stream()),
           "haff_row_stats_finalize")
     return out, stats
+
+
+def rope_permute_rows(w):
+    """The row order haff_gemm_bf16_qkv_rope wants for the fused q|k|v weights [3*H*128, K]: inside every 256-row tile, natural
+    row wn*64 + t*16 + i takes logical row (wn>>1)*128 + (t>>1)*64 + (wn&1)*32 + (t&1)*16 + i."""
+    N = w.shape[0]
+    assert N % 256 == 0
+    j = torch.arange(256)
+    wn, t, i = j // 64, (j // 16) % 4, j % 16
+    logical = (wn // 2) * 128 + (t // 2) * 64 + (wn % 2) * 32 + (t % 2) * 16 + i
+    idx = (torch.arange(0, N, 256)[:, None] + logical[None, :]).reshape(-1).to(w.device)
+    return w.index_select(0, idx).contiguous()
+
+
+def qkv_rope_supported(M, H, d, K, dtype, min_rows=4096):
+    """Prefill-sized batches whose q|k|v projection can carry RoPE and the cache append (haff_gemm_bf16_qkv_rope): (min_rows)
+    enough rows that the 8-wave tile is what linear() would launch anyway."""
+    return dtype == torch.bfloat16 and d == 128 and (H * d) % 256 == 0 and K % 64 == 0 and min_rows <= M < (1 << 22)
+
+
+def qkv_rope(x, w_perm, kcache, vcache, cos_sin, B, T, H, d, pos0):
+    """Rotated q [B*T, H*d] of x @ w.T; the rotated k and v rows land in kcache / vcache [B, Tmax, H*d] at pos0 .. pos0+T-1."""
+    lib = load_library()
+    _req(x, "x")
+    M, K = x.shape
+    assert M == B * T and w_perm.shape == (3 * H * d, K) and x.stride(1) == 1 and w_perm.stride(1) == 1
+    assert x.dtype == torch.bfloat16 and w_perm.dtype == torch.bfloat16 and kcache.dtype == torch.bfloat16
+    assert kcache.is_contiguous() and vcache.is_contiguous() and kcache.shape == vcache.shape and kcache.shape[2] == H * d
+    assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous() and cos_sin.shape[0] >= kcache.shape[1] and cos_sin.shape[1] == d
+    q = torch.empty((M, H * d), dtype=x.dtype, device=x.device)
+    rc = lib.haff_gemm_bf16_qkv_rope(x.data_ptr(), x.stride(0), w_perm.data_ptr(), w_perm.stride(0), q.data_ptr(), q.stride(0),
+                                     kcache.data_ptr(), vcache.data_ptr(), cos_sin.data_ptr(), B, T, kcache.shape[1], int(pos0),
+                                     H, d, K, _stream())
+    check(rc, "haff_gemm_bf16_qkv_rope")
+    return q
 
 
 def fold_norm(w, gamma, beta=None, bias=None):

@@ -81,10 +81,33 @@ class GemmMeter:
             meter.records.append((e0, e1, 2.0 * M * K * N, byts, stream, 2.0 * N * K))
             return out
         ops.linear = timed
+        # the tile-kernel launches that do not go through ops.linear (round 3: residual products that emit the LayerNorm
+        # statistics, the prefill q|k|v product with RoPE + cache append): same events, same bookkeeping
+        self._orig_rs, self._orig_qr = ops.rowstats_gemm, ops.qkv_rope
+
+        def timed_rs(x, w, bias, resid, out, a_map=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            part = meter._orig_rs(x, w, bias, resid, out, a_map)
+            e1.record()
+            M, K, N = out.shape[0], x.shape[1], w.shape[0]
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + 2 * M * N) + 8.0 * M * (N // 64), False, 2.0 * N * K))
+            return part
+
+        def timed_qr(x, w_perm, kcache, vcache, cos_sin, B, T, H, d, pos0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            q = meter._orig_qr(x, w_perm, kcache, vcache, cos_sin, B, T, H, d, pos0)
+            e1.record()
+            M, K, N = x.shape[0], x.shape[1], w_perm.shape[0]
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K))
+            return q
+        ops.rowstats_gemm, ops.qkv_rope = timed_rs, timed_qr
         return self
 
     def __exit__(self, *exc):
         ops.linear = self._orig
+        ops.rowstats_gemm, ops.qkv_rope = self._orig_rs, self._orig_qr
 
     def summary(self):
         """(launches, ms, flop, algorithmic bytes) of the MFMA tile kernel launches."""
@@ -476,6 +499,7 @@ def main(argv=None):
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--fold-norms", action="store_true", help="(default since round 3 for the ViT-H geometry; kept for old command lines)")
+    ap.add_argument("--no-fused-qkv-rope", action="store_true", help="Llama prefill: q|k|v product + haff_rope_cache instead of RoPE / cache append in the product's epilogue (A/B)")
     ap.add_argument("--no-producer-stats", action="store_true", help="folded norms: row statistics by haff_row_stats instead of the producing GEMM's epilogue (A/B)")
     ap.add_argument("--no-fold-norms", action="store_true", help="SAM blocks: LayerNorm kernels instead of the norm carried into the qkv / lin1 products (A/B)")
     ap.add_argument("--tables-global", action="store_true",
@@ -516,6 +540,8 @@ def main(argv=None):
         model.sam_encoder.fold_norms = False
     if args.no_producer_stats:
         model.sam_encoder.producer_stats = False
+    if args.no_fused_qkv_rope:
+        model.llm.fused_qkv_rope = False
     del sd
     torch.cuda.empty_cache()
     B, S = args.batch, cfg.sam.img_size

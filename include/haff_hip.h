@@ -69,6 +69,16 @@ int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, long a_rows
 int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                       const void* resid, long ldr, const int* row_map, const float* ln_stats, const float* ln_colsum,
                       int M, int N, int K, int act, int out_f32, int swiglu, void* stream);
+/* Llama prefill q|k|v projection with rotate-half RoPE and the KV-cache append in the epilogue (transformers
+ * LlamaAttention.forward via llava_llama.py:93-102) — replaces haff_gemm_bf16 + haff_rope_cache on prefill-sized batches.
+ * A bf16 [B*T][K]; Wp bf16 [3*H*d][K]: the fused q|k|v weights with the rows of every 256-row tile permuted — natural tile row
+ * wn*64 + t*16 + i holds logical row (wn>>1)*128 + (t>>1)*64 + (wn&1)*32 + (t&1)*16 + i (wn, t in 0..3, i in 0..15), so that a
+ * lane owns a column and its rotate-half partner; q_out bf16 [B*T][ldq] receives the rotated q (H*d columns); kcache / vcache
+ * bf16 [B][Tmax][H*d] receive the rotated k and v at rows pos0 .. pos0+T-1; cos_sin f32 [Tmax][d] = cos | sin.
+ * d == 128, (H*d) % 256 == 0, K % 64 == 0; otherwise HAFF_ERR_UNSUPPORTED (-2). */
+int haff_gemm_bf16_qkv_rope(const void* A, long lda, const void* Wp, long ldw, void* q_out, long ldq, void* kcache,
+                            void* vcache, const float* cos_sin, int B, int T, int Tmax, int pos0, int H, int d, int K,
+                            void* stream);
 /* residual product that also emits the LayerNorm statistics of its output rows (proj / lin2 of a SAM block,
  * image_encoder.py:186-193): C = A.W^T + bias + resid (bf16; C may alias resid; a_map: optional A-side gather as in
  * haff_gemm_bf16_gather); stat_out f32 [M][N/64][2] = {sum, sum of squares} of each 64-column slice of the fp32 results.

@@ -208,6 +208,18 @@ def test_full_width_llama_layer_matches_oracle(dev, width, mode):
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"llama {width} {mode}: hidden rel err {err:.3e}")
     assert err <= (2e-4 if mode == "f32" else 1.5e-2)   # bf16 measured 6.3e-3 (13B) ... 6.8e-3 (7B)
+    if mode == "bf16":
+        # the prefill with RoPE + KV-cache append inside the q|k|v projection's epilogue (what batches of >= 4096 rows run):
+        # same oracle, same bound; the cached steps behind it read the cache that epilogue wrote
+        llm.fused_qkv_rope = "force"
+        cache = llm.new_cache(B, T + 2)
+        got2 = [llm.forward(xd[:, :T].contiguous(), cache)]
+        for s in range(2):
+            got2.append(llm.forward(xd[:, T + s:T + s + 1].contiguous(), cache))
+        got2 = torch.cat(got2, 1).float().cpu()
+        err2 = (got2 - ref).abs().max().item() / ref.abs().max().item()
+        print(f"llama {width} bf16, fused qkv + RoPE + cache append: hidden rel err {err2:.3e}")
+        assert err2 <= 1.5e-2 and llm._wqkv_rope is not None
 
 
 @pytest.mark.parametrize("width", ["7b", "13b"])

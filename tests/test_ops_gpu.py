@@ -504,6 +504,54 @@ def test_global_attention_pingpong_kernel(dev, B, H, Nq, Nk):
     assert torch.equal(got, ops.attention(q, k, v, d ** -0.5, relh=relh, relw=relw, S=S))
 
 
+@pytest.mark.parametrize("B,T,H,K,pos0", [(4, 291, 8, 1024, 0), (3, 350, 4, 512, 7), (2, 256, 2, 256, 0)])
+def test_qkv_rope_gemm(dev, B, T, H, K, pos0):
+    """haff_gemm_bf16_qkv_rope (q|k|v projection + rotate-half RoPE + KV-cache append in one epilogue, weights row-permuted
+    inside 256-row tiles) against haff_gemm_bf16 + haff_rope_cache: v rows bit-identical (no arithmetic behind the product),
+    rotated q / k equal up to ONE bf16 rounding (the fused form rotates the fp32 accumulators, the pair rounds the product
+    first), and both against fp64. Ragged last M-tile (B*T not a multiple of 256), pos0 > 0, cache rows outside the new
+    positions untouched."""
+    ops = _ops()
+    d, Tmax = 128, T + pos0 + 5
+    hd = H * d
+    x = _rand((B * T, K), dev, torch.bfloat16, 100)
+    w = _rand((3 * hd, K), dev, torch.bfloat16, 101, K ** -0.5)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    ang = torch.arange(Tmax, dtype=torch.float32)[:, None] * inv[None, :]
+    cs = torch.cat([ang.cos(), ang.sin()], 1).contiguous().to(dev)
+    fill = torch.full((B, Tmax, hd), 7.0, dtype=torch.bfloat16, device=dev)
+    # the two-kernel path
+    qkv = ops.linear(x, w)
+    k1, v1 = fill.clone(), fill.clone()
+    ops.rope_cache(qkv, k1, v1, cs, B, T, H, H, d, pos0)
+    q1 = qkv[:, :hd]
+    # fused
+    k2, v2 = fill.clone(), fill.clone()
+    q2 = ops.qkv_rope(x, ops.rope_permute_rows(w), k2, v2, cs, B, T, H, d, pos0)
+    assert torch.equal(v2, v1), "v rows / untouched cache rows differ"
+    new = slice(pos0, pos0 + T)
+    assert torch.equal(k2[:, :pos0], k1[:, :pos0]) and torch.equal(k2[:, pos0 + T:], k1[:, pos0 + T:])
+    # fp64 reference of the rotation on the fp64 product
+    y = x.double() @ w.double().t()
+    y = y.view(B, T, 3, H, d)
+    c = cs[pos0:pos0 + T, :64].double()[None, :, None, :]
+    s_ = cs[pos0:pos0 + T, 64:].double()[None, :, None, :]
+
+    def rot(u):
+        u1, u2 = u[..., :64], u[..., 64:]
+        return torch.cat([u1 * c - u2 * s_, u2 * c + u1 * s_], -1)
+    qr, kr = rot(y[:, :, 0]).reshape(B * T, hd), rot(y[:, :, 1]).reshape(B, T, hd)
+    _close(q2, qr, 1e-2, "fused q vs fp64")
+    _close(k2[:, new], kr, 1e-2, "fused k vs fp64")
+    _close(q2, q1, 2.0 ** -6, "fused q vs two-kernel path")
+    _close(k2[:, new], k1[:, new], 2.0 ** -6, "fused k vs two-kernel path")
+    # and it is at least as close to fp64 as the pair (one rounding less)
+    assert (q2.double() - qr).abs().mean().item() <= (q1.double() - qr).abs().mean().item() * 1.05
+    k3, v3 = fill.clone(), fill.clone()
+    q3 = ops.qkv_rope(x, ops.rope_permute_rows(w), k3, v3, cs, B, T, H, d, pos0)
+    assert torch.equal(q3, q2) and torch.equal(k3, k2) and torch.equal(v3, v2)
+
+
 @pytest.mark.parametrize("M,N,K,gather", [(2048, 1280, 1280, False), (1024, 1280, 5120, False), (1536, 1280, 1280, True)])
 def test_linear_rowstats(dev, M, N, K, gather):
     """haff_gemm_bf16_rowstats: (1) the product + bias + residual is bit-identical to haff_gemm_bf16 on the 256 x 256 tile
