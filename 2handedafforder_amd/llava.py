@@ -127,7 +127,7 @@ class LlamaHip:
         self.carry_rms = dtype == torch.bfloat16 and self.hd == 128 and l.hidden % 128 == 0 and l.ffn % 128 == 0
         self._folded = None
         self._cs = None
-        # Prefill-sized batches (>= 4096 rows): RoPE and the KV-cache append ride in the q|k|v projection's epilogue
+        # Prefill-sized batches (>= 1024 rows: where the 8-wave tile runs anyway): RoPE and the KV-cache append ride in the q|k|v projection's epilogue
         # (ops.qkv_rope): the weights get a second, row-permuted copy on first use (+3.2 GB at 7B, +6.3 GB at 13B of 288)
         self.fused_qkv_rope = True    # ("force": any prefill; False: haff_gemm_bf16 + haff_rope_cache)
         self._wqkv_rope = None
@@ -159,7 +159,7 @@ class LlamaHip:
         cs = self._cos_sin(cache["tmax"])
         x = x.reshape(B * T, H).clone() if not x.is_contiguous() else x.reshape(B * T, H)
         fused = self.fused_qkv_rope and T > 1 and \
-            ops.qkv_rope_supported(B * T, nh, hd, H, self.dtype, 1 if self.fused_qkv_rope == "force" else 4096)
+            ops.qkv_rope_supported(B * T, nh, hd, H, self.dtype, 1 if self.fused_qkv_rope == "force" else 1024)
         if fused and self._wqkv_rope is None:
             self._wqkv_rope = [ops.rope_permute_rows(L["wqkv"]) for L in self.layers]
         for li, L in enumerate(self.layers):

@@ -58,7 +58,7 @@ def row_stats(x, eps, rms=False):
     return stats
 
 
-def linear_rowstats_supported(M, N, K, dtype, min_tiles=256):
+def linear_rowstats_supported(M, N, K, dtype, min_tiles=160):
     """Shapes whose residual product can emit the LayerNorm statistics of its output rows (haff_gemm_bf16_rowstats): whole
     256 x 256 tiles, and (min_tiles) enough of them that the 8-wave tile is what linear() would launch anyway."""
     return dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= min_tiles
@@ -109,7 +109,7 @@ def rope_permute_rows(w):
     return w.index_select(0, idx).contiguous()
 
 
-def qkv_rope_supported(M, H, d, K, dtype, min_rows=4096):
+def qkv_rope_supported(M, H, d, K, dtype, min_rows=1024):
     """Prefill-sized batches whose q|k|v projection can carry RoPE and the cache append (haff_gemm_bf16_qkv_rope): (min_rows)
     enough rows that the 8-wave tile is what linear() would launch anyway."""
     return dtype == torch.bfloat16 and d == 128 and (H * d) % 256 == 0 and K % 64 == 0 and min_rows <= M < (1 << 22)

@@ -73,7 +73,7 @@ class SamEncoderHip:
         self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
         self.fused_global = True      # global blocks: rel-pos inside the attention kernel (bf16, ViT-H geometry); False = tables
         self.producer_stats = True    # folded norms: row statistics from the producing product's epilogue (batches whose proj /
-        #                               lin2 run on the 8-wave tile anyway; "force": any whole-tile batch); False = haff_row_stats
+        #                               lin2 run on the 8-wave tile anyway: >= 2 frames; "force": any); False = haff_row_stats
         # fp32 image embeddings out of the neck (bf16 mode): the last 3x3-conv GEMM writes its fp32 accumulators and the
         # final LayerNorm2d runs in fp32, so the decoder tail (LisaMI355.fp32_tail) starts from un-rounded embeddings.
         # One bf16 rounding of the embedding ALONE costs 0.0005-0.0014 of mask IoU on random weights (tools/parity_sim.py).
@@ -133,7 +133,7 @@ class SamEncoderHip:
         # folded norms: {mean, rstd} of the rows of x, handed from the product that WROTE x (proj / lin2 epilogues sum their own
         # results: ops.linear_rowstats) to the product that normalises it; None = take a statistics pass (ops.row_stats)
         carry = self.fold_norms and self.producer_stats and \
-            ops.linear_rowstats_supported(x.shape[0], C, C, self.dtype, 0 if self.producer_stats == "force" else 256)
+            ops.linear_rowstats_supported(x.shape[0], C, C, self.dtype, 0 if self.producer_stats == "force" else 160)
         st = None
         for i, blk in enumerate(self.blocks):
             compact = (self.compact_windows and not blk["global"] and self.dtype == torch.bfloat16 and s.window == 14

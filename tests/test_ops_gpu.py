@@ -561,6 +561,7 @@ def test_linear_rowstats(dev, M, N, K, gather):
     ops = _ops()
     import haff.ops as hops
     assert hops.linear_rowstats_supported(131072, N, K, torch.bfloat16) and not hops.linear_rowstats_supported(4096, N, K, torch.bfloat16)
+    assert hops.linear_rowstats_supported(8192, N, K, torch.bfloat16)
     x = _rand((M + 300 if gather else M, K), dev, torch.bfloat16, 90)
     w = _rand((N, K), dev, torch.bfloat16, 91, K ** -0.5)
     bias = _rand((N,), dev, torch.float32, 92)
