@@ -78,7 +78,8 @@ class GemmMeter:
             stream = M <= 64 and K % 128 == 0 and not (M > 32 and N >= 16384) and not kw.get("tile_cfg")
             if x.dtype == torch.float32:
                 stream = "f32"   # the fp32 decoder tail (f32-input MFMA GEMM): its own family, not part of the roofline kernel
-            meter.records.append((e0, e1, 2.0 * M * K * N, byts, stream, 2.0 * N * K))
+            meter.records.append((e0, e1, 2.0 * M * K * N, byts, stream, 2.0 * N * K,
+                                  "ln_fold" if kw.get("ln_stats") is not None else "plain"))
             return out
         ops.linear = timed
         # the tile-kernel launches that do not go through ops.linear (round 3: residual products that emit the LayerNorm
@@ -91,7 +92,7 @@ class GemmMeter:
             part = meter._orig_rs(x, w, bias, resid, out, a_map)
             e1.record()
             M, K, N = out.shape[0], x.shape[1], w.shape[0]
-            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + 2 * M * N) + 8.0 * M * (N // 64), False, 2.0 * N * K))
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + 2 * M * N) + 8.0 * M * (N // 64), False, 2.0 * N * K, "rowstats"))
             return part
 
         def timed_qr(x, w_perm, kcache, vcache, cos_sin, B, T, H, d, pos0):
@@ -100,7 +101,7 @@ class GemmMeter:
             q = meter._orig_qr(x, w_perm, kcache, vcache, cos_sin, B, T, H, d, pos0)
             e1.record()
             M, K, N = x.shape[0], x.shape[1], w_perm.shape[0]
-            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K))
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K, "qkv_rope"))
             return q
         ops.rowstats_gemm, ops.qkv_rope = timed_rs, timed_qr
         return self
@@ -117,6 +118,16 @@ class GemmMeter:
         fl = sum(r[2] for r in rec)
         by = sum(r[3] for r in rec)
         return len(rec), ms, fl, by
+
+    def fused_summary(self):
+        """Tile-kernel launches whose epilogue carries extra work (round 3): {kind: (launches, ms, flop)}; and the plain ones."""
+        out = {}
+        for r in self.records:
+            if r[4] is False:
+                kind = r[6]
+                n, ms, fl = out.get(kind, (0, 0.0, 0.0))
+                out[kind] = (n + 1, ms + r[0].elapsed_time(r[1]), fl + r[2])
+        return out
 
     def stream_summary(self):
         """(launches, ms, weight bytes) of the weight-streaming (M <= 64) launches."""
@@ -607,6 +618,11 @@ def main(argv=None):
             "algorithmic_bytes_per_launch_avg": gemm_bytes / n_launch,
             "launches_per_step": n_launch, "avg_launch_us": 1e3 * gemm_ms / n_launch,
             "flops_per_launch_avg": gemm_fl / n_launch, "gemm_share_of_step": gemm_ms / ms_per_step,
+            # the same launches split by what their epilogue carries besides bias / activation / residual (round 3 moved the
+            # LayerNorm fold, the LayerNorm statistics of the output rows, RoPE + KV-cache append INTO these launches: the work
+            # left other kernels, the FLOPs did not change, so `frac` pays for it)
+            "by_epilogue": {k: {"launches_per_step": n, "achieved": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                                "share_of_step": ms / ms_per_step} for k, (n, ms, fl) in sorted(meter.fused_summary().items())},
             "weight_streaming_gemm": {"kernel": "gemm_skinny_kernel (haff_gemm_bf16 with M <= 64: KV-cached decode steps, [SEG] MLP)",
                                       "bound": "hbm", "launches_per_step": ws_n, "share_of_step": ws_ms / ms_per_step,
                                       "achieved": (ws_bytes / (ws_ms * 1e-3) / 1e9) if ws_ms > 0 else None, "peak": 8000.0,
