@@ -216,6 +216,22 @@ __device__ __forceinline__ void permlane16_swap(unsigned& x, unsigned& y) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
 }
 
+// v_permlane32_swap_b32: lanes 32..63 of x trade places with lanes 0..31 of y.
+__device__ __forceinline__ void permlane32_swap(unsigned& x, unsigned& y) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+// sum over the four lanes {l, l^16, l^32, l^48}, in every one of them, on the VALU alone (no ds_bpermute, no lgkmcnt wait):
+// a swap of two copies leaves (x_row0, x_row0, x_row2, x_row2) and (x_row1, x_row1, x_row3, x_row3); the same by halves
+__device__ __forceinline__ float quad_row_sum(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane16_swap(a, b);
+  v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  a = __builtin_bit_cast(unsigned, v);
+  b = a;
+  permlane32_swap(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -234,7 +250,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;             // 16x16 MFMA tiles per wave
   constexpr int WNC = BN / WN;                                    // columns per wave: 64, or 128 for the 4-wave 256^2 tile
   static_assert(WNC == 64, "wave tile width");
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS + (PP ? 512 : 0)];  // [buf][A | W] (+ PP: the tile's bias)
+  // [buf][A | W] (+ PP: the tile's bias 1 KB | folded-norm row statistics {mean, rstd} x 256 rows 2 KB | column sums 1 KB)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS + (PP ? 2048 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -550,6 +567,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     // reads them from LDS: a global load issued there sat in front of pass 0 with its full latency exposed, once per tile
     if (p.bias && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && wave == 0)
       __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + n0 + lane * 4), (lptr_t)(smem + 2 * STAGE_ELEMS), 16, 0, 0);
+    // folded norm: the tile's 256 {mean, rstd} rows and 256 column sums the same way (waves 1-3, three DMA instructions):
+    // loaded at the top of the epilogue they put a memory round trip in front of pass 0 of every tile (+0.35 % of the step,
+    // norm-folded products 1100 -> 1108 TFLOP/s: bench.py `by_epilogue`, profiles/r3_ln_prefetch_ab.txt)
+    if (p.ln_stats && m0 + BM <= p.M && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0) {
+      float* sLn = reinterpret_cast<float*>(smem + 2 * STAGE_ELEMS) + 256;
+      if (wave == 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.ln_stats + 2 * (long)m0 + lane * 4), (lptr_t)(sLn), 16, 0, 0);
+      if (wave == 2) __builtin_amdgcn_global_load_lds((gptr_t)(p.ln_stats + 2 * (long)(m0 + 128) + lane * 4), (lptr_t)(sLn + 256), 16, 0, 0);
+      if (wave == 3 && p.ln_colsum && (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0)
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.ln_colsum + n0 + lane * 4), (lptr_t)(sLn + 512), 16, 0, 0);
+    }
     if (nk > 1) {
       stage_w_q(buf0 ^ 1, BK, Q0{});
       stage_w_q(buf0 ^ 1, BK, Q1{});
@@ -707,7 +734,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   static_assert((WM * WN * 16 * RS + WM * WN * (2 * WROWS + WNC)) * 4 <= STAGE_ELEMS * 2, "epilogue LDS fits one stage");
   float* sStat = reinterpret_cast<float*>(smem + ebuf * STAGE_ELEMS) + WM * WN * 16 * RS + wave * (2 * WROWS + WNC);   // behind the staging images
   float* sCsum = sStat + 2 * WROWS;
-  if (p.ln_stats) {
+  // (8-wave tile, interior tile: both came in by DMA at the top of the tile's K loop — see there)
+  const bool ln_pref = PP && p.ln_stats && m0e + BM <= p.M && n0e + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0 &&
+                       (!p.ln_colsum || (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0);
+  if (ln_pref) {
+    float* sLn = reinterpret_cast<float*>(smem + 2 * STAGE_ELEMS) + 256;
+    sStat = sLn + 2 * wm * WROWS;
+    if (p.ln_colsum) sCsum = sLn + 512 + wn * WNC;
+    else {   // RMSNorm: no mean term — zeros from the wave's own scratch
+#pragma unroll
+      for (int h = 0; h < WNC / 64; ++h) sCsum[h * 64 + lane] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if (p.ln_stats) {
 #pragma unroll
     for (int h = 0; h < WROWS / 64; ++h) {
       const int m = min(m_wave + h * 64 + lane, p.M - 1);
@@ -926,10 +965,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       }
       if constexpr (RES && ALL) {
         if (p.stat_out) {   // the four lanes of a row (same fr, fh = 0..3) -> one {sum, sum of squares} per (row, wave)
-          st1 += __shfl_xor(st1, 16, 64);
-          st2 += __shfl_xor(st2, 16, 64);
-          st1 += __shfl_xor(st1, 32, 64);
-          st2 += __shfl_xor(st2, 32, 64);
+          st1 = quad_row_sum(st1);
+          st2 = quad_row_sum(st2);
           if (fh == 0)
             *reinterpret_cast<float2*>(p.stat_out + ((long)orow * p.stat_slots + (n_wave_out >> 6)) * 2) = float2{st1, st2};
         }
