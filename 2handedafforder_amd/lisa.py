@@ -43,7 +43,9 @@ class LisaMI355:
         self.decode_graphs = True
         self._ingest = None
         self._graphs = {}
-        self._graph_pool = None   # one memory pool shared by every captured step (replays never overlap)
+        # one memory pool shared by every captured step. Replays never overlap: every graph is replayed on the caller's stream,
+        # one after another — the split-K workspaces baked into them (ops._workspace) may be the same buffer
+        self._graph_pool = None
         self._caches = {}
         sd, dev = state_dict, self.device
         assert cfg.clip.n_patches == N_IMG_PAD + 1, "the reference hard-codes 256 image tokens (LISA.py:461)"

@@ -37,7 +37,12 @@ _WORKSPACES = {}
 
 def _workspace(device, nbytes):
     """Scratch HBM for kernels that take a caller-provided workspace: one buffer per (device, stream), so launches on
-    different HIP streams never share one."""
+    different HIP streams never share one.
+    Under hipGraph capture the key is the CAPTURE stream: the buffer is then allocated from the graph's pool and its address is
+    baked into the graph. Branches of one capture that fork onto other streams get their own buffers (their own keys), but two
+    different graphs may end up holding the same buffer — which is why LisaMI355 replays its graphs one after another on one
+    stream (lisa.py: `_graph_pool`, "replays never overlap") and never replays one beside an eager launch that uses the
+    workspace of the same stream key. A caller that wants concurrent replays must capture them with distinct workspaces."""
     key = (device.index, _stream())
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
