@@ -76,6 +76,7 @@ struct GemmArgs {
   // batched launches (blockIdx.y = z): operand z lives at base + (z / nb_inner) * s?o + (z % nb_inner) * s?i elements
   int nb_inner;
   long sAo, sAi, sWo, sWi, sCo, sCi;
+  int k_total;        // split-K with a short last slice: inner batch zi covers K columns [zi*K, min((zi+1)*K, k_total)); 0 = every slice has K
   int nt_out;         // non-temporal output stores (large outputs; chosen by the launcher)
   // weight-streaming kernel with K split over blockIdx.y: each slice writes its fp32 partial tile to ws[slice][M][N]
   // (caller-provided workspace) and skinny_reduce_kernel applies the epilogue to the slice sum, in slice order
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     p.A += zo * p.sAo + zi * p.sAi;
     p.W += zo * p.sWo + zi * p.sWi;
     const long coff = zo * p.sCo + zi * p.sCi;
+    if (p.k_total) p.K = min(p.K, p.k_total - zi * p.K);
     p.C = OUT_F32 ? static_cast<void*>(reinterpret_cast<float*>(p.C) + coff)
                   : static_cast<void*>(reinterpret_cast<bf16_t*>(p.C) + coff);
   }
@@ -1549,7 +1551,17 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // weight-streaming kernel for decode-sized M; past 32 rows the 128x128 tile is faster again on very wide outputs
   // (M = 64: gate/up 53 vs 75 us, lm_head 68 vs 84 us; qkv 49 vs 42, o_proj 46 vs 24, down 113 vs 63)
-  if (M <= 64 && (K % 128) == 0 && tile_cfg == 0 && !(M > 32 && N >= 16384)) {
+  int skinny_max_m = 64;
+#ifdef HAFF_TUNING   // HAFF_SKINNY_MAXM: rows up to which the weight-streaming kernel is taken (A/B against the split-K tile path)
+  {
+    static const int e = [] { const char* v = getenv("HAFF_SKINNY_MAXM"); return v ? atoi(v) : 64; }();
+    skinny_max_m = e;
+  }
+#endif
+  // 33..64 rows with a workspace: wide or deep weights go to the split-K tile path below (M = 64: qkv 31.7 vs 36.7 us, down_proj
+  // 31.5 vs 42.4 us with 16 uneven K slices; o_proj stays here: 17.3 vs 20.6 us; tools/skinny64_ab.py)
+  const bool tile_rows = M > 32 && workspace && (K % BK) == 0 && !ln_stats && (N >= 8192 || K >= 8192);
+  if (M <= skinny_max_m && (K % 128) == 0 && tile_cfg == 0 && !(M > 32 && N >= 16384) && !tile_rows) {
     if (M > 32 && workspace && workspace_bytes >= 4L * 4 * M * N && !a_map) {
       p.ws = reinterpret_cast<float*>(workspace);
       if (launch_skinny_splitk(p, s)) return haff_check_launch();
@@ -1569,13 +1581,16 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int ksteps = K / BK;
     int ks = 0;
+    int kchunk = 0;   // K-tiles per slice; the last slice may be shorter (K = 11008: 172 K-tiles = 15 x 11 + 7)
     if (t128 <= 256 && ksteps >= 32)   // (K = 1024: the second launch costs more than the shorter loop saves, 17.5 -> 19.8 us)
-      for (int c : {16, 8, 4, 2})
-        if (ksteps % c == 0 && ksteps / c >= 4 && t128 * c <= 512 && 4L * c * M * N <= workspace_bytes) { ks = c; break; }
+      for (int c : {16, 8, 4, 2}) {
+        const int kc = (ksteps + c - 1) / c, n_sl = (ksteps + kc - 1) / kc;
+        if (kc >= 4 && ksteps - (n_sl - 1) * kc >= 2 && t128 * n_sl <= 512 && 4L * n_sl * M * N <= workspace_bytes) { ks = n_sl; kchunk = kc; break; }
+      }
     if (ks) {
       GemmArgs q = p;
       q.C = workspace; q.ldc = N; q.bias = nullptr; q.resid = nullptr; q.ldr = 0; q.row_map = nullptr;
-      q.K = K / ks; q.act = 0; q.out_f32 = 1; q.swiglu = 0;   // raw interleaved columns: the reduce kernel pairs them
+      q.K = kchunk * BK; q.k_total = K; q.act = 0; q.out_f32 = 1; q.swiglu = 0;   // raw interleaved columns: the reduce kernel pairs them
       q.nb_inner = ks; q.sAo = 0; q.sWo = 0; q.sCo = 0; q.sAi = q.K; q.sWi = q.K; q.sCi = (long)M * N;
       const int rc = launch_gemm<128, 128, 2, 2>(q, s, ks);
       if (rc) return rc;
