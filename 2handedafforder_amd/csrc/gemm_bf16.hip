@@ -1560,7 +1560,14 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
 #endif
   // 33..64 rows with a workspace: wide or deep weights go to the split-K tile path below (M = 64: qkv 31.7 vs 36.7 us, down_proj
   // 31.5 vs 42.4 us with 16 uneven K slices; o_proj stays here: 17.3 vs 20.6 us; tools/skinny64_ab.py)
-  const bool tile_rows = M > 32 && workspace && (K % BK) == 0 && !ln_stats && (N >= 8192 || K >= 8192);
+  int tile_min_m = 32;
+#ifdef HAFF_TUNING
+  {
+    static const int e = [] { const char* v = getenv("HAFF_TILE_MINM"); return v ? atoi(v) : 32; }();
+    tile_min_m = e;
+  }
+#endif
+  const bool tile_rows = M > tile_min_m && workspace && (K % BK) == 0 && !ln_stats && (N >= 8192 || K >= 8192);
   if (M <= skinny_max_m && (K % 128) == 0 && tile_cfg == 0 && !(M > 32 && N >= 16384) && !tile_rows) {
     if (M > 32 && workspace && workspace_bytes >= 4L * 4 * M * N && !a_map) {
       p.ws = reinterpret_cast<float*>(workspace);
@@ -1577,7 +1584,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   // 64-step K loop each on 96 CUs: 62 us; 4 slices: 384 workgroups x 16 steps). Each slice is a "batch" of the batched
   // launch — operands offset by slice * K/ks along K, fp32 partial tile into ws[slice][M][N] — and skinny_reduce_kernel
   // adds the slices in index order and applies the epilogue: deterministic.
-  if (tile_cfg == 0 && workspace && !ln_stats && M > 32 && (K % BK) == 0) {
+  if (tile_cfg == 0 && workspace && !ln_stats && M > (tile_min_m < 32 ? tile_min_m : 32) && (K % BK) == 0) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int ksteps = K / BK;
     int ks = 0;

@@ -8,7 +8,7 @@ for name, N, K, sw in shapes:
     copies = max(2, int(1.2e9 // (N * K * 2)))
     ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(copies)]
     line = f"{name:8s}"
-    for M in (33, 48, 64):
+    for M in (int(m) for m in os.environ.get('MS', '33,48,64').split(',')):
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         for i in range(copies): ops.linear(x, ws[i], swiglu=sw)
         torch.cuda.synchronize()
