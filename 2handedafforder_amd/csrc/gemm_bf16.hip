@@ -76,6 +76,7 @@ struct GemmArgs {
   // batched launches (blockIdx.y = z): operand z lives at base + (z / nb_inner) * s?o + (z % nb_inner) * s?i elements
   int nb_inner;
   long sAo, sAi, sWo, sWi, sCo, sCi;
+  int deep_k;         // 128x128 tile: K loop with TWO K-tiles of DMA in flight (two barriers per K-tile); set by the launcher
   int k_total;        // split-K with a short last slice: inner batch zi covers K columns [zi*K, min((zi+1)*K, k_total)); 0 = every slice has K
   int nt_out;         // non-temporal output stores (large outputs; chosen by the launcher)
   // weight-streaming kernel with K split over blockIdx.y: each slice writes its fp32 partial tile to ws[slice][M][N]
@@ -644,6 +645,44 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     // is what round 1's form lacked: hipcc had sunk the wait for the last two ds_read_b128 below its end-of-iteration
     // barrier, so a fast wave could request the next tile into a buffer a slow wave was still reading — a write-after-read
     // race that showed as rare wrong fragments beside a second stream (tools/vmcnt_forensics.py).
+    if (p.deep_k) {
+      // Launches whose workgroups are few and whose K loop is what they wait on (one-frame prefill / CLIP / SAM products,
+      // split-K slices, decode batches of 33..64 rows): with ONE K-tile of DMA in flight an iteration lasts one memory round
+      // trip (~1 us) whatever its 32 MFMAs take (0.2 us) — 288 x 12288 x 4096 streamed its weights at 1.5 TB/s. Here the
+      // fragments of K-tile kt go to registers first, a barrier hands its buffer straight back to the DMA (K-tile kt + 2),
+      // and the MFMAs run from registers with two K-tiles in flight behind a COUNTED wait (8 requests per wave per K-tile;
+      // LDS-DMA leaves vmcnt in issue order: tools/probes/vmcnt_order_probe.hip). Two barriers per K-tile cost compute-bound
+      // launches 7 % (measured in round 1), which is why the launcher sets this for the short ones only.
+      constexpr int NS = NA + NW;   // DMA instructions per wave per K-tile
+      static_assert(NS == 8, "counted wait below is written for 8 requests per K-tile");
+      stage(0, 0);
+      if (nk > 1) {
+        stage(1, BK);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        read_frags(cur, 0);
+        read_frags(cur, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this buffer are done BEFORE the barrier (WAR)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
+        mfma_rows(0, 0, TM);
+        mfma_rows(1, 0, TM);
+        if (kt + 1 < nk) {   // K-tile kt + 1 has landed (mine); kt + 2 may stay in flight
+          if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -666,6 +705,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
+    }
     }
   }
 #if defined(HAFF_TUNING) && defined(HAFF_EXP_MFMA32)
@@ -1521,12 +1561,22 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
     if (cap > 0 && gx > cap) gx = cap;
   }
   dim3 grid(gx, nbatch), block(64 * WM * WN);
+  GemmArgs pd = p;
+  if (WM * WN == 4) {
+    long deep_max = 1024;   // 128x128 work items (tiles x slices) up to which the launch takes the two-K-tiles-in-flight loop
+#ifdef HAFF_TUNING
+    static const long dm_env = [] { const char* e = getenv("HAFF_GEMM_DEEP_MAX"); return e ? atol(e) : 1024L; }();
+    deep_max = dm_env;
+#endif
+    pd.deep_k = (long)tiles * nbatch <= deep_max && ((p.K + BK - 1) / BK) >= 3;
+  }
+  const GemmArgs& pl = pd;
   if (p.swiglu) {
-    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, pl);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, pl);
   } else {
-    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
+    if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, pl);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, pl);
   }
   return haff_check_launch();
 }
