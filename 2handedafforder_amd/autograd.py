@@ -369,7 +369,54 @@ class AttentionFn(Function):
         return dq, dk, dv, None, None, None
 
 
-attention = AttentionFn.apply
+class FlashAttentionFn(Function):
+    """The same op without probabilities in HBM (d == 128, bf16: the Llama self-attention of the fine-tune step): forward =
+    haff_attention_lse_bf16 (flash kernel + per-row log-sum-exp), backward = haff_attention_bwd_bf16 (recomputes P per 64 x 64
+    block; dq / dk / dv in one launch, no transposes, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, scale_, causal):
+        lib = load_library()
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Nq, HD = q.shape
+        Nk = k.shape[1]
+        d = HD // H
+        out = torch.empty_like(q)
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        check(lib.haff_attention_lse_bf16(q.data_ptr(), Nq * HD, d, HD, k.data_ptr(), Nk * HD, d, HD, v.data_ptr(), Nk * HD, d, HD,
+                                          out.data_ptr(), Nq * HD, d, HD, B, H, Nq, Nk, d, float(scale_), 1 if causal else 0,
+                                          Nk - Nq, lse.data_ptr(), _s()), "haff_attention_lse_bf16")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cfg = (H, float(scale_), bool(causal))
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = load_library()
+        q, k, v, out, lse = ctx.saved_tensors
+        H, scale_, causal = ctx.cfg
+        do = do.contiguous()
+        B, Nq, HD = q.shape
+        Nk = k.shape[1]
+        d = HD // H
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        n_ws = B * H * (Nq + 4 + ((Nq + 63) // 64) * 64 * d)
+        ws = torch.empty((n_ws,), dtype=torch.float32, device=q.device)
+        check(lib.haff_attention_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                          dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), n_ws, HD, B, H, Nq, Nk, d,
+                                          scale_, 1 if causal else 0, Nk - Nq, _s()), "haff_attention_bwd_bf16")
+        return dq, dk, dv, None, None, None
+
+
+FLASH_TRAINING_ATTENTION = True   # False: every attention of the fine-tune step takes the materialised form (A/B, tests)
+
+
+def attention(q, k, v, H, scale_, causal):
+    """softmax(scale * q k^T [+ causal]) v for token-major q [B,Nq,H*d], k / v [B,Nk,H*d] under autograd."""
+    if (FLASH_TRAINING_ATTENTION and q.dtype == torch.bfloat16 and q.shape[2] // H == 128 and (not causal or k.shape[1] >= q.shape[1])
+            and (q.shape[2] % 8) == 0):
+        return FlashAttentionFn.apply(q, k, v, H, scale_, causal)
+    return AttentionFn.apply(q, k, v, H, scale_, causal)
 
 
 class BgemmFn(Function):

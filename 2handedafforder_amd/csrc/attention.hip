@@ -47,6 +47,9 @@ struct AttnArgs {
   const float* cos_sin;   // [Tmax][d] = cos(0..d/2) | sin(0..d/2)
   // attn_global_pp_kernel<true>: the decomposed rel-pos TABLES (bf16 [2S-1][d]); rel_h / rel_w are computed in the prologue
   const bf16_t *tab_h, *tab_w;
+  // attn_fwd_kernel: optional per-row log-sum-exp of the scores in the LOG2 domain (scale * log2(e) * q.k, masked), f32
+  // [B][H][Nq] — what the flash backward (attention_bwd.hip) recomputes the probabilities from
+  float* lse;
 };
 
 constexpr int QB = 128;   // queries per workgroup
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       l += __shfl_xor(l, 32, 64);
     }
     const float inv = 1.0f / l;
+    if (p.lse && fh == 0 && qrow[qt] < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + qrow[qt]] = m_run[qt] + __builtin_amdgcn_logf(l);
     if (qrow[qt] < p.Nq) {
 #pragma unroll
       for (int dt = 0; dt < ND; ++dt) {
@@ -1249,7 +1253,8 @@ static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
                                void* o, long o_sb, long o_sh, long o_st,
                                int B, int H, int Nq, int Nk, int d, float scale,
                                int causal, int q_pos0,
-                               const float* relh, const float* relw, int S, const int* nk_rows, void* stream) {
+                               const float* relh, const float* relw, int S, const int* nk_rows, void* stream,
+                               float* lse = nullptr) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d > 128 || (d & 7)) return HAFF_ERR_BAD_ARG;
   if ((q_st & 7) || (k_st & 7) || (v_st & 7) || (o_st & 3) || (q_sh & 7) || (k_sh & 7) || (v_sh & 7) || (o_sh & 3) ||
       (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (o_sb & 3))
@@ -1259,8 +1264,9 @@ static int attention_bf16_impl(const void* q, long q_sb, long q_sh, long q_st,
   AttnArgs p{reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v),
              reinterpret_cast<bf16_t*>(o), q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st,
              B, H, Nq, Nk, d, scale, q_pos0, relh, relw, S, nk_rows, nullptr, nullptr, nullptr};
+  p.lse = lse;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (!rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
+  if (!lse && !rel && Nq == 1 && d == DEC_D && (!causal || q_pos0 >= Nk - 1) && (o_sh & 7) == 0 && (o_sb & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
     if (B * H <= 128) hipLaunchKernelGGL((attn_decode_kernel<true, false, 16>), dim3(B * H), dim3(1024), 0, s, p);
     else if (B * H <= 1024) hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * H), dim3(256), 0, s, p);
@@ -1307,6 +1313,19 @@ extern "C" int haff_attention_bf16(const void* q, long q_sb, long q_sh, long q_s
                                    const float* relh, const float* relw, int S, void* stream) {
   return attention_bf16_impl(q, q_sb, q_sh, q_st, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, o_st, B, H, Nq, Nk, d,
                              scale, causal, q_pos0, relh, relw, S, nullptr, stream);
+}
+
+// haff_attention_bf16 that also returns the per-row log-sum-exp of the scores, LOG2 domain (log2 sum_k 2^(scale*log2(e)*q.k)), f32
+// [B][H][Nq]: the forward half of the flash pair whose backward is haff_attention_bwd_bf16 (no probabilities are kept).
+extern "C" int haff_attention_lse_bf16(const void* q, long q_sb, long q_sh, long q_st,
+                                       const void* k, long k_sb, long k_sh, long k_st,
+                                       const void* v, long v_sb, long v_sh, long v_st,
+                                       void* o, long o_sb, long o_sh, long o_st,
+                                       int B, int H, int Nq, int Nk, int d, float scale, int causal, int q_pos0,
+                                       float* lse, void* stream) {
+  if (!lse) return HAFF_ERR_BAD_ARG;
+  return attention_bf16_impl(q, q_sb, q_sh, q_st, k, k_sb, k_sh, k_st, v, v_sb, v_sh, v_st, o, o_sb, o_sh, o_st, B, H, Nq, Nk, d,
+                             scale, causal, q_pos0, nullptr, nullptr, 0, nullptr, stream, lse);
 }
 
 // SAM GLOBAL attention with the decomposed rel-pos bias computed inside the kernel (Attention.forward,

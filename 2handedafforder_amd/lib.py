@@ -59,6 +59,11 @@ _PROTOS = {
                                    c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                    c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_long,
                                    c_void_p],
+    "haff_attention_lse_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
+                                c_void_p, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
+                                c_void_p, c_void_p],
+    "haff_attention_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_global_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                    c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                    c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],

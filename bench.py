@@ -409,6 +409,9 @@ def train_main(args):
     hooks) and the fused clip + AdamW update — nothing skipped. value = samples/s over all ranks."""
     from haff import train_ops as T
     from haff.train_model import LisaTrainable
+    if args.materialised_attention:
+        from haff import autograd as hag
+        hag.FLASH_TRAINING_ATTENTION = False
     rank, world, local_rank = hdist.init_from_env("nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -522,6 +525,8 @@ def main(argv=None):
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: BASELINE configs[2] (the headline metric); train: configs[3], one LoRA fine-tune step per step")
+    ap.add_argument("--materialised-attention", action="store_true",
+                    help="--mode train: the Llama self-attention with probabilities in HBM (batched products + softmax kernels) instead of the flash pair (A/B)")
     ap.add_argument("--train-ids", type=int, default=96)
     ap.add_argument("--train-mask", type=int, default=1024)
     ap.add_argument("--stub-step-ms", type=float, default=None,

@@ -131,6 +131,18 @@ int haff_relpos_tables(const void* q, long q_sb, long q_sh, long q_st, const flo
 int haff_relpos_tables_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* tab_h, const void* tab_w,
                             float* relh, float* relw, int B, int H, int S, int d, void* stream);
 
+/* flash attention pair of the fine-tune path (transformers LlamaAttention under autograd; row a16, LISA.py:175-430):
+ * haff_attention_lse_bf16 = haff_attention_bf16 (no bias) that also returns lse f32 [B][H][Nq] = log2 sum_k 2^(scale*log2(e)*q.k)
+ * over the visible keys; haff_attention_bwd_bf16 = dq, dk, dv from q, k, v, o, dout and lse without the probabilities ever
+ * existing in HBM (d == 128; bitwise repeatable: no atomics). q / o / dout / dq: [B][Nq][ld], k / v / dk / dv: [B][Nk][ld],
+ * head h at columns h*128; workspace f32 with >= B*H*(Nq + 3 + 128*roundup(Nq, 64)) values; causal needs q_pos0 >= 0. */
+int haff_attention_lse_bf16(const void* q, long q_sb, long q_sh, long q_st, const void* k, long k_sb, long k_sh, long k_st,
+                            const void* v, long v_sb, long v_sh, long v_st, void* o, long o_sb, long o_sh, long o_st, int B, int H,
+                            int Nq, int Nk, int d, float scale, int causal, int q_pos0, float* lse, void* stream);
+int haff_attention_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                            void* dq, void* dk, void* dv, float* workspace, long workspace_elems, long ld, int B, int H, int Nq,
+                            int Nk, int d, float scale, int causal, int q_pos0, void* stream);
+
 /* fused SAM WINDOW attention with the decomposed rel-pos bias computed in the kernel (one pass over HBM; replaces
  * haff_relpos_tables_bf16 + haff_attention_bf16 for the 28 windowed ViT-H blocks): Attention.forward
  * (image_encoder.py:235-260) + add_decomposed_rel_pos (:354-392) + get_rel_pos with q_size == k_size (:322-351).

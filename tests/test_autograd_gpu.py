@@ -131,6 +131,53 @@ def test_attention_fn(dev, dtype, B, H, Nq, Nk, d, causal):
     _close(v.grad, vr.grad, tol, "dv")
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,causal", [(2, 4, 351, 351, True), (1, 3, 200, 200, False), (2, 2, 64, 64, True),
+                                              (1, 2, 65, 130, True), (1, 2, 130, 70, False)])
+def test_flash_attention_fn(dev, B, H, Nq, Nk, causal):
+    """The flash pair of the fine-tune path (haff_attention_lse_bf16 + haff_attention_bwd_bf16, d = 128, bf16: no probabilities
+    in HBM) against (1) fp32 torch autograd of the definition and (2) the materialised AttentionFn it replaces; ragged last
+    blocks (351 = 5 x 64 + 31), Nk != Nq (causal offset q_pos0 = Nk - Nq), one block, non-causal; a second backward gives the
+    same bits (dq is summed by the owning workgroup in a fixed order: no atomics)."""
+    A = _ag()
+    d, dtype = 128, torch.bfloat16
+    q, k, v = (_leaf(_rand((B, n, H * d), dev, dtype, s)) for n, s in ((Nq, 40), (Nk, 41), (Nk, 42)))
+    go = _rand((B, Nq, H * d), dev, dtype, 43)
+    scale = d ** -0.5
+    assert A.FLASH_TRAINING_ATTENTION
+    o = A.attention(q, k, v, H, scale, causal)
+    assert o.grad_fn is not None and "Flash" in type(o.grad_fn).__name__
+    o.backward(go)
+    # (1) the definition in fp32
+    qr, kr, vr = (_leaf(t.detach().float()) for t in (q, k, v))
+    q4, k4, v4 = (t.view(B, -1, H, d).permute(0, 2, 1, 3) for t in (qr, kr, vr))
+    s_ = (q4 @ k4.transpose(-1, -2)) * scale
+    if causal:
+        m = torch.arange(Nk, device=dev)[None, :] > torch.arange(Nq, device=dev)[:, None] + (Nk - Nq)
+        s_ = s_.masked_fill(m, float("-inf"))
+    orf = (torch.softmax(s_, -1) @ v4).permute(0, 2, 1, 3).reshape(B, Nq, H * d)
+    orf.backward(go.float())
+    for got, ref, what in ((o, orf, "out"), (q.grad, qr.grad, "dq"), (k.grad, kr.grad, "dk"), (v.grad, vr.grad, "dv")):
+        _close(got, ref, 3e-2, f"flash {what} vs fp32 autograd")
+    # (2) the materialised form on the same inputs
+    qm, km, vm = (_leaf(t.detach()) for t in (q, k, v))
+    A.FLASH_TRAINING_ATTENTION = False
+    try:
+        om = A.attention(qm, km, vm, H, scale, causal)
+        om.backward(go)
+    finally:
+        A.FLASH_TRAINING_ATTENTION = True
+    for got, ref, what in ((o, om, "out"), (q.grad, qm.grad, "dq"), (k.grad, km.grad, "dk"), (v.grad, vm.grad, "dv")):
+        _close(got, ref, 2e-2, f"flash {what} vs materialised")
+    # the flash gradients are no further from fp32 than the materialised ones (mean error)
+    e_f = sum((g.float() - r).abs().mean().item() for g, r in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)))
+    e_m = sum((g.float() - r).abs().mean().item() for g, r in ((qm.grad, qr.grad), (km.grad, kr.grad), (vm.grad, vr.grad)))
+    assert e_f <= 1.25 * e_m, (e_f, e_m)
+    # repeatable to the bit
+    q2, k2, v2 = (_leaf(t.detach()) for t in (q, k, v))
+    A.attention(q2, k2, v2, H, scale, causal).backward(go)
+    assert torch.equal(q2.grad, q.grad) and torch.equal(k2.grad, k.grad) and torch.equal(v2.grad, v.grad)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_rope_bmm_embed_ce(dev, dtype):
     A = _ag()
