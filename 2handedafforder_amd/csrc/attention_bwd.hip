@@ -90,34 +90,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(BwdArgs p) {
     for (int dt = 0; dt < 8; ++dt) dKt[dt] = dVt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     int i0 = 0;
     if (p.causal) i0 = max(0, j * BB - p.q_pos0) / BB;   // first query block with a query that sees a key of this block
-    for (int i = i0; i < nqb; ++i) {
-      __syncthreads();   // previous iteration's reads of sQ / sQs / sdO / sdS are done
-      // ---- stage the query block: q raw + pre-scaled, dO, lse, delta ----
+    // the query block of iteration i + 1 is fetched into registers while iteration i computes (228 -> 202 us per layer at
+    // 8 x 32 x 351 tokens; the rest is one wave per SIMD waiting on its own LDS reads: 3 % of the fine-tune step)
+    uint4 nq[4], ndo[4];
+    float nl = 0.f, nd = 0.f;
+    auto fetch_block = [&](int i) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
         const int c = tid + ii * 256, r = c >> 4, col = (c & 15) * 8;
-        uint4 qv = make_uint4(0, 0, 0, 0), dv = make_uint4(0, 0, 0, 0), qs = make_uint4(0, 0, 0, 0);
-        if (i * BB + r < p.Nq) {
+        nq[ii] = ndo[ii] = make_uint4(0, 0, 0, 0);
+        if (i < nqb && i * BB + r < p.Nq) {
           const long off = qbase + (long)(i * BB + r) * p.ld + col;
-          qv = *reinterpret_cast<const uint4*>(p.q + off);
-          dv = *reinterpret_cast<const uint4*>(p.dout + off);
-          const unsigned w4[4] = {qv.x, qv.y, qv.z, qv.w};
-          unsigned o4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o4[e] = pack_bf16x2(__uint_as_float(w4[e] << 16) * sl2, __uint_as_float(w4[e] & 0xffff0000u) * sl2);
-          qs = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+          nq[ii] = *reinterpret_cast<const uint4*>(p.q + off);
+          ndo[ii] = *reinterpret_cast<const uint4*>(p.dout + off);
         }
-        *reinterpret_cast<uint4*>(sQ + r * BSTR + col) = qv;
-        *reinterpret_cast<uint4*>(sQs + r * BSTR + col) = qs;
-        *reinterpret_cast<uint4*>(sdO + r * BSTR + col) = dv;
+      }
+      nl = nd = 0.f;
+      if (tid < BB && i < nqb && i * BB + tid < p.Nq) {
+        nl = p.lse[(long)bh * p.Nq + i * BB + tid];
+        nd = p.delta[(long)bh * p.Nq + i * BB + tid];
+      }
+    };
+    fetch_block(i0);
+    for (int i = i0; i < nqb; ++i) {
+      __syncthreads();   // previous iteration's reads of sQ / sQs / sdO / sdS are done
+      // ---- the query block (already in registers) -> LDS: q raw + pre-scaled, dO, lse, delta ----
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int c = tid + ii * 256, r = c >> 4, col = (c & 15) * 8;
+        const unsigned w4[4] = {nq[ii].x, nq[ii].y, nq[ii].z, nq[ii].w};
+        unsigned o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o4[e] = pack_bf16x2(__uint_as_float(w4[e] << 16) * sl2, __uint_as_float(w4[e] & 0xffff0000u) * sl2);
+        *reinterpret_cast<uint4*>(sQ + r * BSTR + col) = nq[ii];
+        *reinterpret_cast<uint4*>(sQs + r * BSTR + col) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        *reinterpret_cast<uint4*>(sdO + r * BSTR + col) = ndo[ii];
       }
       if (tid < BB) {
-        const int qq = i * BB + tid;
-        sL[tid] = qq < p.Nq ? p.lse[(long)bh * p.Nq + qq] : 0.f;
-        sD[tid] = qq < p.Nq ? p.delta[(long)bh * p.Nq + qq] : 0.f;
+        sL[tid] = nl;
+        sD[tid] = nd;
       }
       __syncthreads();
+      fetch_block(i + 1);   // in flight under this iteration's products
 
       // ---- S = Qs . K^T and dP = dO . V^T for the wave's 16 keys x 64 queries ----
       f32x4 sS[4], dP[4];
