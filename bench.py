@@ -73,13 +73,14 @@ class GemmMeter:
             byts = 2.0 * (M * K + N * K + M * n_out + (M * n_out if kw.get("resid") is not None else 0))
             if out.dtype == torch.float32:
                 byts += 2.0 * M * n_out
-            # which kernel family the C-ABI dispatches to (gemm_bf16.hip: gemm_bf16_impl): the weight-streaming kernel
-            # for M <= 64 (HBM-bound), the MFMA tile kernel otherwise — the roofline below is the tile kernel's
-            stream = M <= 64 and K % 128 == 0 and not (M > 32 and N >= 16384) and not kw.get("tile_cfg")
+            # two families with two rooflines: launches of <= 64 rows are decode steps / the [SEG] MLP — HBM-bound weight
+            # streaming whichever kernel gemm_bf16_impl picks for them (the weight-streaming kernel, or since round 3 the split-K
+            # tile path for wide / deep weights at 33..64 rows); everything larger is the MFMA-bound tile kernel
+            stream = M <= 64 and not kw.get("tile_cfg")
             if x.dtype == torch.float32:
                 stream = "f32"   # the fp32 decoder tail (f32-input MFMA GEMM): its own family, not part of the roofline kernel
             meter.records.append((e0, e1, 2.0 * M * K * N, byts, stream, 2.0 * N * K,
-                                  "ln_fold" if kw.get("ln_stats") is not None else "plain"))
+                                  "ln_fold" if kw.get("ln_stats") is not None else "plain", (M, N, K)))
             return out
         ops.linear = timed
         # the tile-kernel launches that do not go through ops.linear (round 3: residual products that emit the LayerNorm
@@ -92,7 +93,7 @@ class GemmMeter:
             part = meter._orig_rs(x, w, bias, resid, out, a_map)
             e1.record()
             M, K, N = out.shape[0], x.shape[1], w.shape[0]
-            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + 2 * M * N) + 8.0 * M * (N // 64), False, 2.0 * N * K, "rowstats"))
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + 2 * M * N) + 8.0 * M * (N // 64), False, 2.0 * N * K, "rowstats", (M, N, K)))
             return part
 
         def timed_qr(x, w_perm, kcache, vcache, cos_sin, B, T, H, d, pos0):
@@ -101,7 +102,7 @@ class GemmMeter:
             q = meter._orig_qr(x, w_perm, kcache, vcache, cos_sin, B, T, H, d, pos0)
             e1.record()
             M, K, N = x.shape[0], x.shape[1], w_perm.shape[0]
-            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K, "qkv_rope"))
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K, "qkv_rope", (M, N, K)))
             return q
         ops.rowstats_gemm, ops.qkv_rope = timed_rs, timed_qr
         return self
@@ -128,6 +129,18 @@ class GemmMeter:
                 n, ms, fl = out.get(kind, (0, 0.0, 0.0))
                 out[kind] = (n + 1, ms + r[0].elapsed_time(r[1]), fl + r[2])
         return out
+
+    def shape_summary(self, top=12):
+        """The tile-kernel launches grouped by (M, N, K, epilogue kind), heaviest first."""
+        agg = {}
+        for r in self.records:
+            if r[4] is False:
+                key = r[7] + (r[6],)
+                n, ms, fl = agg.get(key, (0, 0.0, 0.0))
+                agg[key] = (n + 1, ms + r[0].elapsed_time(r[1]), fl + r[2])
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+        return [{"M": k[0], "N": k[1], "K": k[2], "epilogue": k[3], "launches_per_step": n, "ms_per_step": round(ms, 3),
+                 "achieved": round(fl / (ms * 1e-3) / 1e12, 1)} for k, (n, ms, fl) in rows]
 
     def stream_summary(self):
         """(launches, ms, weight bytes) of the weight-streaming (M <= 64) launches."""
@@ -631,7 +644,8 @@ def main(argv=None):
             # left other kernels, the FLOPs did not change, so `frac` pays for it)
             "by_epilogue": {k: {"launches_per_step": n, "achieved": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
                                 "share_of_step": ms / ms_per_step} for k, (n, ms, fl) in sorted(meter.fused_summary().items())},
-            "weight_streaming_gemm": {"kernel": "gemm_skinny_kernel (haff_gemm_bf16 with M <= 64: KV-cached decode steps, [SEG] MLP)",
+            "by_shape": meter.shape_summary(),
+            "weight_streaming_gemm": {"kernel": "haff_gemm_bf16 launches with M <= 64 (KV-cached decode steps, [SEG] MLP): gemm_skinny_kernel, or the split-K 128x128 tile path for wide / deep weights at 33..64 rows",
                                       "bound": "hbm", "launches_per_step": ws_n, "share_of_step": ws_ms / ms_per_step,
                                       "achieved": (ws_bytes / (ws_ms * 1e-3) / 1e9) if ws_ms > 0 else None, "peak": 8000.0,
                                       "unit": "GB/s", "algorithmic_bytes": "2*N*K (the weight matrix, read once)"},
