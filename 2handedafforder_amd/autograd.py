@@ -83,6 +83,14 @@ def colsum(x2d):
     return out
 
 
+def _mul(a, b):
+    lib = load_library()
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    check(lib.haff_mul(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _dt(a), _s()), "haff_mul")
+    return out
+
+
 def axpby(a, b, alpha, beta):
     lib = load_library()
     a = a.contiguous()
@@ -417,6 +425,98 @@ def attention(q, k, v, H, scale_, causal):
             and (q.shape[2] % 8) == 0):
         return FlashAttentionFn.apply(q, k, v, H, scale_, causal)
     return AttentionFn.apply(q, k, v, H, scale_, causal)
+
+
+class LoraQKVRopeFn(Function):
+    """The adapted q | k | v projection of one Llama layer with RoPE, as ONE autograd node (peft LoRA on q_proj / v_proj,
+    2Haff/train_ds.py:192-230; rotate-half RoPE of transformers' LlamaAttention):
+
+        q = rope(x Wq^T + s (xd Aq^T) Bq^T),  k = rope(x Wk^T),  v = x Wv^T + s (xd Av^T) Bv^T,   xd = x * keep (adapter dropout)
+
+    bf16, head dim 128, rank <= 8 (csrc/lora.hip). The rank activations are carried TRANSPOSED ([16][M]: they come out of the
+    weight-streaming product with the roles swapped, A2 as its 16 "activation rows" and the token rows as its "weights"), the
+    rank-8 updates ride in one pass over q|k|v together with RoPE, and backward needs neither transposed copies of its
+    operands nor autograd's slice adjoints: d(qkv) is assembled in one pass, dA / dB are contractions over the rows."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, wqkv_t, aq, bq, av, bv, cos_sin, T, heads, scale_, keep):
+        lib = load_library()
+        M, K = x.shape
+        H = wqkv.shape[0] // 3
+        d = H // heads
+        r = aq.shape[0]
+        dev = x.device
+        x = x.contiguous()
+        qkv = ops.linear(x, wqkv)
+        xd = x if keep is None else _mul(x, keep)
+        a2 = torch.zeros((16, K), dtype=x.dtype, device=dev)
+        a2[0:r] = aq
+        a2[8:8 + r] = av
+        b2 = torch.zeros((2, H, 8), dtype=x.dtype, device=dev)
+        b2[0, :, :r] = bq
+        b2[1, :, :r] = bv
+        Mp = _pad8(M)
+        tT = torch.zeros((16, Mp), dtype=x.dtype, device=dev)
+        ops.linear(a2, xd, out=tT[:, :M])
+        q, k, v = (torch.empty((M, H), dtype=x.dtype, device=dev) for _ in range(3))
+        check(lib.haff_lora_qkv_rope_fwd(qkv.data_ptr(), qkv.stride(0), tT.data_ptr(), Mp, b2[0].data_ptr(), b2[1].data_ptr(), 8,
+                                         cos_sin.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), H, M, H, d, int(T),
+                                         float(scale_), _s()), "haff_lora_qkv_rope_fwd")
+        ctx.save_for_backward(xd, wqkv_t, a2, b2, tT, cos_sin, keep if keep is not None else torch.empty(0, device=dev))
+        ctx.cfg = (int(T), heads, float(scale_), r)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        lib = load_library()
+        xd, wqkv_t, a2, b2, tT, cos_sin, keep = ctx.saved_tensors
+        T, heads, scale_, r = ctx.cfg
+        M, K = xd.shape
+        H = b2.shape[1]
+        d = H // heads
+        dev, dt_ = xd.device, xd.dtype
+        Mp = tT.shape[1]
+        dq, dk, dv = dq.contiguous(), dk.contiguous(), dv.contiguous()
+        dqkv = torch.empty((M, 3 * H), dtype=dt_, device=dev)
+        check(lib.haff_lora_qkv_rope_bwd(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), H, cos_sin.data_ptr(), dqkv.data_ptr(), 3 * H,
+                                         M, H, d, T, _s()), "haff_lora_qkv_rope_bwd")
+        # dt^T [16][M] = B^T . d(q|v)^T: the weight-streaming product again, the gradient rows as its "weights"
+        b2t = b2.transpose(1, 2).contiguous()   # [2][8][H]
+        dtT = torch.zeros((16, Mp), dtype=dt_, device=dev)
+        ops.linear(b2t[0], dqkv[:, :H], out=dtT[0:8, :M])
+        ops.linear(b2t[1], dqkv[:, 2 * H:], out=dtT[8:16, :M])
+
+        def tn(sT, R, big, n, out, transposed, j_valid):
+            n_ws = lib.haff_lora_tn_workspace_elems(M, R, n)
+            assert n_ws > 0
+            ws = torch.empty((n_ws,), dtype=torch.float32, device=dev)
+            check(lib.haff_lora_tn(sT.data_ptr(), Mp, R, big.data_ptr(), big.stride(0), M, n, ws.data_ptr(), ws.numel(),
+                                   out.data_ptr(), out.stride(0), 1 if out.dtype == torch.float32 else 0, 1 if transposed else 0,
+                                   j_valid, scale_, _s()), "haff_lora_tn")
+            return out
+
+        dbq = tn(tT[0:8], 8, dqkv[:, :H], H, torch.empty((H, r), dtype=dt_, device=dev), True, r)
+        dbv = tn(tT[8:16], 8, dqkv[:, 2 * H:], H, torch.empty((H, r), dtype=dt_, device=dev), True, r)
+        da2 = tn(dtT, 16, xd, K, torch.empty((16, K), dtype=dt_, device=dev), False, 16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(dqkv, wqkv_t)
+            check(lib.haff_lora_dx(dtT.data_ptr(), Mp, a2.data_ptr(), K, keep.data_ptr() if keep.numel() else 0, K, dx.data_ptr(),
+                                   dx.stride(0), 1, M, K, scale_, _s()), "haff_lora_dx")
+        return dx, None, None, da2[0:r], dbq, da2[8:8 + r], dbv, None, None, None, None, None
+
+
+def lora_qkv_rope_supported(x, wqkv, aq, heads):
+    H = wqkv.shape[0] // 3
+    return (x.dtype == torch.bfloat16 and H % heads == 0 and H // heads == 128 and aq.shape[0] <= 8 and x.shape[1] % 128 == 0
+            and x.shape[0] >= 16)
+
+
+FUSED_LORA_QKV = True   # False: the adapters run as separate LinearFn / scale / add / rope nodes (A/B, tests)
+
+
+def lora_qkv_rope(x, wqkv, wqkv_t, aq, bq, av, bv, cos_sin, T, heads, scale_, keep=None):
+    return LoraQKVRopeFn.apply(x, wqkv, wqkv_t, aq, bq, av, bv, cos_sin, T, heads, scale_, keep)
 
 
 class BgemmFn(Function):

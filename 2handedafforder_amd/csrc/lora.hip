@@ -1,0 +1,359 @@
+// Rank-r adapter kernels of the LoRA fine-tune path (reference: peft LoraConfig on q_proj / v_proj, 2Haff/train_ds.py:192-230;
+// the adapted projections feed LlamaAttention's rotate-half RoPE, model/llava/model/language_model/llava_llama.py:76-101).
+//
+//   forward    q = rope(x.Wq^T + s.(x.Aq^T).Bq^T),  k = rope(x.Wk^T),  v = x.Wv^T + s.(x.Av^T).Bv^T
+//
+// The frozen product x.[Wq;Wk;Wv]^T is the tile GEMM's; everything a rank-8 update adds is HBM-bound row traffic, and the
+// generic route (four N = 8 / K = 8 products on the 128 x 128 tile, scale, add, two RoPE passes, and in backward three
+// transposes per dW plus the zero-fill / copy / add chain of autograd's slice adjoints) cost ~0.9 ms per Llama layer and
+// step — 14 % of the configs[3] step. Here:
+//   * t^T = A2.x^T [16][M] (A2 = [Aq; Av]) is ONE weight-streaming launch of gemm_bf16.hip with the roles swapped (the
+//     activation rows are the streamed operand);
+//   * lora_qkv_rope_fwd_kernel reads q|k|v once, adds the rank-r update with one 75 %-empty MFMA per 16 x 16 tile (k = the
+//     adapter index: the matrix pipe is idle on this path anyway), rotates q and k, writes the three attention operands;
+//   * lora_qkv_rope_bwd_kernel assembles d(qkv) = [rope^T dq | rope^T dk | dv] in one pass (no slice adjoints);
+//   * dt^T = B^T.dq^T is again the swapped weight-streaming product; lora_dx_kernel adds s.keep.(dt.A2) into the d(x) the
+//     frozen product's adjoint wrote; lora_tn_kernel is the one contraction over ROWS (dA = dt^T.x, dB = dq^T.t): rank rows
+//     in SGPRs, the big operand streamed once, per-row-block partials summed in index order (no atomics, deterministic).
+// bf16 storage, fp32 arithmetic, head dim 128, rank <= 8 per adapter.
+#include "haff_common.h"
+
+namespace {
+
+constexpr int HD = 128;   // head dim (Llama 7B / 13B)
+
+__device__ __forceinline__ bf16x8 zero_frag() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// the 16 x 32 operand tile of t (rows = activation rows row0.., k = adapter index 0..15, 16..31 empty) out of t^T [16][ldt]
+__device__ __forceinline__ bf16x8 load_t_frag(const bf16_t* tT, long ldt, long row, int fh) {
+  bf16x8 f = zero_frag();
+  if (fh < 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (short)tT[(long)(8 * fh + i) * ldt + row];
+  }
+  return f;
+}
+
+struct LoraFwdArgs {
+  const bf16_t* qkv; long ld_qkv;
+  const bf16_t* tT; long ldt;
+  const bf16_t *Bq, *Bv; int ldb;
+  const float* cs;
+  bf16_t *qo, *ko, *vo; long ldo;
+  long M; int H, T; float scale;
+};
+
+// one wave = one head (128 columns: tiles c = 0..3 hold columns 16c.., tiles 4..7 their rotate-half partners +64) x 16-row
+// tiles; lane (fr, fh) owns row fr, columns 4fh..4fh+3 of every tile — the MFMA's output layout with the COLUMN operand first
+__global__ __launch_bounds__(256, 3) void lora_qkv_rope_fwd_kernel(LoraFwdArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fh = lane >> 4;
+  const int head = blockIdx.x;
+  const long n_rt = (p.M + 15) / 16;
+  bf16x8 bq[8], bv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const long col = (long)head * HD + 16 * c + fr;
+    bq[c] = fh == 0 ? *reinterpret_cast<const bf16x8*>(p.Bq + col * p.ldb) : zero_frag();
+    bv[c] = fh == 1 ? *reinterpret_cast<const bf16x8*>(p.Bv + col * p.ldb) : zero_frag();
+  }
+  for (long rt = (long)blockIdx.y * 4 + wave; rt < n_rt; rt += (long)gridDim.y * 4) {
+    const long row = rt * 16 + fr;
+    const bool valid = row < p.M;
+    const long rc = valid ? row : p.M - 1;
+    const int pos = (int)(rc % p.T);
+    const bf16x8 tt = load_t_frag(p.tT, p.ldt, rc, fh);
+    const bf16_t* src = p.qkv + rc * p.ld_qkv + (long)head * HD + 4 * fh;
+    bf16_t* dq_o = p.qo + rc * p.ldo + (long)head * HD + 4 * fh;
+    bf16_t* dk_o = p.ko + rc * p.ldo + (long)head * HD + 4 * fh;
+    bf16_t* dv_o = p.vo + rc * p.ldo + (long)head * HD + 4 * fh;
+    auto unpack = [](const uint2& r, float (&v)[4]) {
+      v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+      v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // column tile c and its rotate-half partner c + 4
+      const uint2 rq0 = *reinterpret_cast<const uint2*>(src + 16 * c), rq1 = *reinterpret_cast<const uint2*>(src + 64 + 16 * c);
+      const uint2 rk0 = *reinterpret_cast<const uint2*>(src + p.H + 16 * c), rk1 = *reinterpret_cast<const uint2*>(src + p.H + 64 + 16 * c);
+      const uint2 rv0 = *reinterpret_cast<const uint2*>(src + 2 * (long)p.H + 16 * c);
+      const uint2 rv1 = *reinterpret_cast<const uint2*>(src + 2 * (long)p.H + 64 + 16 * c);
+      const float4 co = *reinterpret_cast<const float4*>(p.cs + (long)pos * HD + 16 * c + 4 * fh);
+      const float4 si = *reinterpret_cast<const float4*>(p.cs + (long)pos * HD + 64 + 16 * c + 4 * fh);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[c], tt, z, 0, 0, 0);
+      const f32x4 dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[c + 4], tt, z, 0, 0, 0);
+      const f32x4 dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[c], tt, z, 0, 0, 0);
+      const f32x4 dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[c + 4], tt, z, 0, 0, 0);
+      float qa[4], qb[4], ka[4], kb[4], va[4], vb[4];
+      unpack(rq0, qa); unpack(rq1, qb);
+      unpack(rk0, ka); unpack(rk1, kb);
+      unpack(rv0, va); unpack(rv1, vb);
+      const float cc[4] = {co.x, co.y, co.z, co.w}, ss[4] = {si.x, si.y, si.z, si.w};
+      float q1[4], q2[4], k1[4], k2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ql = qa[r] + p.scale * dq0[r], qh = qb[r] + p.scale * dq1[r];
+        q1[r] = ql * cc[r] - qh * ss[r];
+        q2[r] = qh * cc[r] + ql * ss[r];
+        k1[r] = ka[r] * cc[r] - kb[r] * ss[r];
+        k2[r] = kb[r] * cc[r] + ka[r] * ss[r];
+        va[r] += p.scale * dv0[r];
+        vb[r] += p.scale * dv1[r];
+      }
+      if (valid) {
+        store4(dq_o + 16 * c, q1); store4(dq_o + 64 + 16 * c, q2);
+        store4(dk_o + 16 * c, k1); store4(dk_o + 64 + 16 * c, k2);
+        store4(dv_o + 16 * c, va); store4(dv_o + 64 + 16 * c, vb);
+      }
+    }
+  }
+}
+
+// d(qkv) [M][3H] = [rope^T dq | rope^T dk | dv]: thread = (row, head, 8 low columns + their partners)
+__global__ __launch_bounds__(256) void lora_qkv_rope_bwd_kernel(const bf16_t* dq, const bf16_t* dk, const bf16_t* dv, long ld_in,
+                                                              const float* cs, bf16_t* dqkv, long ld_out, long M, int H, int T) {
+  const int nh = H / HD;
+  const long total = M * nh * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i & 7);
+    const int head = (int)((i >> 3) % nh);
+    const long row = (i >> 3) / nh;
+    const int pos = (int)(row % T);
+    const long col = (long)head * HD + 8 * ch;
+    float co[8], si[8];
+    load8(cs + (long)pos * HD + 8 * ch, co);
+    load8(cs + (long)pos * HD + 64 + 8 * ch, si);
+    float a[8], b[8], x1[8], x2[8];
+    load8(dq + row * ld_in + col, a);
+    load8(dq + row * ld_in + col + 64, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x1[e] = a[e] * co[e] + b[e] * si[e]; x2[e] = b[e] * co[e] - a[e] * si[e]; }
+    store8(dqkv + row * ld_out + col, x1);
+    store8(dqkv + row * ld_out + col + 64, x2);
+    load8(dk + row * ld_in + col, a);
+    load8(dk + row * ld_in + col + 64, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x1[e] = a[e] * co[e] + b[e] * si[e]; x2[e] = b[e] * co[e] - a[e] * si[e]; }
+    store8(dqkv + row * ld_out + H + col, x1);
+    store8(dqkv + row * ld_out + H + col + 64, x2);
+    *reinterpret_cast<uint4*>(dqkv + row * ld_out + 2 * (long)H + col) = *reinterpret_cast<const uint4*>(dv + row * ld_in + col);
+    *reinterpret_cast<uint4*>(dqkv + row * ld_out + 2 * (long)H + col + 64) = *reinterpret_cast<const uint4*>(dv + row * ld_in + col + 64);
+  }
+}
+
+// dx[row][col] (+)= scale * keep[row][col] * sum_j dt[row][j] * A2[j][col]: wave = 128 columns x 16-row tiles
+struct LoraDxArgs {
+  const bf16_t* dtT; long ldt;
+  const bf16_t* A2; long lda;
+  const bf16_t* keep; long ldk;
+  bf16_t* dx; long ldx;
+  long M; int K; int accumulate; float scale;
+};
+__global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fh = lane >> 4;
+  const long c0 = (long)blockIdx.x * 128;
+  const long n_rt = (p.M + 15) / 16;
+  bf16x8 af[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    af[c] = zero_frag();
+    if (fh < 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[c][i] = (short)p.A2[(long)(8 * fh + i) * p.lda + c0 + 16 * c + fr];
+    }
+  }
+  for (long rt = (long)blockIdx.y * 4 + wave; rt < n_rt; rt += (long)gridDim.y * 4) {
+    const long row = rt * 16 + fr;
+    const bool valid = row < p.M;
+    const long rc = valid ? row : p.M - 1;
+    const bf16x8 tt = load_t_frag(p.dtT, p.ldt, rc, fh);
+    uint2 old[8], kp[8];
+    bf16_t* dst = p.dx + rc * p.ldx + c0 + 4 * fh;
+    if (p.accumulate) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) old[c] = *reinterpret_cast<const uint2*>(dst + 16 * c);
+    }
+    if (p.keep) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kp[c] = *reinterpret_cast<const uint2*>(p.keep + rc * p.ldk + c0 + 4 * fh + 16 * c);
+    }
+    f32x4 d[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], tt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    if (!valid) continue;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float v[4] = {p.scale * d[c][0], p.scale * d[c][1], p.scale * d[c][2], p.scale * d[c][3]};
+      if (p.keep) {
+        v[0] *= __uint_as_float(kp[c].x << 16); v[1] *= __uint_as_float(kp[c].x & 0xffff0000u);
+        v[2] *= __uint_as_float(kp[c].y << 16); v[3] *= __uint_as_float(kp[c].y & 0xffff0000u);
+      }
+      if (p.accumulate) {
+        v[0] += __uint_as_float(old[c].x << 16); v[1] += __uint_as_float(old[c].x & 0xffff0000u);
+        v[2] += __uint_as_float(old[c].y << 16); v[3] += __uint_as_float(old[c].y & 0xffff0000u);
+      }
+      store4(dst + 16 * c, v);
+    }
+  }
+}
+
+// part[rb][j][n] = sum over the row block's rows m of sT[j][m] * big[m][n]: workgroup = 128 columns (2 per lane) x one row
+// block; its 4 waves take 8-row groups in turn (the R x 8 rank values of a group are wave-uniform: scalar loads), and meet in
+// LDS in wave order
+template <int R>
+__global__ __launch_bounds__(256) void lora_tn_kernel(const bf16_t* sT, long lds, const bf16_t* big, long ldb, long M, int N,
+                                                      int rows_per_block, float* part) {
+  __shared__ float red[4][R][128];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long col = (long)blockIdx.x * 128 + 2 * lane;
+  const bool col_ok = col < N;   // N % 2 == 0 (checked by the launcher)
+  const long r_lo = (long)blockIdx.y * rows_per_block;
+  long r_hi = r_lo + rows_per_block;
+  if (r_hi > M) r_hi = M;
+  float acc[R][2];
+#pragma unroll
+  for (int j = 0; j < R; ++j) acc[j][0] = acc[j][1] = 0.f;
+  for (long m0 = r_lo + 8 * wave; m0 < r_hi; m0 += 32) {   // r_lo % 8 == 0, lds % 8 == 0: 16-B aligned rank rows
+    unsigned bw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long m = m0 + i;
+      bw[i] = (col_ok && m < r_hi) ? *reinterpret_cast<const unsigned*>(big + m * ldb + col) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint4 sv = *reinterpret_cast<const uint4*>(sT + (long)j * lds + m0);
+      const unsigned sw[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned h = (i & 1) ? (sw[i >> 1] & 0xffff0000u) : (sw[i >> 1] << 16);
+        const float s = (m0 + i < r_hi) ? __uint_as_float(h) : 0.f;
+        acc[j][0] = fmaf(s, __uint_as_float(bw[i] << 16), acc[j][0]);
+        acc[j][1] = fmaf(s, __uint_as_float(bw[i] & 0xffff0000u), acc[j][1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    red[wave][j][2 * lane] = acc[j][0];
+    red[wave][j][2 * lane + 1] = acc[j][1];
+  }
+  __syncthreads();
+  float* dst = part + (long)blockIdx.y * R * N;
+  for (int e = threadIdx.x; e < R * 128; e += 256) {
+    const int j = e >> 7, c = e & 127;
+    const long n = (long)blockIdx.x * 128 + c;
+    if (n < N) dst[(long)j * N + n] = ((red[0][j][c] + red[1][j][c]) + red[2][j][c]) + red[3][j][c];
+  }
+}
+
+// out = scale * sum over row blocks (index order) of part[rb][j][n]; rows j < j_valid only; [j][n] or transposed [n][j]
+template <typename TO>
+__global__ void lora_tn_reduce_kernel(const float* part, int nrb, int R, int N, TO* out, long ldo, int transposed, int j_valid,
+                                      float scale) {
+  const long total = (long)j_valid * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / N);
+    const long n = i - (long)j * N;
+    float s = 0.f;
+    for (int rb = 0; rb < nrb; ++rb) s += part[((long)rb * R + j) * N + n];
+    s *= scale;
+    elem<TO>::st(transposed ? out + n * ldo + j : out + (long)j * ldo + n, s);
+  }
+}
+
+inline hipStream_t HS(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int check_launch() { return hipGetLastError() == hipSuccess ? HAFF_OK : HAFF_ERR_LAUNCH; }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+}  // namespace
+
+extern "C" int haff_lora_qkv_rope_fwd(const void* qkv, long ld_qkv, const void* tT, long ldt, const void* Bq, const void* Bv,
+                                      int ldb, const float* cos_sin, void* q_out, void* k_out, void* v_out, long ldo, long M,
+                                      int H, int d, int T, float scale, void* stream) {
+  if (M <= 0 || T <= 0 || H <= 0 || !qkv || !tT || !Bq || !Bv || !cos_sin || !q_out || !k_out || !v_out) return HAFF_ERR_BAD_ARG;
+  if (d != HD || H % HD || ldb != 8) return HAFF_ERR_UNSUPPORTED;
+  if (ld_qkv < 3L * H || ldo < H || ldt < M || (ld_qkv & 3) || (ldo & 3)) return HAFF_ERR_BAD_ARG;
+  if (!al8(qkv) || !al16(Bq) || !al16(Bv) || !al16(cos_sin) || !al8(q_out) || !al8(k_out) || !al8(v_out)) return HAFF_ERR_BAD_ARG;
+  LoraFwdArgs p{(const bf16_t*)qkv, ld_qkv, (const bf16_t*)tT, ldt, (const bf16_t*)Bq, (const bf16_t*)Bv, ldb, cos_sin,
+                (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)v_out, ldo, M, H, T, scale};
+  const long n_rt = (M + 15) / 16;
+  long gy = (n_rt + 3) / 4;
+  const int nh = H / HD;
+  const long cap = (2048 + nh - 1) / nh;   // ~2048 workgroups: 8 per CU
+  if (gy > cap) gy = cap;
+  hipLaunchKernelGGL(lora_qkv_rope_fwd_kernel, dim3(nh, (unsigned)gy), dim3(256), 0, HS(stream), p);
+  return check_launch();
+}
+
+extern "C" int haff_lora_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, long ld_in, const float* cos_sin, void* dqkv,
+                                      long ld_out, long M, int H, int d, int T, void* stream) {
+  if (M <= 0 || T <= 0 || H <= 0 || !dq || !dk || !dv || !cos_sin || !dqkv) return HAFF_ERR_BAD_ARG;
+  if (d != HD || H % HD) return HAFF_ERR_UNSUPPORTED;
+  if (ld_in < H || ld_out < 3L * H || (ld_in & 7) || (ld_out & 7)) return HAFF_ERR_BAD_ARG;
+  if (!al16(dq) || !al16(dk) || !al16(dv) || !al16(cos_sin) || !al16(dqkv)) return HAFF_ERR_BAD_ARG;
+  const long total = M * (H / HD) * 8;
+  long g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(lora_qkv_rope_bwd_kernel, dim3((unsigned)g), dim3(256), 0, HS(stream), (const bf16_t*)dq, (const bf16_t*)dk,
+                     (const bf16_t*)dv, ld_in, cos_sin, (bf16_t*)dqkv, ld_out, M, H, T);
+  return check_launch();
+}
+
+extern "C" int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda, const void* keep, long ldk, void* dx, long ldx,
+                            int accumulate, long M, int K, float scale, void* stream) {
+  if (M <= 0 || K <= 0 || !dtT || !A2 || !dx) return HAFF_ERR_BAD_ARG;
+  if (K % 128) return HAFF_ERR_UNSUPPORTED;
+  if (ldt < M || lda < K || ldx < K || (ldx & 3) || (keep && (ldk < K || (ldk & 3)))) return HAFF_ERR_BAD_ARG;
+  if (!al8(dx) || (keep && !al8(keep))) return HAFF_ERR_BAD_ARG;
+  LoraDxArgs p{(const bf16_t*)dtT, ldt, (const bf16_t*)A2, lda, (const bf16_t*)keep, ldk, (bf16_t*)dx, ldx, M, K, accumulate, scale};
+  const long n_rt = (M + 15) / 16;
+  long gy = (n_rt + 3) / 4;
+  const int gx = K / 128;
+  const long cap = (2048 + gx - 1) / gx;
+  if (gy > cap) gy = cap;
+  hipLaunchKernelGGL(lora_dx_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, HS(stream), p);
+  return check_launch();
+}
+
+// rows per block of haff_lora_tn (multiple of 32): ~16 row blocks
+static long lora_tn_rows_per_block(long M) {
+  long rpb = ((M + 15) / 16 + 31) / 32 * 32;
+  return rpb < 32 ? 32 : rpb;
+}
+static long lora_tn_ws(long M, int R, int N) {
+  const long rpb = lora_tn_rows_per_block(M);
+  return ((M + rpb - 1) / rpb) * (long)R * N;
+}
+extern "C" int haff_lora_tn_workspace_elems(long M, int R, int N) {   // f32 values haff_lora_tn wants; < 0: does not fit an int
+  const long n = (M > 0 && R > 0 && N > 0) ? lora_tn_ws(M, R, N) : -1;
+  return n > 0x7fffffffL ? HAFF_ERR_UNSUPPORTED : (int)n;
+}
+extern "C" int haff_lora_tn(const void* sT, long lds, int R, const void* big, long ldb, long M, int N, float* workspace,
+                            long workspace_elems, void* out, long ldo, int out_f32, int transposed, int j_valid, float scale,
+                            void* stream) {
+  if (M <= 0 || N <= 0 || !sT || !big || !workspace || !out || j_valid <= 0 || j_valid > R) return HAFF_ERR_BAD_ARG;
+  if (R != 8 && R != 16) return HAFF_ERR_UNSUPPORTED;
+  if ((lds & 7) || lds < (M + 7) / 8 * 8 || !al16(sT) || (N & 1) || (ldb & 1) || ldb < N || (reinterpret_cast<uintptr_t>(big) & 3))
+    return HAFF_ERR_BAD_ARG;
+  if (workspace_elems < lora_tn_ws(M, R, N)) return HAFF_ERR_BAD_ARG;
+  if (ldo < (transposed ? j_valid : N)) return HAFF_ERR_BAD_ARG;
+  const long rpb = lora_tn_rows_per_block(M);
+  const int nrb = (int)((M + rpb - 1) / rpb);
+  const dim3 g((N + 127) / 128, nrb), b(256);
+  if (R == 8)
+    hipLaunchKernelGGL((lora_tn_kernel<8>), g, b, 0, HS(stream), (const bf16_t*)sT, lds, (const bf16_t*)big, ldb, M, N, (int)rpb, workspace);
+  else
+    hipLaunchKernelGGL((lora_tn_kernel<16>), g, b, 0, HS(stream), (const bf16_t*)sT, lds, (const bf16_t*)big, ldb, M, N, (int)rpb, workspace);
+  const long total = (long)j_valid * N;
+  long gr = (total + 255) / 256;
+  if (gr > 4096) gr = 4096;
+  if (out_f32)
+    hipLaunchKernelGGL((lora_tn_reduce_kernel<float>), dim3((unsigned)gr), b, 0, HS(stream), workspace, nrb, R, N, (float*)out, ldo, transposed, j_valid, scale);
+  else
+    hipLaunchKernelGGL((lora_tn_reduce_kernel<bf16_t>), dim3((unsigned)gr), b, 0, HS(stream), workspace, nrb, R, N, (bf16_t*)out, ldo, transposed, j_valid, scale);
+  return check_launch();
+}

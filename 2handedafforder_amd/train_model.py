@@ -105,19 +105,24 @@ class LisaTrainable:
         for i, L in enumerate(llm.layers):
             wt = self.wt[i]
             h = A.rmsnorm(x, L["n1"], l.rms_eps)
-            qkv = A.linear(h, L["wqkv"], None, None, wt["wqkv"])
-            hl = h
+            pre = f"model.layers.{i}.self_attn."
+            keep = None
             if self.training and self.lora_dropout > 0:
                 keep = (torch.rand(h.shape, device=h.device) >= self.lora_dropout).to(h.dtype) / (1 - self.lora_dropout)
-                hl = DropoutMul.apply(h, keep)
-            pre = f"model.layers.{i}.self_attn."
-            dq = A.linear(A.linear(hl, P[pre + "q_proj.lora_A"]), _pad_k(P[pre + "q_proj.lora_B"]))
-            dv = A.linear(A.linear(hl, P[pre + "v_proj.lora_A"]), _pad_k(P[pre + "v_proj.lora_B"]))
-            q = A.add(qkv[:, :H], A.scale(dq, self.lora_scale))
-            k = qkv[:, H:2 * H]
-            v = A.add(qkv[:, 2 * H:], A.scale(dv, self.lora_scale))
-            q = A.rope(q, cs, T, nh, hd)
-            k = A.rope(k, cs, T, nh, hd)
+            if A.FUSED_LORA_QKV and A.lora_qkv_rope_supported(h, L["wqkv"], P[pre + "q_proj.lora_A"], nh):
+                # one node: q|k|v product, both rank-r updates, RoPE (csrc/lora.hip)
+                q, k, v = A.lora_qkv_rope(h, L["wqkv"], wt["wqkv"], P[pre + "q_proj.lora_A"], P[pre + "q_proj.lora_B"],
+                                          P[pre + "v_proj.lora_A"], P[pre + "v_proj.lora_B"], cs, T, nh, self.lora_scale, keep)
+            else:
+                qkv = A.linear(h, L["wqkv"], None, None, wt["wqkv"])
+                hl = h if keep is None else DropoutMul.apply(h, keep)
+                dq = A.linear(A.linear(hl, P[pre + "q_proj.lora_A"]), _pad_k(P[pre + "q_proj.lora_B"]))
+                dv = A.linear(A.linear(hl, P[pre + "v_proj.lora_A"]), _pad_k(P[pre + "v_proj.lora_B"]))
+                q = A.add(qkv[:, :H], A.scale(dq, self.lora_scale))
+                k = qkv[:, H:2 * H]
+                v = A.add(qkv[:, 2 * H:], A.scale(dv, self.lora_scale))
+                q = A.rope(q, cs, T, nh, hd)
+                k = A.rope(k, cs, T, nh, hd)
             a = A.attention(q.view(B, T, H), k.view(B, T, H), v.view(B, T, H), nh, hd ** -0.5, True)
             x = A.linear(a.view(B * T, H), L["wo"], None, x, wt["wo"])
             h = A.rmsnorm(x, L["n2"], l.rms_eps)

@@ -425,6 +425,9 @@ def train_main(args):
     if args.materialised_attention:
         from haff import autograd as hag
         hag.FLASH_TRAINING_ATTENTION = False
+    if args.separate_lora:
+        from haff import autograd as hag
+        hag.FUSED_LORA_QKV = False
     rank, world, local_rank = hdist.init_from_env("nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -540,6 +543,8 @@ def main(argv=None):
                     help="infer: BASELINE configs[2] (the headline metric); train: configs[3], one LoRA fine-tune step per step")
     ap.add_argument("--materialised-attention", action="store_true",
                     help="--mode train: the Llama self-attention with probabilities in HBM (batched products + softmax kernels) instead of the flash pair (A/B)")
+    ap.add_argument("--separate-lora", action="store_true",
+                    help="--mode train: the q / v adapters as separate product / scale / add / RoPE nodes instead of the fused node of csrc/lora.hip (A/B)")
     ap.add_argument("--train-ids", type=int, default=96)
     ap.add_argument("--train-mask", type=int, default=1024)
     ap.add_argument("--stub-step-ms", type=float, default=None,

@@ -143,6 +143,28 @@ int haff_attention_bwd_bf16(const void* q, const void* k, const void* v, const v
                             void* dq, void* dk, void* dv, float* workspace, long workspace_elems, long ld, int B, int H, int Nq,
                             int Nk, int d, float scale, int causal, int q_pos0, void* stream);
 
+/* rank-r adapter path of the fine-tune step (peft LoRA on q_proj / v_proj: 2Haff/train_ds.py:192-230; RoPE of the adapted
+ * projections: llava_llama.py -> transformers LlamaAttention). bf16, head dim d == 128, rank <= 8 per adapter; see csrc/lora.hip.
+ * tT / dtT: [16][ld] = the TRANSPOSED rank activations, rows 0..7 the q adapter, 8..15 the v adapter (unused ranks zero);
+ * Bq / Bv: [H][8] (ldb == 8, unused rank columns zero); A2: [16][K] = [Aq; 0; Av; 0]; cos_sin f32 [T][128], position = row % T.
+ * haff_lora_qkv_rope_fwd: q_out = rope(qkv[:, :H] + scale * t_q.Bq^T), k_out = rope(qkv[:, H:2H]), v_out = qkv[:, 2H:] + scale * t_v.Bv^T
+ * haff_lora_qkv_rope_bwd: dqkv [M][3H] = [rope^T dq | rope^T dk | dv] (the adjoint of the q|k|v product's output)
+ * haff_lora_dx:           dx (+)= scale * keep .* (dt . A2)   (keep: optional dropout mask values [M][K])
+ * haff_lora_tn:           out = scale * sT . big  (sT [R][lds] with R = 8 or 16, lds % 8 == 0, padding finite; big [M][N]; contraction over the M
+ *                         rows; out [j_valid][N] or, transposed, [N][j_valid], bf16 or f32) — the dA / dB contraction without a
+ *                         transposed copy of either operand; workspace f32 with haff_lora_tn_workspace_elems values;
+ *                         row-block partials are added in index order (deterministic). */
+int haff_lora_qkv_rope_fwd(const void* qkv, long ld_qkv, const void* tT, long ldt, const void* Bq, const void* Bv, int ldb,
+                           const float* cos_sin, void* q_out, void* k_out, void* v_out, long ldo, long M, int H, int d, int T,
+                           float scale, void* stream);
+int haff_lora_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, long ld_in, const float* cos_sin, void* dqkv,
+                           long ld_out, long M, int H, int d, int T, void* stream);
+int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda, const void* keep, long ldk, void* dx, long ldx,
+                 int accumulate, long M, int K, float scale, void* stream);
+int haff_lora_tn_workspace_elems(long M, int R, int N);
+int haff_lora_tn(const void* sT, long lds, int R, const void* big, long ldb, long M, int N, float* workspace,
+                 long workspace_elems, void* out, long ldo, int out_f32, int transposed, int j_valid, float scale, void* stream);
+
 /* fused SAM WINDOW attention with the decomposed rel-pos bias computed in the kernel (one pass over HBM; replaces
  * haff_relpos_tables_bf16 + haff_attention_bf16 for the 28 windowed ViT-H blocks): Attention.forward
  * (image_encoder.py:235-260) + add_decomposed_rel_pos (:354-392) + get_rel_pos with q_size == k_size (:322-351).

@@ -178,6 +178,90 @@ def test_flash_attention_fn(dev, B, H, Nq, Nk, causal):
     assert torch.equal(q2.grad, q.grad) and torch.equal(k2.grad, k.grad) and torch.equal(v2.grad, v.grad)
 
 
+@pytest.mark.parametrize("B,T,heads,K,r,drop", [(2, 37, 2, 256, 8, False), (3, 50, 3, 384, 8, True), (1, 129, 2, 256, 4, True),
+                                                (2, 16, 1, 128, 1, False)])
+def test_lora_qkv_rope_fn(dev, B, T, heads, K, r, drop):
+    """The adapted q|k|v projection + RoPE as one node (csrc/lora.hip: haff_lora_qkv_rope_fwd / _bwd, haff_lora_dx, haff_lora_tn
+    and the role-swapped weight-streaming products) against (1) fp32 torch autograd of the definition (peft LoRA on q_proj /
+    v_proj with a shared dropout mask, rotate-half RoPE) and (2) the chain of separate nodes it replaces; row counts that
+    are not multiples of 16 or 8, ranks below 8 (zero-padded adapters), with and without the dropout mask; repeatable to the bit."""
+    A = _ag()
+    dtype, d = torch.bfloat16, 128
+    H, M = heads * d, B * T
+    scale = 16.0 / r
+    x = _leaf(_rand((M, K), dev, dtype, 50))
+    w = _rand((3 * H, K), dev, dtype, 51, K ** -0.5)
+    wt = A.transpose(w)[0]
+    aq, av = (_leaf(_rand((r, K), dev, dtype, s_, K ** -0.5)) for s_ in (52, 53))
+    bq, bv = (_leaf(_rand((H, r), dev, dtype, s_, 0.3)) for s_ in (54, 55))
+    keep = None
+    if drop:
+        g = torch.Generator(device="cpu").manual_seed(56)
+        keep = ((torch.rand((M, K), generator=g) >= 0.25).float() / 0.75).to(dtype).to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    ang = torch.arange(T + 3, dtype=torch.float32)[:, None] * inv[None, :]
+    cs = torch.cat([ang.cos(), ang.sin()], 1).contiguous().to(dev)
+    gq, gk, gv = (_rand((M, H), dev, dtype, s_) for s_ in (57, 58, 59))
+    assert A.lora_qkv_rope_supported(x, w, aq, heads)
+    q, k, v = A.lora_qkv_rope(x, w, wt, aq, bq, av, bv, cs, T, heads, scale, keep)
+    assert "LoraQKVRope" in type(q.grad_fn).__name__
+    torch.autograd.backward([q, k, v], [gq, gk, gv])
+
+    # (1) the definition in fp32
+    def rope(t):
+        t4 = t.view(B, T, heads, d)
+        co, si = cs[:T, :d // 2].view(1, T, 1, d // 2), cs[:T, d // 2:].view(1, T, 1, d // 2)
+        t1, t2 = t4[..., :d // 2], t4[..., d // 2:]
+        return torch.cat([t1 * co - t2 * si, t2 * co + t1 * si], -1).reshape(M, H)
+
+    xr, aqr, avr, bqr, bvr = (_leaf(t.detach().float()) for t in (x, aq, av, bq, bv))
+    xd = xr if keep is None else xr * keep.float()
+    qkv = xr @ w.float().t()
+    qr = rope(qkv[:, :H] + scale * (xd @ aqr.t()) @ bqr.t())
+    kr = rope(qkv[:, H:2 * H])
+    vr = qkv[:, 2 * H:] + scale * (xd @ avr.t()) @ bvr.t()
+    torch.autograd.backward([qr, kr, vr], [gq.float(), gk.float(), gv.float()])
+    for got, ref, what in ((q, qr, "q"), (k, kr, "k"), (v, vr, "v"), (x.grad, xr.grad, "dx"), (aq.grad, aqr.grad, "dAq"),
+                           (av.grad, avr.grad, "dAv"), (bq.grad, bqr.grad, "dBq"), (bv.grad, bvr.grad, "dBv")):
+        assert got.shape == ref.shape, what
+        _close(got, ref, 3e-2, f"fused lora {what} vs fp32 autograd")
+    # (2) the separate nodes on the same inputs
+    xs, aqs, avs, bqs, bvs = (_leaf(t.detach()) for t in (x, aq, av, bq, bv))
+
+    def padk(b_):
+        if b_.shape[1] % 8 == 0:
+            return b_
+        return torch.cat([b_, torch.zeros((b_.shape[0], 8 - b_.shape[1] % 8), dtype=b_.dtype, device=b_.device)], 1)
+
+    def pada(a_):   # rank rows padded to 8 so that the next product's K is a multiple of 8
+        if a_.shape[0] % 8 == 0:
+            return a_
+        return torch.cat([a_, torch.zeros((8 - a_.shape[0] % 8, a_.shape[1]), dtype=a_.dtype, device=a_.device)], 0)
+
+    qkvs = A.linear(xs, w, None, None, wt)
+    hl = xs if keep is None else xs * keep
+    qs = A.rope(A.add(qkvs[:, :H], A.scale(A.linear(A.linear(hl, pada(aqs)), padk(bqs)), scale)), cs, T, heads, d)
+    ks = A.rope(qkvs[:, H:2 * H], cs, T, heads, d)
+    vs = A.add(qkvs[:, 2 * H:], A.scale(A.linear(A.linear(hl, pada(avs)), padk(bvs)), scale))
+    torch.autograd.backward([qs, ks, vs], [gq, gk, gv])
+    for got, ref, what in ((q, qs, "q"), (k, ks, "k"), (v, vs, "v"), (x.grad, xs.grad, "dx"), (aq.grad, aqs.grad, "dAq"),
+                           (av.grad, avs.grad, "dAv"), (bq.grad, bqs.grad, "dBq"), (bv.grad, bvs.grad, "dBv")):
+        _close(got, ref, 3e-2, f"fused lora {what} vs separate nodes")
+    # the fused node is no further from fp32 than the chain it replaces
+    pairs_f = ((x.grad, xr.grad), (aq.grad, aqr.grad), (bq.grad, bqr.grad), (av.grad, avr.grad), (bv.grad, bvr.grad))
+    pairs_s = ((xs.grad, xr.grad), (aqs.grad, aqr.grad), (bqs.grad, bqr.grad), (avs.grad, avr.grad), (bvs.grad, bvr.grad))
+    e_f = sum(((g_.float() - r_).abs().mean() / r_.abs().mean()).item() for g_, r_ in pairs_f)
+    e_s = sum(((g_.float() - r_).abs().mean() / r_.abs().mean()).item() for g_, r_ in pairs_s)
+    assert e_f <= 1.25 * e_s, (e_f, e_s)
+    # repeatable to the bit
+    x2, aq2, av2, bq2, bv2 = (_leaf(t.detach()) for t in (x, aq, av, bq, bv))
+    q2, k2, v2 = A.lora_qkv_rope(x2, w, wt, aq2, bq2, av2, bv2, cs, T, heads, scale, keep)
+    torch.autograd.backward([q2, k2, v2], [gq, gk, gv])
+    assert torch.equal(q2, q) and torch.equal(v2, v)
+    for a_, b_ in ((x2.grad, x.grad), (aq2.grad, aq.grad), (av2.grad, av.grad), (bq2.grad, bq.grad), (bv2.grad, bv.grad)):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_rope_bmm_embed_ce(dev, dtype):
     A = _ag()
