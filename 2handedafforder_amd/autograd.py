@@ -433,6 +433,9 @@ class LoraQKVRopeFn(Function):
 
         q = rope(x Wq^T + s (xd Aq^T) Bq^T),  k = rope(x Wk^T),  v = x Wv^T + s (xd Av^T) Bv^T,   xd = x * keep (adapter dropout)
 
+    keep holds the mask VALUES: 0 / 1/(1-p) as torch's dropout writes them, or 0 / 1 with the 1/(1-p) folded into s (what
+    train_model passes: one Bernoulli launch for the mask, and x * keep is then exact in bf16).
+
     bf16, head dim 128, rank <= 8 (csrc/lora.hip). The rank activations are carried TRANSPOSED ([16][M]: they come out of the
     weight-streaming product with the roles swapped, A2 as its 16 "activation rows" and the token rows as its "weights"), the
     rank-8 updates ride in one pass over q|k|v together with RoPE, and backward needs neither transposed copies of its
@@ -449,14 +452,17 @@ class LoraQKVRopeFn(Function):
         x = x.contiguous()
         qkv = ops.linear(x, wqkv)
         xd = x if keep is None else _mul(x, keep)
-        a2 = torch.zeros((16, K), dtype=x.dtype, device=dev)
-        a2[0:r] = aq
-        a2[8:8 + r] = av
-        b2 = torch.zeros((2, H, 8), dtype=x.dtype, device=dev)
-        b2[0, :, :r] = bq
-        b2[1, :, :r] = bv
-        Mp = _pad8(M)
-        tT = torch.zeros((16, Mp), dtype=x.dtype, device=dev)
+        if r == 8:   # the default rank: no padding, one launch each
+            a2, b2 = torch.cat([aq, av], 0), torch.stack([bq, bv], 0)
+        else:
+            a2 = torch.zeros((16, K), dtype=x.dtype, device=dev)
+            a2[0:r] = aq
+            a2[8:8 + r] = av
+            b2 = torch.zeros((2, H, 8), dtype=x.dtype, device=dev)
+            b2[0, :, :r] = bq
+            b2[1, :, :r] = bv
+        Mp = (M + 15) // 16 * 16
+        tT = (torch.empty if Mp == M else torch.zeros)((16, Mp), dtype=x.dtype, device=dev)   # pad columns stay finite (zero)
         ops.linear(a2, xd, out=tT[:, :M])
         q, k, v = (torch.empty((M, H), dtype=x.dtype, device=dev) for _ in range(3))
         check(lib.haff_lora_qkv_rope_fwd(qkv.data_ptr(), qkv.stride(0), tT.data_ptr(), Mp, b2[0].data_ptr(), b2[1].data_ptr(), 8,
@@ -482,7 +488,7 @@ class LoraQKVRopeFn(Function):
                                          M, H, d, T, _s()), "haff_lora_qkv_rope_bwd")
         # dt^T [16][M] = B^T . d(q|v)^T: the weight-streaming product again, the gradient rows as its "weights"
         b2t = b2.transpose(1, 2).contiguous()   # [2][8][H]
-        dtT = torch.zeros((16, Mp), dtype=dt_, device=dev)
+        dtT = (torch.empty if Mp == M else torch.zeros)((16, Mp), dtype=dt_, device=dev)
         ops.linear(b2t[0], dqkv[:, :H], out=dtT[0:8, :M])
         ops.linear(b2t[1], dqkv[:, 2 * H:], out=dtT[8:16, :M])
 

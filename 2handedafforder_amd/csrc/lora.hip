@@ -208,31 +208,45 @@ __global__ __launch_bounds__(256) void lora_tn_kernel(const bf16_t* sT, long lds
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long col = (long)blockIdx.x * 128 + 2 * lane;
-  const bool col_ok = col < N;   // N % 2 == 0 (checked by the launcher)
+  const long colc = col < N ? col : 0;   // N % 2 == 0 (checked by the launcher); columns past N are computed on column 0 and dropped
   const long r_lo = (long)blockIdx.y * rows_per_block;
   long r_hi = r_lo + rows_per_block;
   if (r_hi > M) r_hi = M;
   float acc[R][2];
 #pragma unroll
   for (int j = 0; j < R; ++j) acc[j][0] = acc[j][1] = 0.f;
-  for (long m0 = r_lo + 8 * wave; m0 < r_hi; m0 += 32) {   // r_lo % 8 == 0, lds % 8 == 0: 16-B aligned rank rows
-    unsigned bw[8];
+  // 16 rows per step (r_lo % 64 == 0, lds % 8 == 0 and lds >= roundup(M, 16): 32-B aligned rank rows), the next step's 16
+  // loads of the big operand in flight while this step's 2 * 16 * R FMAs run: a wave has only a handful of steps, and
+  // with one memory round trip per step the launch ran at a quarter of the HBM rate
+  auto load_rows = [&](long m0, unsigned (&bw)[16]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long m = m0 + i;
-      bw[i] = (col_ok && m < r_hi) ? *reinterpret_cast<const unsigned*>(big + m * ldb + col) : 0u;
+    for (int i = 0; i < 16; ++i) {   // rows past the block re-read its last row (their rank value is forced to 0 below)
+      const long m = m0 + i < r_hi ? m0 + i : r_hi - 1;
+      bw[i] = *reinterpret_cast<const unsigned*>(big + m * ldb + colc);
     }
+  };
+  unsigned bw[16], nx[16];
+  long m0 = r_lo + 16 * wave;
+  if (m0 < r_hi) load_rows(m0, bw);
+  for (; m0 < r_hi; m0 += 64) {
+    const bool more = m0 + 64 < r_hi;
+    if (more) load_rows(m0 + 64, nx);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      const uint4 sv = *reinterpret_cast<const uint4*>(sT + (long)j * lds + m0);
-      const unsigned sw[4] = {sv.x, sv.y, sv.z, sv.w};
+      const uint4 s0 = *reinterpret_cast<const uint4*>(sT + (long)j * lds + m0);
+      const uint4 s1 = *reinterpret_cast<const uint4*>(sT + (long)j * lds + m0 + 8);
+      const unsigned sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 16; ++i) {
         const unsigned h = (i & 1) ? (sw[i >> 1] & 0xffff0000u) : (sw[i >> 1] << 16);
-        const float s = (m0 + i < r_hi) ? __uint_as_float(h) : 0.f;
-        acc[j][0] = fmaf(s, __uint_as_float(bw[i] << 16), acc[j][0]);
-        acc[j][1] = fmaf(s, __uint_as_float(bw[i] & 0xffff0000u), acc[j][1]);
+        const float sv = (m0 + i < r_hi) ? __uint_as_float(h) : 0.f;
+        acc[j][0] = fmaf(sv, __uint_as_float(bw[i] << 16), acc[j][0]);
+        acc[j][1] = fmaf(sv, __uint_as_float(bw[i] & 0xffff0000u), acc[j][1]);
       }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bw[i] = nx[i];
     }
   }
 #pragma unroll
@@ -319,10 +333,10 @@ extern "C" int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda,
   return check_launch();
 }
 
-// rows per block of haff_lora_tn (multiple of 32): ~16 row blocks
+// rows per block of haff_lora_tn (multiple of 64): ~16 row blocks
 static long lora_tn_rows_per_block(long M) {
-  long rpb = ((M + 15) / 16 + 31) / 32 * 32;
-  return rpb < 32 ? 32 : rpb;
+  long rpb = ((M + 15) / 16 + 63) / 64 * 64;
+  return rpb < 64 ? 64 : rpb;
 }
 static long lora_tn_ws(long M, int R, int N) {
   const long rpb = lora_tn_rows_per_block(M);
@@ -337,7 +351,7 @@ extern "C" int haff_lora_tn(const void* sT, long lds, int R, const void* big, lo
                             void* stream) {
   if (M <= 0 || N <= 0 || !sT || !big || !workspace || !out || j_valid <= 0 || j_valid > R) return HAFF_ERR_BAD_ARG;
   if (R != 8 && R != 16) return HAFF_ERR_UNSUPPORTED;
-  if ((lds & 7) || lds < (M + 7) / 8 * 8 || !al16(sT) || (N & 1) || (ldb & 1) || ldb < N || (reinterpret_cast<uintptr_t>(big) & 3))
+  if ((lds & 7) || lds < (M + 15) / 16 * 16 || !al16(sT) || (N & 1) || (ldb & 1) || ldb < N || (reinterpret_cast<uintptr_t>(big) & 3))
     return HAFF_ERR_BAD_ARG;
   if (workspace_elems < lora_tn_ws(M, R, N)) return HAFF_ERR_BAD_ARG;
   if (ldo < (transposed ? j_valid : N)) return HAFF_ERR_BAD_ARG;

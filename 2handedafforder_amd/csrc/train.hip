@@ -134,6 +134,81 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* x, const T* dy, 
   }
 }
 
+// the same for bf16 rows of C = 512 * NV elements (Llama hidden sizes): the row and its gradient live in registers as 16-byte
+// loads — ONE pass over HBM; the generic kernel above walks the row four times with 2-byte loads (74 us for 2808 x 4096
+// against 15 us of traffic at the HBM rate: 2.6 % of the fine-tune step)
+template <bool RMS, int NV>
+__global__ __launch_bounds__(256) void norm_bwd_vec_kernel(const bf16_t* x, const bf16_t* dy, const float* w, bf16_t* dx, float* dyx,
+                                                          int rows, float eps) {
+  constexpr int C = 512 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (long)row * C;
+  const bf16_t* dr = dy + (long)row * C;
+  uint4 xv[NV], dv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    xv[i] = *reinterpret_cast<const uint4*>(xr + (i * 64 + lane) * 8);
+    dv[i] = *reinterpret_cast<const uint4*>(dr + (i * 64 + lane) * 8);
+  }
+  auto unpack = [](const uint4& r, float (&v)[8]) {
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(u[e] << 16); v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+  };
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float v[8];
+    unpack(xv[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  float mean = 0.f, rstd;
+  if (RMS) rstd = 1.0f / sqrtf(s2 / C + eps);
+  else {
+    mean = s1 / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float v[8];
+      unpack(xv[i], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
+    }
+    sq = wave_sum(sq);
+    rstd = 1.0f / sqrtf(sq / C + eps);
+  }
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float v[8], d[8], wv[8];
+    unpack(xv[i], v);
+    unpack(dv[i], d);
+    load8(w + (i * 64 + lane) * 8, wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float g = d[e] * wv[e]; a += g; b += g * ((v[e] - mean) * rstd); }
+  }
+  a = wave_sum(a) / C; b = wave_sum(b) / C;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float v[8], d[8], wv[8], o[8];
+    unpack(xv[i], v);
+    unpack(dv[i], d);
+    load8(w + (i * 64 + lane) * 8, wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (v[e] - mean) * rstd;
+      o[e] = rstd * (d[e] * wv[e] - (RMS ? 0.f : a) - xh * b);
+      d[e] *= xh;
+    }
+    store8(dx + (long)row * C + (i * 64 + lane) * 8, o);
+    if (dyx) store8(dyx + (long)row * C + (i * 64 + lane) * 8, d);
+  }
+}
+
 // column sums of x [R][C] -> out f32 [C] (bias / LN weight gradients); out must be zeroed by the caller
 template <typename T>
 __global__ void colsum_kernel(const T* x, float* out, long R, int C, long rows_per_block) {
@@ -424,6 +499,15 @@ extern "C" int haff_norm_bwd(const void* x, const void* dy, const float* w, void
                              int rms, int dtype, void* stream) {
   if (rows <= 0 || C <= 0) return HAFF_ERR_BAD_ARG;
   dim3 g((rows + 3) / 4), b(256);
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                    reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dyx)) & 15) == 0;
+  if (dtype == 0 && al && (C == 4096 || C == 5120)) {   // Llama 7B / 13B rows: one pass, the row in registers
+#define HAFF_NBV(R_, NV_) hipLaunchKernelGGL((norm_bwd_vec_kernel<R_, NV_>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, eps)
+    if (C == 4096) { if (rms) HAFF_NBV(true, 8); else HAFF_NBV(false, 8); }
+    else { if (rms) HAFF_NBV(true, 10); else HAFF_NBV(false, 10); }
+#undef HAFF_NBV
+    return haff_check_launch();
+  }
   if (dtype == 0) {
     if (rms) hipLaunchKernelGGL((norm_bwd_kernel<bf16_t, true>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, C, eps);
     else hipLaunchKernelGGL((norm_bwd_kernel<bf16_t, false>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, C, eps);

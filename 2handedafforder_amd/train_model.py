@@ -106,16 +106,20 @@ class LisaTrainable:
             wt = self.wt[i]
             h = A.rmsnorm(x, L["n1"], l.rms_eps)
             pre = f"model.layers.{i}.self_attn."
-            keep = None
-            if self.training and self.lora_dropout > 0:
-                keep = (torch.rand(h.shape, device=h.device) >= self.lora_dropout).to(h.dtype) / (1 - self.lora_dropout)
+            drop = self.lora_dropout if self.training else 0.0
             if A.FUSED_LORA_QKV and A.lora_qkv_rope_supported(h, L["wqkv"], P[pre + "q_proj.lora_A"], nh):
-                # one node: q|k|v product, both rank-r updates, RoPE (csrc/lora.hip)
+                # one node: q|k|v product, both rank-r updates, RoPE (csrc/lora.hip); the dropout mask as 0 / 1 values from one
+                # Bernoulli launch, its 1/(1-p) folded into the adapter scale
+                keep = torch.empty(h.shape, dtype=h.dtype, device=h.device).bernoulli_(1.0 - drop) if drop > 0 else None
                 q, k, v = A.lora_qkv_rope(h, L["wqkv"], wt["wqkv"], P[pre + "q_proj.lora_A"], P[pre + "q_proj.lora_B"],
-                                          P[pre + "v_proj.lora_A"], P[pre + "v_proj.lora_B"], cs, T, nh, self.lora_scale, keep)
+                                          P[pre + "v_proj.lora_A"], P[pre + "v_proj.lora_B"], cs, T, nh,
+                                          self.lora_scale / (1.0 - drop), keep)
             else:
                 qkv = A.linear(h, L["wqkv"], None, None, wt["wqkv"])
-                hl = h if keep is None else DropoutMul.apply(h, keep)
+                hl = h
+                if drop > 0:
+                    keep = (torch.rand(h.shape, device=h.device) >= drop).to(h.dtype) / (1 - drop)
+                    hl = DropoutMul.apply(h, keep)
                 dq = A.linear(A.linear(hl, P[pre + "q_proj.lora_A"]), _pad_k(P[pre + "q_proj.lora_B"]))
                 dv = A.linear(A.linear(hl, P[pre + "v_proj.lora_A"]), _pad_k(P[pre + "v_proj.lora_B"]))
                 q = A.add(qkv[:, :H], A.scale(dq, self.lora_scale))

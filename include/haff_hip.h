@@ -150,7 +150,7 @@ int haff_attention_bwd_bf16(const void* q, const void* k, const void* v, const v
  * haff_lora_qkv_rope_fwd: q_out = rope(qkv[:, :H] + scale * t_q.Bq^T), k_out = rope(qkv[:, H:2H]), v_out = qkv[:, 2H:] + scale * t_v.Bv^T
  * haff_lora_qkv_rope_bwd: dqkv [M][3H] = [rope^T dq | rope^T dk | dv] (the adjoint of the q|k|v product's output)
  * haff_lora_dx:           dx (+)= scale * keep .* (dt . A2)   (keep: optional dropout mask values [M][K])
- * haff_lora_tn:           out = scale * sT . big  (sT [R][lds] with R = 8 or 16, lds % 8 == 0, padding finite; big [M][N]; contraction over the M
+ * haff_lora_tn:           out = scale * sT . big  (sT [R][lds] with R = 8 or 16, lds % 8 == 0, lds >= roundup(M, 16), padding finite; big [M][N]; contraction over the M
  *                         rows; out [j_valid][N] or, transposed, [N][j_valid], bf16 or f32) — the dA / dB contraction without a
  *                         transposed copy of either operand; workspace f32 with haff_lora_tn_workspace_elems values;
  *                         row-block partials are added in index order (deterministic). */

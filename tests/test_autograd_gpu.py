@@ -106,6 +106,31 @@ def test_act_swiglu_norms(dev, dtype):
     _close(a.grad, ar.grad, tol, "rms dx")
 
 
+@pytest.mark.parametrize("C", [4096, 5120])
+def test_norm_adjoints_llama_width(dev, C):
+    """bf16 rows of 4096 / 5120 take the one-pass register-resident adjoint (norm_bwd_vec_kernel): RMSNorm and LayerNorm
+    (with the weight / bias gradients) against fp32 torch autograd, 37 rows (a partial last workgroup), and against the generic
+    kernel's result on a column count next to it."""
+    A = _ag()
+    dtype, R = torch.bfloat16, 37
+    x = _rand((R, C), dev, dtype, 14, 2.0) + 0.5
+    w, b = _leaf(_rand((C,), dev, torch.float32, 15) + 1.0), _leaf(_rand((C,), dev, torch.float32, 16))
+    gy = _rand((R, C), dev, dtype, 17)
+    a = _leaf(x)
+    A.layernorm(a, w, b, 1e-5).backward(gy)
+    ar, wr, br = _leaf(x.float()), _leaf(w.detach()), _leaf(b.detach())
+    F.layer_norm(ar, (C,), wr, br, 1e-5).backward(gy.float())
+    _close(a.grad, ar.grad, 3e-2, "ln dx")
+    _close(w.grad, wr.grad, 3e-2, "ln dw")
+    _close(b.grad, br.grad, 3e-2, "ln db")
+    a = _leaf(x)
+    A.rmsnorm(a, w.detach(), 1e-5).backward(gy)
+    ar = _leaf(x.float())
+    (ar * torch.rsqrt(ar.pow(2).mean(-1, keepdim=True) + 1e-5) * w.detach()).backward(gy.float())
+    _close(a.grad, ar.grad, 3e-2, "rms dx")
+    assert (a.grad.float() - ar.grad).abs().mean().item() <= 4e-3 * ar.grad.abs().mean().item() + 1e-6   # bf16 rounding of dx only
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,H,Nq,Nk,d,causal", [(2, 4, 37, 37, 32, True), (2, 8, 6, 200, 16, False), (1, 8, 130, 6, 16, False),
                                                 (2, 2, 50, 50, 128, True)])
