@@ -43,67 +43,67 @@ struct LoraFwdArgs {
   long M; int H, T; float scale;
 };
 
-// one wave = one head (128 columns: tiles c = 0..3 hold columns 16c.., tiles 4..7 their rotate-half partners +64) x 16-row
-// tiles; lane (fr, fh) owns row fr, columns 4fh..4fh+3 of every tile — the MFMA's output layout with the COLUMN operand first
+// one wave = one head x 16-row tiles. The head's 128 columns are four groups of 32 (groups 2, 3 = the rotate-half partners of
+// groups 0, 1); a group takes TWO MFMAs whose column operands are loaded in a permuted order (MFMA h, operand row i = column
+// 8 * (i / 4) + 4 * h + i % 4), so that lane (fr, fh) ends up with row fr, columns 8fh .. 8fh+7 of the group: 16-byte
+// loads and stores, 64 contiguous bytes per row and instruction (the natural operand order leaves 4 columns per lane:
+// 8-byte accesses in 32-byte runs, which held this kernel at 2.4 TB/s)
 __global__ __launch_bounds__(256, 3) void lora_qkv_rope_fwd_kernel(LoraFwdArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fh = lane >> 4;
   const int head = blockIdx.x;
   const long n_rt = (p.M + 15) / 16;
-  bf16x8 bq[8], bv[8];
+  bf16x8 bq[4][2], bv[4][2];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const long col = (long)head * HD + 16 * c + fr;
-    bq[c] = fh == 0 ? *reinterpret_cast<const bf16x8*>(p.Bq + col * p.ldb) : zero_frag();
-    bv[c] = fh == 1 ? *reinterpret_cast<const bf16x8*>(p.Bv + col * p.ldb) : zero_frag();
-  }
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long col = (long)head * HD + 32 * g + 8 * (fr >> 2) + 4 * h + (fr & 3);
+      bq[g][h] = fh == 0 ? *reinterpret_cast<const bf16x8*>(p.Bq + col * p.ldb) : zero_frag();
+      bv[g][h] = fh == 1 ? *reinterpret_cast<const bf16x8*>(p.Bv + col * p.ldb) : zero_frag();
+    }
   for (long rt = (long)blockIdx.y * 4 + wave; rt < n_rt; rt += (long)gridDim.y * 4) {
     const long row = rt * 16 + fr;
     const bool valid = row < p.M;
     const long rc = valid ? row : p.M - 1;
     const int pos = (int)(rc % p.T);
     const bf16x8 tt = load_t_frag(p.tT, p.ldt, rc, fh);
-    const bf16_t* src = p.qkv + rc * p.ld_qkv + (long)head * HD + 4 * fh;
-    bf16_t* dq_o = p.qo + rc * p.ldo + (long)head * HD + 4 * fh;
-    bf16_t* dk_o = p.ko + rc * p.ldo + (long)head * HD + 4 * fh;
-    bf16_t* dv_o = p.vo + rc * p.ldo + (long)head * HD + 4 * fh;
-    auto unpack = [](const uint2& r, float (&v)[4]) {
-      v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-      v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-    };
+    const bf16_t* src = p.qkv + rc * p.ld_qkv + (long)head * HD + 8 * fh;
+    bf16_t* q_o = p.qo + rc * p.ldo + (long)head * HD + 8 * fh;
+    bf16_t* k_o = p.ko + rc * p.ldo + (long)head * HD + 8 * fh;
+    bf16_t* v_o = p.vo + rc * p.ldo + (long)head * HD + 8 * fh;
+    const float* csr = p.cs + (long)pos * HD + 8 * fh;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {   // column tile c and its rotate-half partner c + 4
-      const uint2 rq0 = *reinterpret_cast<const uint2*>(src + 16 * c), rq1 = *reinterpret_cast<const uint2*>(src + 64 + 16 * c);
-      const uint2 rk0 = *reinterpret_cast<const uint2*>(src + p.H + 16 * c), rk1 = *reinterpret_cast<const uint2*>(src + p.H + 64 + 16 * c);
-      const uint2 rv0 = *reinterpret_cast<const uint2*>(src + 2 * (long)p.H + 16 * c);
-      const uint2 rv1 = *reinterpret_cast<const uint2*>(src + 2 * (long)p.H + 64 + 16 * c);
-      const float4 co = *reinterpret_cast<const float4*>(p.cs + (long)pos * HD + 16 * c + 4 * fh);
-      const float4 si = *reinterpret_cast<const float4*>(p.cs + (long)pos * HD + 64 + 16 * c + 4 * fh);
+    for (int g = 0; g < 2; ++g) {   // column group g and its rotate-half partner g + 2
+      float qa[8], qb[8], ka[8], kb[8], va[8], vb[8], co[8], si[8];
+      load8(src + 32 * g, qa); load8(src + 64 + 32 * g, qb);
+      load8(src + p.H + 32 * g, ka); load8(src + p.H + 64 + 32 * g, kb);
+      load8(src + 2 * (long)p.H + 32 * g, va); load8(src + 2 * (long)p.H + 64 + 32 * g, vb);
+      load8(csr + 32 * g, co); load8(csr + 64 + 32 * g, si);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[c], tt, z, 0, 0, 0);
-      const f32x4 dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[c + 4], tt, z, 0, 0, 0);
-      const f32x4 dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[c], tt, z, 0, 0, 0);
-      const f32x4 dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[c + 4], tt, z, 0, 0, 0);
-      float qa[4], qb[4], ka[4], kb[4], va[4], vb[4];
-      unpack(rq0, qa); unpack(rq1, qb);
-      unpack(rk0, ka); unpack(rk1, kb);
-      unpack(rv0, va); unpack(rv1, vb);
-      const float cc[4] = {co.x, co.y, co.z, co.w}, ss[4] = {si.x, si.y, si.z, si.w};
-      float q1[4], q2[4], k1[4], k2[4];
+      f32x4 dq0[2], dq1[2], dv0[2], dv1[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ql = qa[r] + p.scale * dq0[r], qh = qb[r] + p.scale * dq1[r];
-        q1[r] = ql * cc[r] - qh * ss[r];
-        q2[r] = qh * cc[r] + ql * ss[r];
-        k1[r] = ka[r] * cc[r] - kb[r] * ss[r];
-        k2[r] = kb[r] * cc[r] + ka[r] * ss[r];
-        va[r] += p.scale * dv0[r];
-        vb[r] += p.scale * dv1[r];
+      for (int h = 0; h < 2; ++h) {
+        dq0[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[g][h], tt, z, 0, 0, 0);
+        dq1[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[g + 2][h], tt, z, 0, 0, 0);
+        dv0[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[g][h], tt, z, 0, 0, 0);
+        dv1[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[g + 2][h], tt, z, 0, 0, 0);
+      }
+      float q1[8], q2[8], k1[8], k2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ql = qa[e] + p.scale * dq0[e >> 2][e & 3], qh = qb[e] + p.scale * dq1[e >> 2][e & 3];
+        q1[e] = ql * co[e] - qh * si[e];
+        q2[e] = qh * co[e] + ql * si[e];
+        k1[e] = ka[e] * co[e] - kb[e] * si[e];
+        k2[e] = kb[e] * co[e] + ka[e] * si[e];
+        va[e] += p.scale * dv0[e >> 2][e & 3];
+        vb[e] += p.scale * dv1[e >> 2][e & 3];
       }
       if (valid) {
-        store4(dq_o + 16 * c, q1); store4(dq_o + 64 + 16 * c, q2);
-        store4(dk_o + 16 * c, k1); store4(dk_o + 64 + 16 * c, k2);
-        store4(dv_o + 16 * c, va); store4(dv_o + 64 + 16 * c, vb);
+        store8(q_o + 32 * g, q1); store8(q_o + 64 + 32 * g, q2);
+        store8(k_o + 32 * g, k1); store8(k_o + 64 + 32 * g, k2);
+        store8(v_o + 32 * g, va); store8(v_o + 64 + 32 * g, vb);
       }
     }
   }
@@ -149,51 +149,47 @@ struct LoraDxArgs {
   bf16_t* dx; long ldx;
   long M; int K; int accumulate; float scale;
 };
-__global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxArgs p) {
+__global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxArgs p) {   // column operands permuted as in the forward kernel
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fh = lane >> 4;
   const long c0 = (long)blockIdx.x * 128;
   const long n_rt = (p.M + 15) / 16;
-  bf16x8 af[8];
+  bf16x8 af[4][2];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    af[c] = zero_frag();
-    if (fh < 2) {
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) af[c][i] = (short)p.A2[(long)(8 * fh + i) * p.lda + c0 + 16 * c + fr];
+    for (int h = 0; h < 2; ++h) {
+      af[g][h] = zero_frag();
+      if (fh < 2) {
+        const long col = c0 + 32 * g + 8 * (fr >> 2) + 4 * h + (fr & 3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[g][h][i] = (short)p.A2[(long)(8 * fh + i) * p.lda + col];
+      }
     }
-  }
   for (long rt = (long)blockIdx.y * 4 + wave; rt < n_rt; rt += (long)gridDim.y * 4) {
     const long row = rt * 16 + fr;
     const bool valid = row < p.M;
     const long rc = valid ? row : p.M - 1;
     const bf16x8 tt = load_t_frag(p.dtT, p.ldt, rc, fh);
-    uint2 old[8], kp[8];
-    bf16_t* dst = p.dx + rc * p.ldx + c0 + 4 * fh;
-    if (p.accumulate) {
+    bf16_t* dst = p.dx + rc * p.ldx + c0 + 8 * fh;
+    const bf16_t* kpr = p.keep ? p.keep + rc * p.ldk + c0 + 8 * fh : nullptr;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) old[c] = *reinterpret_cast<const uint2*>(dst + 16 * c);
-    }
-    if (p.keep) {
+    for (int g = 0; g < 4; ++g) {
+      float old[8], kp[8];
+      if (p.accumulate) load8(dst + 32 * g, old);
+      if (kpr) load8(kpr + 32 * g, kp);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 d[2];
+      d[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g][0], tt, z, 0, 0, 0);
+      d[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g][1], tt, z, 0, 0, 0);
+      float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) kp[c] = *reinterpret_cast<const uint2*>(p.keep + rc * p.ldk + c0 + 4 * fh + 16 * c);
-    }
-    f32x4 d[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) d[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], tt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    if (!valid) continue;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float v[4] = {p.scale * d[c][0], p.scale * d[c][1], p.scale * d[c][2], p.scale * d[c][3]};
-      if (p.keep) {
-        v[0] *= __uint_as_float(kp[c].x << 16); v[1] *= __uint_as_float(kp[c].x & 0xffff0000u);
-        v[2] *= __uint_as_float(kp[c].y << 16); v[3] *= __uint_as_float(kp[c].y & 0xffff0000u);
+      for (int e = 0; e < 8; ++e) {
+        v[e] = p.scale * d[e >> 2][e & 3];
+        if (kpr) v[e] *= kp[e];
+        if (p.accumulate) v[e] += old[e];
       }
-      if (p.accumulate) {
-        v[0] += __uint_as_float(old[c].x << 16); v[1] += __uint_as_float(old[c].x & 0xffff0000u);
-        v[2] += __uint_as_float(old[c].y << 16); v[3] += __uint_as_float(old[c].y & 0xffff0000u);
-      }
-      store4(dst + 16 * c, v);
+      if (valid) store8(dst + 32 * g, v);
     }
   }
 }
@@ -281,7 +277,6 @@ __global__ void lora_tn_reduce_kernel(const float* part, int nrb, int R, int N, 
 inline hipStream_t HS(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int check_launch() { return hipGetLastError() == hipSuccess ? HAFF_OK : HAFF_ERR_LAUNCH; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
 }  // namespace
 
@@ -290,8 +285,8 @@ extern "C" int haff_lora_qkv_rope_fwd(const void* qkv, long ld_qkv, const void* 
                                       int H, int d, int T, float scale, void* stream) {
   if (M <= 0 || T <= 0 || H <= 0 || !qkv || !tT || !Bq || !Bv || !cos_sin || !q_out || !k_out || !v_out) return HAFF_ERR_BAD_ARG;
   if (d != HD || H % HD || ldb != 8) return HAFF_ERR_UNSUPPORTED;
-  if (ld_qkv < 3L * H || ldo < H || ldt < M || (ld_qkv & 3) || (ldo & 3)) return HAFF_ERR_BAD_ARG;
-  if (!al8(qkv) || !al16(Bq) || !al16(Bv) || !al16(cos_sin) || !al8(q_out) || !al8(k_out) || !al8(v_out)) return HAFF_ERR_BAD_ARG;
+  if (ld_qkv < 3L * H || ldo < H || ldt < M || (ld_qkv & 7) || (ldo & 7)) return HAFF_ERR_BAD_ARG;
+  if (!al16(qkv) || !al16(Bq) || !al16(Bv) || !al16(cos_sin) || !al16(q_out) || !al16(k_out) || !al16(v_out)) return HAFF_ERR_BAD_ARG;
   LoraFwdArgs p{(const bf16_t*)qkv, ld_qkv, (const bf16_t*)tT, ldt, (const bf16_t*)Bq, (const bf16_t*)Bv, ldb, cos_sin,
                 (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)v_out, ldo, M, H, T, scale};
   const long n_rt = (M + 15) / 16;
@@ -321,8 +316,8 @@ extern "C" int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda,
                             int accumulate, long M, int K, float scale, void* stream) {
   if (M <= 0 || K <= 0 || !dtT || !A2 || !dx) return HAFF_ERR_BAD_ARG;
   if (K % 128) return HAFF_ERR_UNSUPPORTED;
-  if (ldt < M || lda < K || ldx < K || (ldx & 3) || (keep && (ldk < K || (ldk & 3)))) return HAFF_ERR_BAD_ARG;
-  if (!al8(dx) || (keep && !al8(keep))) return HAFF_ERR_BAD_ARG;
+  if (ldt < M || lda < K || ldx < K || (ldx & 7) || (keep && (ldk < K || (ldk & 7)))) return HAFF_ERR_BAD_ARG;
+  if (!al16(dx) || (keep && !al16(keep))) return HAFF_ERR_BAD_ARG;
   LoraDxArgs p{(const bf16_t*)dtT, ldt, (const bf16_t*)A2, lda, (const bf16_t*)keep, ldk, (bf16_t*)dx, ldx, M, K, accumulate, scale};
   const long n_rt = (M + 15) / 16;
   long gy = (n_rt + 3) / 4;
