@@ -38,7 +38,7 @@ def _leaf(t):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (37, 43, 72), (5, 8, 256)])
+@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (37, 43, 72), (5, 8, 256), (2100, 256, 64), (1300, 128, 32)])   # the last two: 16-byte column sums for db
 def test_linear_fn(dev, dtype, M, N, K):
     A = _ag()
     x, w = _leaf(_rand((M, K), dev, dtype, 1)), _leaf(_rand((N, K), dev, dtype, 2, K ** -0.5))
