@@ -35,6 +35,7 @@ class LisaTrainable:
         self.lora_r, self.lora_scale, self.lora_dropout = lora_r, lora_alpha / lora_r, lora_dropout
         self.w_ce, self.w_dice, self.w_bce = ce_loss_weight, dice_loss_weight, bce_loss_weight
         self.training = True
+        self.overlap_sam = True   # False: the SAM encoder on the caller's stream, in front of everything else (A/B)
         sd, dev = state_dict, self.device
         P = self.params = OrderedDict()
 
@@ -212,8 +213,17 @@ class LisaTrainable:
         cfg, dev = self.cfg, self.device
         base = self.base
         input_ids, labels, offset = input_ids.to(dev), labels.to(dev), offset.to(dev)
+        # The frozen SAM encoder feeds only the mask decoders: it runs on the model's side stream beside the CLIP tower and
+        # the Llama forward, whose M = conversations x tokens products leave CUs idle (2808 x 4096 outputs = 176 tiles of
+        # 256 x 256 on 256 CUs), and is joined in front of the decoders.
+        cur = torch.cuda.current_stream(dev)
+        side = base._sam_stream if (self.overlap_sam and dev.type == "cuda") else cur
         with torch.no_grad():
-            emb = base.get_visual_embs(images)                                    # frozen SAM encoder (LISA.py:191)
+            images = images.to(dev)
+            if side is not cur:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                emb = base.get_visual_embs(images)                                # frozen SAM encoder (LISA.py:191)
             n_conv = input_ids.shape[0]
             reps = (offset[1:] - offset[:-1]).tolist()
             clip_rep = torch.cat([images_clip[i:i + 1].expand(r, -1, -1, -1) for i, r in enumerate(reps)], 0)
@@ -254,6 +264,9 @@ class LisaTrainable:
         frame_idx = torch.cat([torch.full((seg_off[i + 1] - seg_off[i],), i, dtype=torch.long, device=dev) for i in range(bsz)])
         Pn = pred.shape[0]
         N, C = emb.shape[1], emb.shape[2]
+        if side is not cur:
+            cur.wait_stream(side)
+            emb.record_stream(cur)
         with torch.no_grad():
             src = emb.index_select(0, frame_idx).reshape(Pn * N, C)
             src = ops.add_bcast(src, base.sam_decoder.no_mask, mod=1).view(Pn, N, C)

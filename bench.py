@@ -434,6 +434,7 @@ def train_main(args):
     cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
     sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
     model = LisaTrainable(cfg, sd, dtype=torch.bfloat16, device=device)
+    model.overlap_sam = not args.single_stream   # --single-stream: the frozen SAM encoder in front of the Llama forward instead of beside it
     del sd
     torch.cuda.empty_cache()
     b = args.batch if args.batch != 64 else 8
@@ -483,7 +484,8 @@ def train_main(args):
                              "traffic": None, "launches_per_step": n_launch, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
                              "flops_per_launch_avg": gemm_fl / max(n_launch, 1), "algorithmic_bytes_per_launch_avg": gemm_bytes / max(n_launch, 1),
                              "gemm_share_of_step": gemm_ms / ms_per_step,
-                             "executed_gemm_flop_per_sample": meter.total_gemm_flop() / b},
+                             "executed_gemm_flop_per_sample": meter.total_gemm_flop() / b,
+                             "by_shape": meter.shape_summary(top=24)},
                 "cpu_baseline": None,
                 "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
         print(json.dumps(line), flush=True)
