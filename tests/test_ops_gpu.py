@@ -552,6 +552,34 @@ def test_qkv_rope_gemm(dev, B, T, H, K, pos0):
     assert torch.equal(q3, q2) and torch.equal(k3, k2) and torch.equal(v3, v2)
 
 
+@pytest.mark.parametrize("M,N,K,inplace", [(4136, 4096, 128, False), (16448, 1024, 256, True), (4136, 256, 128, False)])
+def test_linear_row_tail_split(dev, M, N, K, inplace):
+    """linear() sends a <= 64-row tail that would cost the persistent 256 x 256 tile an extra round out as its own launch (CLIP at
+    64 frames: 16448 rows): the two-launch form equals the one-launch form (whole row tiles bit for bit on the same tile, the
+    tail rows to bf16 rounding: the weight-streaming kernel sums K in another order), bias + activation + in-place residual
+    included; shapes where the tail adds no round stay one launch."""
+    ops = _ops()
+    import haff.ops as hops
+    x = _rand((M, K), dev, torch.bfloat16, 70)
+    w = _rand((N, K), dev, torch.bfloat16, 71, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 72)
+    resid = _rand((M, N), dev, torch.bfloat16, 73)
+    assert hops.SPLIT_ROW_TAIL
+    o_split = resid.clone() if inplace else None
+    o_split = ops.linear(x, w, bias=bias, act=ops.ACT_QUICK_GELU, resid=o_split if inplace else resid, out=o_split)
+    hops.SPLIT_ROW_TAIL = False
+    try:
+        o_one = ops.linear(x, w, bias=bias, act=ops.ACT_QUICK_GELU, resid=resid)
+    finally:
+        hops.SPLIT_ROW_TAIL = True
+    m0 = M & ~255
+    assert torch.equal(o_split[:m0], o_one[:m0])
+    _close(o_split[m0:], o_one[m0:], 2.0 ** -7, "tail rows")
+    ref = F.linear(x.float(), w.float(), bias)
+    ref = ref * torch.sigmoid(1.702 * ref) + resid.float()
+    _close(o_split, ref, 2e-2, "two-launch linear vs fp32")
+
+
 @pytest.mark.parametrize("M,N,K,gather", [(2048, 1280, 1280, False), (1024, 1280, 5120, False), (1536, 1280, 1280, True)])
 def test_linear_rowstats(dev, M, N, K, gather):
     """haff_gemm_bf16_rowstats: (1) the product + bias + residual is bit-identical to haff_gemm_bf16 on the 256 x 256 tile
