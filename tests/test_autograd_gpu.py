@@ -383,6 +383,17 @@ def test_losses_and_bilinear(dev):
     u = F.interpolate(mr[:, None], (224, 224), mode="bilinear", align_corners=False)
     F.interpolate(u[..., :224, :168], (120, 90), mode="bilinear", align_corners=False)[:, 0].backward(g)
     _close(m.grad, mr.grad, 1e-5, "bilinear grad")
+    # the gather adjoint at a non-integer up-scale of a crop (rows outside the crop get no gradient), twice: same bits
+    m2 = _leaf(_rand((3, 40, 48), dev, torch.float32, 44))
+    g2 = _rand((3, 101, 77), dev, torch.float32, 45)
+    A.resize_bilinear(m2, (33, 48), (101, 77)).backward(g2)
+    m2r = _leaf(m2.detach())
+    F.interpolate(m2r[:, None, :33, :48], (101, 77), mode="bilinear", align_corners=False)[:, 0].backward(g2)
+    _close(m2.grad, m2r.grad, 1e-5, "bilinear grad (crop, 3.06x / 1.6x)")
+    assert m2.grad[:, 33:].abs().max().item() == 0.0
+    m3 = _leaf(m2.detach())
+    A.resize_bilinear(m3, (33, 48), (101, 77)).backward(g2)
+    assert torch.equal(m3.grad, m2.grad)
 
 
 def test_adamw_matches_torch(dev):
