@@ -95,6 +95,44 @@ __global__ void mul_kernel(const T* a, const T* b, T* out, long n) {
     elem<T>::st(out + i, elem<T>::ld(a + i) * elem<T>::ld(b + i));
 }
 
+// bf16 forms with 16-byte accesses: a thread owns 8 consecutive outputs (half a 16-column group)
+__global__ void swiglu_fwd_vec_kernel(const bf16_t* gu, bf16_t* y, long M, int F) {
+  const long n8 = M * F / 8;
+  const int f8 = F >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / f8;
+    const int j = (int)(i - m * f8) * 8;
+    const long base = m * 2 * F + (j >> 4) * 32 + (j & 15);
+    float g[8], u[8], o[8];
+    load8(gu + base, g);
+    load8(gu + base + 16, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.0f + expf(-g[e])) * u[e];
+    store8(y + m * F + j, o);
+  }
+}
+__global__ void swiglu_bwd_vec_kernel(const bf16_t* gu, const bf16_t* dy, bf16_t* dgu, long M, int F) {
+  const long n8 = M * F / 8;
+  const int f8 = F >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / f8;
+    const int j = (int)(i - m * f8) * 8;
+    const long base = m * 2 * F + (j >> 4) * 32 + (j & 15);
+    float g[8], u[8], d[8], dg[8], du[8];
+    load8(gu + base, g);
+    load8(gu + base + 16, u);
+    load8(dy + m * F + j, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sg = 1.0f / (1.0f + expf(-g[e]));
+      dg[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));
+      du[e] = d[e] * g[e] * sg;
+    }
+    store8(dgu + base, dg);
+    store8(dgu + base + 16, du);
+  }
+}
+
 // ---- norm adjoints: one wave per row ---------------------------------------------------------------------------
 // LayerNorm: xhat = (x-mean)*rstd, g = dy*w ; dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dyx = dy*xhat (f32, for dw)
 // RMSNorm  : xhat = x*rstd ;            dx = rstd*(g - xhat*mean(g*xhat))
@@ -538,6 +576,10 @@ extern "C" int haff_act_bwd(const void* x, const void* dy, void* dx, long n, int
 }
 extern "C" int haff_swiglu_fwd(const void* gu, void* y, long M, int F, int dtype, void* stream) {
   if (M <= 0 || F <= 0 || (F & 15)) return HAFF_ERR_BAD_ARG;
+  if (dtype == 0 && ((reinterpret_cast<uintptr_t>(gu) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    hipLaunchKernelGGL(swiglu_fwd_vec_kernel, dim3(grid_for(M * F / 8, 256)), dim3(256), 0, HS(stream), (const bf16_t*)gu, (bf16_t*)y, M, F);
+    return haff_check_launch();
+  }
   dim3 g(grid_for(M * F, 256)), b(256);
   DISPATCH_T(dtype, hipLaunchKernelGGL((swiglu_fwd_kernel<bf16_t>), g, b, 0, HS(stream), (const bf16_t*)gu, (bf16_t*)y, M, F),
              hipLaunchKernelGGL((swiglu_fwd_kernel<float>), g, b, 0, HS(stream), (const float*)gu, (float*)y, M, F));
@@ -545,6 +587,10 @@ extern "C" int haff_swiglu_fwd(const void* gu, void* y, long M, int F, int dtype
 }
 extern "C" int haff_swiglu_bwd(const void* gu, const void* dy, void* dgu, long M, int F, int dtype, void* stream) {
   if (M <= 0 || F <= 0 || (F & 15)) return HAFF_ERR_BAD_ARG;
+  if (dtype == 0 && ((reinterpret_cast<uintptr_t>(gu) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dgu)) & 15) == 0) {
+    hipLaunchKernelGGL(swiglu_bwd_vec_kernel, dim3(grid_for(M * F / 8, 256)), dim3(256), 0, HS(stream), (const bf16_t*)gu, (const bf16_t*)dy, (bf16_t*)dgu, M, F);
+    return haff_check_launch();
+  }
   dim3 g(grid_for(M * F, 256)), b(256);
   DISPATCH_T(dtype, hipLaunchKernelGGL((swiglu_bwd_kernel<bf16_t>), g, b, 0, HS(stream), (const bf16_t*)gu, (const bf16_t*)dy, (bf16_t*)dgu, M, F),
              hipLaunchKernelGGL((swiglu_bwd_kernel<float>), g, b, 0, HS(stream), (const float*)gu, (const float*)dy, (float*)dgu, M, F));
