@@ -204,7 +204,7 @@ def test_flash_attention_fn(dev, B, H, Nq, Nk, causal):
 
 
 @pytest.mark.parametrize("B,T,heads,K,r,drop", [(2, 37, 2, 256, 8, False), (3, 50, 3, 384, 8, True), (1, 129, 2, 256, 4, True),
-                                                (2, 16, 1, 128, 1, False)])
+                                                (2, 16, 1, 128, 1, False), (1, 40, 40, 5120, 8, True)])   # the last: 13B widths
 def test_lora_qkv_rope_fn(dev, B, T, heads, K, r, drop):
     """The adapted q|k|v projection + RoPE as one node (csrc/lora.hip: haff_lora_qkv_rope_fwd / _bwd, haff_lora_dx, haff_lora_tn
     and the role-swapped weight-streaming products) against (1) fp32 torch autograd of the definition (peft LoRA on q_proj /
