@@ -584,12 +584,14 @@ class CrossEntropyFn(Function):
     """mean over rows with label >= 0 of (logsumexp(logits) - logits[label])  (CrossEntropyLoss, ignore_index=-100)."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, n_valid=None):
         lib = load_library()
         logits = logits.contiguous()
         labels = labels.contiguous()
         R, V = logits.shape
-        n_valid = max(int((labels >= 0).sum().item()), 1)
+        if n_valid is None:   # (a host read: callers that know the count — the labels came from the host — pass it)
+            n_valid = int((labels >= 0).sum().item())
+        n_valid = max(int(n_valid), 1)
         row_loss = torch.empty((R,), dtype=torch.float32, device=logits.device)
         dlogits = torch.empty_like(logits)
         check(lib.haff_cross_entropy(logits.data_ptr(), logits.stride(0), labels.data_ptr(), row_loss.data_ptr(), dlogits.data_ptr(),
@@ -601,10 +603,11 @@ class CrossEntropyFn(Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
-        return axpby(dlogits, None, float(g.item()), 0.0), None
+        return dlogits * g.to(dlogits.dtype), None, None   # the upstream scalar stays on the device (no read-back at the head of backward)
 
 
-cross_entropy = CrossEntropyFn.apply
+def cross_entropy(logits, labels, n_valid=None):
+    return CrossEntropyFn.apply(logits, labels, n_valid)
 
 
 class MaskLossFn(Function):
@@ -621,22 +624,23 @@ class MaskLossFn(Function):
                   "haff_mask_loss_stats")
         ctx.save_for_backward(x, t, stats)
         ctx.wgts = [float(w) for w in wgts]
-        st = stats.cpu()
-        bce = st[:, 0] / hw
-        num = 2 * st[:, 1] / 1000 + 1e-6
-        den = st[:, 2] / 1000 + st[:, 3] / 1000 + 1e-6
-        return torch.stack([bce, 1 - num / den], dim=1).to(x.device)
+        # four sums per sample -> {bce, dice}: a handful of n-element device ops (scalar plumbing; a host round trip here
+        # would drain the launch queue once per frame and hand)
+        bce = stats[:, 0] / hw
+        num = 2 * stats[:, 1] / 1000 + 1e-6
+        den = stats[:, 2] / 1000 + stats[:, 3] / 1000 + 1e-6
+        return torch.stack([bce, 1 - num / den], dim=1)
 
     @staticmethod
     def backward(ctx, g):
         lib = load_library()
         x, t, stats = ctx.saved_tensors
         n, hw = x.shape
-        gh = g.cpu()
+        coef = g.to(torch.float32).contiguous()   # [n, 2] upstream gradients of {bce, dice}: read by the kernel, not by the host
         dx = torch.empty_like(x)
         for i in range(n):
-            check(lib.haff_mask_loss_grad(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), dx[i].data_ptr(), 1, hw,
-                                          ctx.wgts[i], float(gh[i, 0]), float(gh[i, 1]), _s()), "haff_mask_loss_grad")
+            check(lib.haff_mask_loss_grad_dev(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), dx[i].data_ptr(), 1, hw,
+                                              ctx.wgts[i], coef[i].data_ptr(), _s()), "haff_mask_loss_grad_dev")
         return dx, None, None
 
 
@@ -699,11 +703,7 @@ class TaxonomyCEFn(Function):
     @staticmethod
     def backward(ctx, g, _gp):
         (dz,) = ctx.saved_tensors
-        gh = g.cpu()
-        out = torch.empty_like(dz)
-        for i in range(dz.shape[0]):  # per-row upstream scalar (rows = samples of a micro-batch)
-            out[i] = axpby(dz[i], None, float(gh[i]), 0.0)
-        return out, None
+        return dz * g.to(dz.dtype)[:, None], None   # per-row upstream scalar, applied on the device
 
 
 taxonomy_ce = TaxonomyCEFn.apply

@@ -414,9 +414,12 @@ __global__ void mask_loss_stats_kernel(const float* x, const float* t, float* st
     atomicAdd(stats + s * 4 + 2, c); atomicAdd(stats + s * 4 + 3, d);
   }
 }
+// coef (device, f32 [n_samples][2], may be null): the upstream gradients of {bce, dice}; they multiply c_bce / c_dice, so the
+// caller never has to read them back to the host (a read-back at the head of backward drains the launch queue)
 __global__ void mask_loss_grad_kernel(const float* x, const float* t, const float* stats, float* dx, long n, float wgt,
-                                      float c_bce, float c_dice) {
+                                      float c_bce, float c_dice, const float* coef) {
   const long s = blockIdx.y;
+  if (coef) { c_bce *= coef[2 * s]; c_dice *= coef[2 * s + 1]; }
   const float sum_pt = stats[s * 4 + 1], sum_p = stats[s * 4 + 2], sum_t = stats[s * 4 + 3];
   const float num = 2.f * sum_pt / 1000.f + 1e-6f, den = sum_p / 1000.f + sum_t / 1000.f + 1e-6f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -530,7 +533,8 @@ __global__ void sumsq_kernel(const T* g, float* out, long n) {
 // gradient scaled by gscale (clipping / accumulation average), optional low-precision copy of the parameter.
 template <typename TG, typename TP>
 __global__ void adamw_kernel(float* master, float* m, float* v, const TG* g, TP* param_lp, long n, float lr, float b1, float b2,
-                             float eps, float wd, float bc1, float bc2, float gscale) {
+                             float eps, float wd, float bc1, float bc2, float gscale, const float* gscale_dev) {
+  if (gscale_dev) gscale *= *gscale_dev;   // the clip coefficient straight from the device (no host read of the gradient norm)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gr = elem<TG>::ld(g + i) * gscale;
     float w = master[i];
@@ -693,7 +697,14 @@ extern "C" int haff_mask_loss_grad(const float* x, const float* t, const float* 
                                    float c_bce, float c_dice, void* stream) {
   if (n_samples <= 0 || n <= 0) return HAFF_ERR_BAD_ARG;
   dim3 g(grid_for(n, 256) > 256 ? 256 : grid_for(n, 256), n_samples), b(256);
-  hipLaunchKernelGGL(mask_loss_grad_kernel, g, b, 0, HS(stream), x, t, stats, dx, n, wgt, c_bce, c_dice);
+  hipLaunchKernelGGL(mask_loss_grad_kernel, g, b, 0, HS(stream), x, t, stats, dx, n, wgt, c_bce, c_dice, (const float*)nullptr);
+  return haff_check_launch();
+}
+extern "C" int haff_mask_loss_grad_dev(const float* x, const float* t, const float* stats, float* dx, int n_samples, long n, float wgt,
+                                       const float* coef, void* stream) {
+  if (n_samples <= 0 || n <= 0 || !coef) return HAFF_ERR_BAD_ARG;
+  dim3 g(grid_for(n, 256) > 256 ? 256 : grid_for(n, 256), n_samples), b(256);
+  hipLaunchKernelGGL(mask_loss_grad_kernel, g, b, 0, HS(stream), x, t, stats, dx, n, wgt, 1.f, 1.f, coef);
   return haff_check_launch();
 }
 extern "C" int haff_resize_bilinear_bwd(const float* dout, float* din, int N, int Hs, int Ws, int Hc, int Wc, int Ho, int Wo,
@@ -717,16 +728,29 @@ extern "C" int haff_sumsq(const void* g, float* out, long n, int dtype, void* st
   return haff_check_launch();
 }
 // g_dtype: gradient storage (0 bf16 / 1 f32); lp_dtype: -1 none, 0 bf16 copy of the updated parameter
-extern "C" int haff_adamw_step(float* master, float* m, float* v, const void* g, void* param_lp, long n, float lr, float beta1,
-                               float beta2, float eps, float wd, int step, float gscale, int g_dtype, int lp_dtype, void* stream) {
+static int adamw_launch(float* master, float* m, float* v, const void* g, void* param_lp, long n, float lr, float beta1,
+                               float beta2, float eps, float wd, int step, float gscale, const float* gscale_dev, int g_dtype, int lp_dtype, void* stream) {
   if (n <= 0 || step <= 0) return HAFF_ERR_BAD_ARG;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   dim3 gr(grid_for(n, 256)), b(256);
   if (g_dtype == 0)
-    hipLaunchKernelGGL((adamw_kernel<bf16_t, bf16_t>), gr, b, 0, HS(stream), master, m, v, (const bf16_t*)g, lp_dtype == 0 ? (bf16_t*)param_lp : nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale);
+    hipLaunchKernelGGL((adamw_kernel<bf16_t, bf16_t>), gr, b, 0, HS(stream), master, m, v, (const bf16_t*)g, lp_dtype == 0 ? (bf16_t*)param_lp : nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gscale_dev);
   else
-    hipLaunchKernelGGL((adamw_kernel<float, bf16_t>), gr, b, 0, HS(stream), master, m, v, (const float*)g, lp_dtype == 0 ? (bf16_t*)param_lp : nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale);
+    hipLaunchKernelGGL((adamw_kernel<float, bf16_t>), gr, b, 0, HS(stream), master, m, v, (const float*)g, lp_dtype == 0 ? (bf16_t*)param_lp : nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gscale_dev);
   return haff_check_launch();
+}
+
+extern "C" int haff_adamw_step(float* master, float* m, float* v, const void* g, void* param_lp, long n, float lr, float beta1,
+                               float beta2, float eps, float wd, int step, float gscale, int g_dtype, int lp_dtype, void* stream) {
+  return adamw_launch(master, m, v, g, param_lp, n, lr, beta1, beta2, eps, wd, step, gscale, nullptr, g_dtype, lp_dtype, stream);
+}
+// the same with the gradient scale multiplied by a device scalar (the clip coefficient min(1, 1 / (norm + 1e-6)) computed on the
+// device: the optimizer launches are then queued behind backward without the host waiting for the norm)
+extern "C" int haff_adamw_step_dev(float* master, float* m, float* v, const void* g, void* param_lp, long n, float lr, float beta1,
+                                   float beta2, float eps, float wd, int step, float gscale, const float* gscale_dev, int g_dtype,
+                                   int lp_dtype, void* stream) {
+  if (!gscale_dev) return HAFF_ERR_BAD_ARG;
+  return adamw_launch(master, m, v, g, param_lp, n, lr, beta1, beta2, eps, wd, step, gscale, gscale_dev, g_dtype, lp_dtype, stream);
 }
 
 // z, t f32 [rows][C<=8]; probs (may be null) = softmax(z); loss f32[rows]; dz (may be null) = d loss / d z

@@ -117,11 +117,14 @@ _PROTOS = {
     "haff_rope": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_cross_entropy": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_int, c_void_p],
     "haff_mask_loss_stats": [c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p],
+    "haff_mask_loss_grad_dev": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p, c_void_p],
     "haff_mask_loss_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_float, c_float, c_void_p],
     "haff_resize_bilinear_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_scatter_add_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "haff_taxonomy_ce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "haff_sumsq": [c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "haff_adamw_step_dev": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
+                            c_int, c_float, c_void_p, c_int, c_int, c_void_p],
     "haff_adamw_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                         c_int, c_float, c_int, c_int, c_void_p],
 }

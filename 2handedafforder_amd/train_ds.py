@@ -367,13 +367,14 @@ def main(argv):
             reducer.finish()
             grads = reducer.grads()
             gscale = 1.0 / args.grad_accumulation_steps
-            norm = float(T.grad_norm(grads)) * gscale
-            gscale *= min(1.0, 1.0 / (norm + 1e-6))                                  # gradient_clipping: 1.0
+            # gradient_clipping: 1.0 — the coefficient min(1, 1 / (norm + 1e-6)) is computed and consumed on the device (the
+            # optimizer launches queue up behind backward; no host read of the norm)
+            clip = T.clip_coef_device(T.grad_norm(grads) * gscale, 1.0)
             lr = T.warmup_decay_lr(global_step, total_steps, args.lr)
             for k, p in model.named_parameters():
                 if p.grad is not None:
                     T.adamw_step(states[k], p.grad, lr=lr, betas=(args.beta1, args.beta2), eps=1e-8, wd=0.0, gscale=gscale,
-                                 param_lp=p.data)
+                                 param_lp=p.data, gscale_dev=clip)
             global_step += 1
             meters[0].update(time.time() - end)
             end = time.time()

@@ -212,7 +212,35 @@ class LisaTrainable:
                 taxonomies_list, label_list, resize_list, inference=False, **kwargs):
         cfg, dev = self.cfg, self.device
         base = self.base
-        input_ids, labels, offset = input_ids.to(dev), labels.to(dev), offset.to(dev)
+        # Host-side bookkeeping FIRST, from host copies of the small integer inputs (one early read of input_ids / offset /
+        # taxonomies when they live on the device): image-token positions, [SEG] rows, prompts per frame, loss weights. Read
+        # back mid-forward (int(argmax), nonzero, tolist, .cpu()) each of them drained the launch queue — behind the Llama
+        # forward the ~700 small launches of the two mask decoders then went out one by one with the GPU waiting on the host.
+        ids_host, off_host = input_ids.detach().cpu(), [int(v) for v in offset.detach().cpu().tolist()]
+        tax_host = taxonomies_list.detach().float().cpu()
+        img_pos = [int((ids_host[b] == IMAGE_TOKEN_INDEX).int().argmax()) for b in range(ids_host.shape[0])]
+        seg_host = ids_host[:, 1:] == cfg.seg_token_idx
+        seg_host = torch.cat([torch.zeros((ids_host.shape[0], N_IMG_PAD), dtype=torch.bool), seg_host,
+                              torch.zeros((ids_host.shape[0], 1), dtype=torch.bool)], dim=1)
+        b_idx_h, t_idx_h = seg_host.nonzero(as_tuple=True)
+        counts_h = seg_host.int().sum(-1)
+        seg_off = [int(v) for v in torch.cat([torch.zeros(1, dtype=torch.long), counts_h.cumsum(-1)], 0)[off_host].tolist()]
+        lab_host = labels.detach().cpu()
+        bsz = len(off_host) - 1
+        lab = []
+        for b in range(ids_host.shape[0]):   # llava_arch.py:185-208 on the labels: image rows are -100; then shift by one
+            p = img_pos[b]
+            lb = torch.cat([lab_host[b, :p], torch.full((N_IMG_PAD + 1,), -100, dtype=lab_host.dtype), lab_host[b, p + 1:]])
+            lab.append(torch.cat([lb[1:], torch.full((1,), -100, dtype=lab_host.dtype)]))
+        lab = torch.stack(lab).reshape(-1)
+        n_valid = int((lab >= 0).sum())
+        # ... and every host -> device copy of the step up front as well (a pageable copy waits for the stream it is ordered on)
+        input_ids, lab_dev = input_ids.to(dev), lab.to(dev)
+        b_idx, t_idx = b_idx_h.to(dev), t_idx_h.to(dev)
+        frame_idx = torch.tensor([i for i in range(bsz) for _ in range(seg_off[i + 1] - seg_off[i])], dtype=torch.long).to(dev)
+        gt_l = torch.stack([t.to(dev) for t in masks_list_left], 0).float()
+        gt_r = torch.stack([t.to(dev) for t in masks_list_right], 0).float()
+        gt_tax = taxonomies_list.to(dev).float()
         # The frozen SAM encoder feeds only the mask decoders: it runs on the model's side stream beside the CLIP tower and
         # the Llama forward, whose M = conversations x tokens products leave CUs idle (2808 x 4096 outputs = 176 tiles of
         # 256 x 256 on 256 CUs), and is joined in front of the decoders.
@@ -225,43 +253,29 @@ class LisaTrainable:
             with torch.cuda.stream(side):
                 emb = base.get_visual_embs(images)                                # frozen SAM encoder (LISA.py:191)
             n_conv = input_ids.shape[0]
-            reps = (offset[1:] - offset[:-1]).tolist()
+            reps = [off_host[i + 1] - off_host[i] for i in range(len(off_host) - 1)]
             clip_rep = torch.cat([images_clip[i:i + 1].expand(r, -1, -1, -1) for i, r in enumerate(reps)], 0)
             img = base.encode_images(clip_rep)                                     # frozen CLIP + projector
-        bsz = emb.shape[0]
-        assert bsz == len(offset) - 1
+        assert emb.shape[0] == bsz
         L = input_ids.shape[1]
         T = L + N_IMG_PAD
         # splice (llava_arch.py:185-208): [embed(ids[:p]) ; image features ; embed(ids[p+1:])]
-        is_img = input_ids == IMAGE_TOKEN_INDEX
         tok = A.embed(self.params["model.embed_tokens.weight"], input_ids)       # sentinel rows are dropped below
         rows = []
         for b in range(n_conv):
-            p = int(is_img[b].int().argmax())
+            p = img_pos[b]
             rows.append(torch.cat([tok[b, :p], img[b], tok[b, p + 1:]], dim=0))
         x = torch.stack(rows, 0).reshape(n_conv * T, cfg.llm.hidden)
         hidden = self._llm(x, n_conv, T)
         out = {}
         if not inference:
             logits = A.linear(hidden, self.params["lm_head.weight"])
-            lab = []
-            for b in range(n_conv):
-                p = int(is_img[b].int().argmax())
-                lb = torch.cat([labels[b, :p], torch.full((N_IMG_PAD + 1,), -100, dtype=labels.dtype, device=dev), labels[b, p + 1:]])
-                lab.append(torch.cat([lb[1:], torch.full((1,), -100, dtype=labels.dtype, device=dev)]))  # shift by one
-            ce = A.cross_entropy(logits, torch.stack(lab).reshape(-1))
+            ce = A.cross_entropy(logits, lab_dev, n_valid)
         # [SEG] rows (LISA.py:195-207) and text_hidden_fcs on those rows only
-        m = input_ids[:, 1:] == cfg.seg_token_idx
-        m = torch.cat([torch.zeros((n_conv, N_IMG_PAD), dtype=torch.bool, device=dev), m,
-                       torch.zeros((n_conv, 1), dtype=torch.bool, device=dev)], dim=1)
-        b_idx, t_idx = m.nonzero(as_tuple=True)
         sel = hidden.view(n_conv, T, -1)[b_idx, t_idx]
         P = self.params
         h = A.act(A.linear(sel, P["model.text_hidden_fcs.0.0.weight"], P["model.text_hidden_fcs.0.0.bias"]), ACT_RELU)
         pred = A.linear(h, P["model.text_hidden_fcs.0.2.weight"], P["model.text_hidden_fcs.0.2.bias"])
-        counts = m.int().sum(-1)
-        seg_off = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), counts.cumsum(-1)], 0)[offset].tolist()
-        frame_idx = torch.cat([torch.full((seg_off[i + 1] - seg_off[i],), i, dtype=torch.long, device=dev) for i in range(bsz)])
         Pn = pred.shape[0]
         N, C = emb.shape[1], emb.shape[2]
         if side is not cur:
@@ -279,18 +293,14 @@ class LisaTrainable:
             for lo, dst, side in ((lo_l, pl, "left"), (lo_r, pr, "right")):
                 up = A.resize_bilinear(lo[a:b], lo.shape[-2:], (S, S))
                 dst.append(A.resize_bilinear(up, resize_list[i], tuple(label_list[i][side].shape)))
-        gt_l = torch.stack([t.to(dev) for t in masks_list_left], 0).float()
-        gt_r = torch.stack([t.to(dev) for t in masks_list_right], 0).float()
-        gt_tax = taxonomies_list.to(dev).float()
         tax_loss_rows, tax_probs = A.taxonomy_ce(tax_logits, gt_tax[frame_idx])
         if inference:
             return {"pred_masks_left": torch.stack(pl, 0), "pred_masks_right": torch.stack(pr, 0),
                     "pred_taxonomies": torch.stack([tax_probs[seg_off[i]:seg_off[i + 1]] for i in range(bsz)]),
                     "gt_masks_left": gt_l, "gt_masks_right": gt_r, "gt_taxonomies": gt_tax}
         # losses (LISA.py:346-430)
-        gt_host = gt_tax.cpu()
-        w_l = (gt_host[:, 0] + gt_host[:, 2] + gt_host[:, 3]).tolist()
-        w_r = (gt_host[:, 1] + gt_host[:, 2] + gt_host[:, 3]).tolist()
+        w_l = (tax_host[:, 0] + tax_host[:, 2] + tax_host[:, 3]).tolist()
+        w_r = (tax_host[:, 1] + tax_host[:, 2] + tax_host[:, 3]).tolist()
         num_masks = 0
         bce_l = bce_r = dice_l = dice_r = 0.0
         for i in range(bsz):

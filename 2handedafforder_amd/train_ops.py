@@ -20,17 +20,24 @@ class AdamWState:
         self.step = 0
 
 
-def adamw_step(state, grad, lr, betas=(0.9, 0.95), eps=1e-8, wd=0.0, gscale=1.0, param_lp=None):
-    """One fused AdamW update (torch.optim.AdamW semantics); optionally refreshes a bf16 copy of the parameter."""
+def adamw_step(state, grad, lr, betas=(0.9, 0.95), eps=1e-8, wd=0.0, gscale=1.0, param_lp=None, gscale_dev=None):
+    """One fused AdamW update (torch.optim.AdamW semantics); optionally refreshes a bf16 copy of the parameter.
+    gscale_dev: device fp32 scalar multiplied into gscale inside the kernel (clip_coef_device: no host read of the norm)."""
     lib = load_library()
     state.step += 1
     grad = grad.contiguous()
     lp_ptr, lp_dt = 0, -1
     if param_lp is not None and param_lp.dtype == torch.bfloat16:
         lp_ptr, lp_dt = param_lp.data_ptr(), 0
-    check(lib.haff_adamw_step(state.master.data_ptr(), state.m.data_ptr(), state.v.data_ptr(), grad.data_ptr(), lp_ptr,
-                              state.master.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(wd),
-                              state.step, float(gscale), _dt(grad), lp_dt, _s()), "haff_adamw_step")
+    if gscale_dev is not None:
+        assert gscale_dev.dtype == torch.float32 and gscale_dev.numel() == 1
+        check(lib.haff_adamw_step_dev(state.master.data_ptr(), state.m.data_ptr(), state.v.data_ptr(), grad.data_ptr(), lp_ptr,
+                                      state.master.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(wd),
+                                      state.step, float(gscale), gscale_dev.data_ptr(), _dt(grad), lp_dt, _s()), "haff_adamw_step_dev")
+    else:
+        check(lib.haff_adamw_step(state.master.data_ptr(), state.m.data_ptr(), state.v.data_ptr(), grad.data_ptr(), lp_ptr,
+                                  state.master.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(wd),
+                                  state.step, float(gscale), _dt(grad), lp_dt, _s()), "haff_adamw_step")
     if param_lp is not None and param_lp.dtype == torch.float32:
         param_lp.copy_(state.master)  # fp32 parameters alias the master values (plain copy)
 
@@ -43,6 +50,12 @@ def grad_norm(grads):
         g = g.contiguous()
         check(lib.haff_sumsq(g.data_ptr(), acc.data_ptr(), g.numel(), _dt(g), _s()), "haff_sumsq")
     return acc.sqrt()
+
+
+def clip_coef_device(norm, max_norm=1.0):
+    """min(1, max_norm / (norm + 1e-6)) of a device-scalar gradient norm, as a device fp32 scalar (torch.nn.utils.clip_grad_norm_'s
+    coefficient; gradient clipping 1.0 of the reference's engine config, train_ds.py:381) — for adamw_step(gscale_dev=)."""
+    return torch.clamp(max_norm / (norm.to(torch.float32) + 1e-6), max=1.0).reshape(1)
 
 
 def warmup_decay_lr(step, total_steps, base_lr, warmup_steps=100, warmup_min_lr=0.0):

@@ -450,10 +450,11 @@ def train_main(args):
         out = model(**batch)
         out["loss"].backward()
         reducer.finish()
-        norm = float(T.grad_norm(reducer.grads()))      # the step's one host read (clip_grad_norm's scalar, train_ds.py:381)
-        gscale = min(1.0, 1.0 / (norm + 1e-6))
+        # clip_grad_norm's coefficient (train_ds.py:381) stays on the device: the optimizer launches queue up behind backward
+        # instead of waiting for a host read of the norm (the timed region's host reads are the step-start copies of the ids)
+        clip = T.clip_coef_device(T.grad_norm(reducer.grads()), 1.0)
         for k, p in named:
-            T.adamw_step(states[k], p.grad, lr=3e-4, gscale=gscale, param_lp=p.data)
+            T.adamw_step(states[k], p.grad, lr=3e-4, gscale=1.0, param_lp=p.data, gscale_dev=clip)
         losses.append(out["loss"].detach())
     for _ in range(args.warmup):
         step()

@@ -326,6 +326,9 @@ int haff_cross_entropy(const void* logits, long ld, const long* labels, float* r
 int haff_mask_loss_stats(const float* x, const float* t, float* stats, int n_samples, long n, float wgt, void* stream);
 int haff_mask_loss_grad(const float* x, const float* t, const float* stats, float* dx, int n_samples, long n, float wgt,
                         float c_bce, float c_dice, void* stream);
+/* the same with the upstream gradients of {bce, dice} read from device memory (coef f32 [n_samples][2]): no host read-back */
+int haff_mask_loss_grad_dev(const float* x, const float* t, const float* stats, float* dx, int n_samples, long n, float wgt,
+                            const float* coef, void* stream);
 /* taxonomy loss (LISA.py:414-417): CrossEntropyLoss on the already soft-maxed probabilities p = softmax(z) with a soft
  * target t: loss[r] = -sum_c t_c log_softmax(p)_c; probs / dz may be null; C <= 8 */
 int haff_taxonomy_ce(const float* z, const float* t, float* probs, float* loss, float* dz, int rows, int C, void* stream);
@@ -339,6 +342,10 @@ int haff_sumsq(const void* g, float* out, long n, int dtype, void* stream);
 /* fused AdamW on fp32 master weights (+ optional bf16 copy), torch semantics, gradient pre-scaled by gscale */
 int haff_adamw_step(float* master, float* m, float* v, const void* g, void* param_lp, long n, float lr, float beta1,
                     float beta2, float eps, float wd, int step, float gscale, int g_dtype, int lp_dtype, void* stream);
+/* the same, the gradient scale multiplied by *gscale_dev (device f32: the clip coefficient computed on the device) */
+int haff_adamw_step_dev(float* master, float* m, float* v, const void* g, void* param_lp, long n, float lr, float beta1,
+                        float beta2, float eps, float wd, int step, float gscale, const float* gscale_dev, int g_dtype,
+                        int lp_dtype, void* stream);
 
 #ifdef __cplusplus
 }

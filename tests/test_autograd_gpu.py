@@ -409,4 +409,14 @@ def test_adamw_matches_torch(dev):
         opt.step()
         T.adamw_step(state, g, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, wd=0.0, gscale=1.0)
     _close(state.master, ref.detach(), 1e-6, "adamw")
+    # the clip coefficient from the device (haff_adamw_step_dev) = the same update with the host float
+    g = _rand((1000,), dev, torch.float32, 70, 5.0)
+    s_host, s_dev = T.AdamWState(p.clone()), T.AdamWState(p.clone())
+    norm = T.grad_norm([g])
+    coef = T.clip_coef_device(norm, 1.0)
+    T.adamw_step(s_host, g, lr=1e-3, gscale=0.5 * min(1.0, 1.0 / (float(norm) + 1e-6)))
+    T.adamw_step(s_dev, g, lr=1e-3, gscale=0.5, gscale_dev=coef)
+    assert float(coef) < 1.0
+    _close(s_dev.master, s_host.master, 1e-6, "adamw with a device clip coefficient")
+    _close(s_dev.v, s_host.v, 1e-5, "adamw v with a device clip coefficient")
     assert abs(T.grad_norm([g, g]).item() - math.sqrt(2) * g.norm().item()) < 1e-2
