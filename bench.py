@@ -461,6 +461,13 @@ def train_main(args):
     elapsed = hdist.timed_steps(step, args.steps, device)
     ms_per_step = 1e3 * elapsed / args.steps
     sps = world * b * args.steps / elapsed
+    # how long the host needs to ENQUEUE one step on an idle GPU (no read-back waits on device work then): the step is GPU-bound
+    # while this stays below ms_per_step
+    torch.cuda.synchronize()
+    t_host = time.time()
+    step()
+    host_enqueue_ms = 1e3 * (time.time() - t_host)
+    torch.cuda.synchronize()
     if rank == 0:
         with GemmMeter() as meter:
             step()
@@ -479,6 +486,7 @@ def train_main(args):
                            "parallelism": "sample-sharded DDP x%d (all-reduce of %.2f GB of bf16/fp32 gradients per step in %d buckets)" %
                                           (world, sum(f.numel() * f.element_size() for f in reducer.grads()) / 1e9, len(reducer.buckets))},
                 "samples_per_s_per_gpu": sps / world,
+                "host_enqueue_ms_per_step": host_enqueue_ms,
                 "loss_first_last": [float(losses[0]), float(losses[-1])],
                 "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (every haff_gemm_bf16 launch with M > 64 of the step: forward, dX and dW products)",
                              "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
