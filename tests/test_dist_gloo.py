@@ -292,3 +292,16 @@ def test_bucket_layout_with_alternating_dtypes():
         assert p.grad is not None and p.grad.shape == p.shape
         b = red.buckets[red.bucket_of[id(p)]]
         assert p.grad.untyped_storage().data_ptr() == b["flat"].untyped_storage().data_ptr()
+
+
+def test_clip_coefficient_on_the_device_matches_the_host_rule():
+    """train_ops.clip_coef_device = min(1, max_norm / (norm + 1e-6)) as a one-element fp32 tensor (the clip coefficient stays
+    on the device so that the optimizer launches do not wait for a host read of the gradient norm); lr schedule sanity."""
+    from haff import train_ops as T
+    for norm in (0.0, 0.3, 1.0, 4.0, 123.5):
+        want = min(1.0, 1.0 / (norm + 1e-6))
+        got = T.clip_coef_device(torch.tensor(norm, dtype=torch.float64), 1.0)
+        assert got.dtype == torch.float32 and got.shape == (1,)
+        assert abs(float(got) - want) <= 1e-6 * max(want, 1.0)
+    assert abs(float(T.clip_coef_device(torch.tensor(10.0), 5.0)) - 0.5) < 1e-6
+    assert T.warmup_decay_lr(0, 1000, 3e-4) == 0.0 and abs(T.warmup_decay_lr(100, 1000, 3e-4) - 3e-4) < 1e-12
