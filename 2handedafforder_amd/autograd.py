@@ -75,6 +75,28 @@ def bgemm(a, w, out=None, out_dtype=None):
     return out
 
 
+def gemm_tn_supported(a, b):
+    return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.stride(0) % 8 == 0
+            and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def gemm_tn(a, b, out_dtype=None):
+    """a [M, N1], b [M, N2] (bf16, row strides free) -> a^T @ b [N1, N2]: the contraction runs over the ROWS, no transposed copy of
+    either operand (haff_gemm_tn_bf16)."""
+    lib = load_library()
+    assert gemm_tn_supported(a, b)
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    out = torch.empty((N1, N2), dtype=out_dtype or a.dtype, device=a.device)
+    n_ws = lib.haff_gemm_tn_workspace_elems(M, N1, N2)
+    assert n_ws > 0
+    ws = torch.empty((n_ws,), dtype=torch.float32, device=a.device)
+    check(lib.haff_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), M, N1, N2, ws.data_ptr(), n_ws, out.data_ptr(),
+                                1 if out.dtype == torch.float32 else 0, _s()), "haff_gemm_tn_bf16")
+    return out
+
+
 def colsum(x2d):
     lib = load_library()
     x2d = x2d.contiguous()
@@ -106,6 +128,9 @@ def axpby(a, b, alpha, beta):
 # ------------------------------------------------------------------------------------------------------------------
 # Functions
 # ------------------------------------------------------------------------------------------------------------------
+TN_WEIGHT_GRADIENTS = True   # False: dW through haff_transpose + the NT product (A/B, tests)
+
+
 class LinearFn(Function):
     """y = x @ w.T + bias (+ resid). w_t: optional precomputed w.T (frozen weights keep one resident)."""
 
@@ -134,10 +159,13 @@ class LinearFn(Function):
                 dyk[:, :N] = dy
             dx = ops.linear(dyk, w_t)
         if ctx.needs_input_grad[1]:
-            Mp = _pad8(M)
-            dy_t = transpose(dy, Rp=Mp)[0]   # [N, Mp]
-            x_t = transpose(x, Rp=Mp)[0]     # [K, Mp]
-            dw = ops.linear(dy_t, x_t)       # [N, K]
+            if TN_WEIGHT_GRADIENTS and M >= 16 and gemm_tn_supported(dy, x):
+                dw = gemm_tn(dy, x)              # [N, K] = dy^T . x, both operands read as they lie (csrc/gemm_tn.hip)
+            else:
+                Mp = _pad8(M)
+                dy_t = transpose(dy, Rp=Mp)[0]   # [N, Mp]
+                x_t = transpose(x, Rp=Mp)[0]     # [K, Mp]
+                dw = ops.linear(dy_t, x_t)       # [N, K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)
         if ctx.has_resid and ctx.needs_input_grad[3]:

@@ -64,6 +64,8 @@ _PROTOS = {
                                 c_void_p, c_void_p],
     "haff_attention_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
+    "haff_gemm_tn_workspace_elems": [c_long, c_int, c_int],
+    "haff_gemm_tn_bf16": [c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p],
     "haff_lora_qkv_rope_fwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_long, c_long, c_int, c_int, c_int, c_float, c_void_p],
     "haff_lora_qkv_rope_bwd": [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p],

@@ -143,6 +143,16 @@ int haff_attention_bwd_bf16(const void* q, const void* k, const void* v, const v
                             void* dq, void* dk, void* dv, float* workspace, long workspace_elems, long ld, int B, int H, int Nq,
                             int Nk, int d, float scale, int causal, int q_pos0, void* stream);
 
+/* TN product of the fine-tune step: out [N1][N2] = A^T . B, A [M][lda] (N1 columns), B [M][ldb] (N2 columns), bf16, contraction
+ * over the M rows — the weight gradient dW = dY^T . X of a trainable Linear (torch.nn.Linear under autograd: text_hidden_fcs and
+ * the mask decoders, train_ds.py:232-244) without transposed copies of dY and X (csrc/gemm_tn.hip: fragments through the
+ * transposing LDS read). N1, N2, lda, ldb % 8 == 0, 16-byte aligned bases, else HAFF_ERR_UNSUPPORTED (the caller then takes
+ * haff_transpose + haff_gemm_bf16). out contiguous, bf16 or f32; workspace f32 with haff_gemm_tn_workspace_elems values
+ * (split partials, added in index order: repeatable to the bit). */
+int haff_gemm_tn_workspace_elems(long M, int N1, int N2);
+int haff_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, long M, int N1, int N2, float* workspace,
+                      long workspace_elems, void* out, int out_f32, void* stream);
+
 /* rank-r adapter path of the fine-tune step (peft LoRA on q_proj / v_proj: 2Haff/train_ds.py:192-230; RoPE of the adapted
  * projections: llava_llama.py -> transformers LlamaAttention). bf16, head dim d == 128, rank <= 8 per adapter; see csrc/lora.hip.
  * tT / dtT: [16][ld] = the TRANSPOSED rank activations, rows 0..7 the q adapter, 8..15 the v adapter (unused ranks zero);

@@ -106,6 +106,39 @@ def test_act_swiglu_norms(dev, dtype):
     _close(a.grad, ar.grad, tol, "rms dx")
 
 
+@pytest.mark.parametrize("M,N1,N2,strided", [(300, 8, 8, False), (1000, 256, 128, False), (4133, 136, 264, True), (70000, 256, 256, False),
+                                             (513, 32, 2048, True)])
+def test_gemm_tn(dev, M, N1, N2, strided):
+    """haff_gemm_tn_bf16: a^T @ b with the contraction over the rows (the weight gradient of a trainable Linear) against fp32
+    torch; ragged row counts (partial last slab / split), tiles cut by N1 / N2, operands that are column slices of wider
+    tensors; a second launch gives the same bits (split partials are added in index order); LinearFn takes it for dW."""
+    A = _ag()
+    a = _rand((M, N1 + (24 if strided else 0)), dev, torch.bfloat16, 80)
+    b = _rand((M, N2 + (8 if strided else 0)), dev, torch.bfloat16, 81)
+    av, bv = (a[:, 16:16 + N1], b[:, :N2]) if strided else (a, b)
+    assert A.gemm_tn_supported(av, bv)
+    out = A.gemm_tn(av, bv)
+    ref = av.float().t() @ bv.float()
+    _close(out, ref, 1.2e-2, "gemm_tn bf16 out")
+    out32 = A.gemm_tn(av, bv, torch.float32)
+    _close(out32, ref, 2e-3 if M < 5000 else 4e-3, "gemm_tn f32 out")   # fp32 accumulation of bf16 products
+    assert torch.equal(A.gemm_tn(av, bv), out)
+    assert not A.gemm_tn_supported(a[:, 1:1 + N1], b[:, :N2])   # a misaligned column slice goes the transposing way
+    # through LinearFn: dW by the TN product equals dW by transposes + the NT product to bf16 rounding
+    if N1 <= 512:
+        x, w = _leaf(bv.contiguous()), _leaf(_rand((N1, N2), dev, torch.bfloat16, 82, N2 ** -0.5))
+        gy = av.contiguous()
+        A.linear(x, w).backward(gy)
+        x2, w2 = _leaf(x.detach()), _leaf(w.detach())
+        A.TN_WEIGHT_GRADIENTS = False
+        try:
+            A.linear(x2, w2).backward(gy)
+        finally:
+            A.TN_WEIGHT_GRADIENTS = True
+        _close(w.grad, w2.grad, 1.2e-2, "LinearFn dW: TN product vs transposes")
+        _close(w.grad, gy.float().t() @ x.detach().float(), 1.2e-2, "LinearFn dW vs fp32")
+
+
 @pytest.mark.parametrize("C", [4096, 5120])
 def test_norm_adjoints_llama_width(dev, C):
     """bf16 rows of 4096 / 5120 take the one-pass register-resident adjoint (norm_bwd_vec_kernel): RMSNorm and LayerNorm
