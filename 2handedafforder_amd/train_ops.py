@@ -118,9 +118,14 @@ class GradBucketReducer:
       dtype; every bucket owns ONE flat buffer in the gradients' own dtype and each p.grad is a VIEW into it: backward
       accumulates straight into the bucket (no cat, no up-cast, no copy back);
     * post-accumulate hooks count a bucket's arrivals; on the LAST micro-step of an accumulation window (begin(sync=True))
-      the bucket's async all-reduce (RCCL over xGMI on the GPU node, gloo in the CPU tests) is launched the moment its
-      last gradient lands, while backward continues into the earlier layers;
-    * finish() launches whatever never fired (tensors the loss does not reach), waits, and turns sums into means.
+      the bucket's async all-reduce (RCCL over xGMI on the GPU node, gloo in the CPU tests) is launched once its last
+      gradient has landed AND every lower-indexed bucket has been launched, while backward continues into the earlier layers;
+    * collectives are issued in BUCKET-INDEX ORDER ONLY, on every rank, whatever its autograd graph reached (the reference's
+      ZeRO-2 engine reduces fixed buckets in a fixed order, train_ds.py:372-393): a rank whose micro-batch has no [SEG] or no
+      left hand never sees some hooks fire, and a hook-arrival order would make it issue its all-reduces in a different
+      sequence than its peers — on RCCL a hang or silently mismatched reductions. A bucket that never completes on this
+      rank simply holds back the ones behind it until finish();
+    * finish() launches the rest in index order, waits, and turns sums into means.
     """
 
     def __init__(self, named_params, bucket_bytes=64 << 20):
@@ -152,7 +157,8 @@ class GradBucketReducer:
                 p.register_post_accumulate_grad_hook(self._on_grad)
             b["n"], b["pending"], b["work"] = len(b["params"]), len(b["params"]), None
         self.sync = False
-        self.launch_order = []     # bucket indices in the order their all-reduce was issued (tests / tracing)
+        self.next_launch = 0       # lowest bucket index whose all-reduce has not been issued in this window
+        self.launch_order = []     # bucket indices in the order their all-reduce was issued (always 0, 1, 2, ...; tests / tracing)
 
     def zero(self):
         for b in self.buckets:
@@ -162,30 +168,35 @@ class GradBucketReducer:
         """Call before each backward: sync=True on the micro-step whose gradients complete the accumulation window."""
         self.sync = bool(sync) and self.world > 1
         self.launch_order = []
+        self.next_launch = 0
         for b in self.buckets:
             b["pending"], b["work"] = b["n"], None
 
     def _launch(self, bi):
+        assert bi == self.next_launch, "all-reduces leave in bucket-index order on every rank"
         b = self.buckets[bi]
         b["work"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
         self.launch_order.append(bi)
+        self.next_launch = bi + 1
+
+    def _drain_ready(self):
+        while self.next_launch < len(self.buckets) and self.buckets[self.next_launch]["pending"] <= 0:
+            self._launch(self.next_launch)
 
     def _on_grad(self, p):
         if not self.sync:
             return
-        bi = self.bucket_of[id(p)]
-        b = self.buckets[bi]
+        b = self.buckets[self.bucket_of[id(p)]]
         b["pending"] -= 1
-        if b["pending"] == 0 and b["work"] is None:
-            self._launch(bi)
+        if b["pending"] == 0:
+            self._drain_ready()
 
     def finish(self):
         """After the last backward of the window: every bucket reduced and averaged in place (p.grad views see it)."""
         if self.world == 1:
             return
-        for bi, b in enumerate(self.buckets):
-            if b["work"] is None:
-                self._launch(bi)
+        while self.next_launch < len(self.buckets):   # buckets the loss did not (fully) reach on this rank, and all behind them
+            self._launch(self.next_launch)
         for b in self.buckets:
             b["work"].wait()
             b["flat"].div_(self.world)

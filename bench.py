@@ -461,6 +461,7 @@ def train_main(args):
     elapsed = hdist.timed_steps(step, args.steps, device)
     ms_per_step = 1e3 * elapsed / args.steps
     sps = world * b * args.steps / elapsed
+    n_ranks = rccl_ranks(device)
     # how long the host needs to ENQUEUE one step on an idle GPU (no read-back waits on device work then): the step is GPU-bound
     # while this stays below ms_per_step
     torch.cuda.synchronize()
@@ -485,7 +486,7 @@ def train_main(args):
                            "samples_per_step_per_gpu": b,
                            "parallelism": "sample-sharded DDP x%d (all-reduce of %.2f GB of bf16/fp32 gradients per step in %d buckets)" %
                                           (world, sum(f.numel() * f.element_size() for f in reducer.grads()) / 1e9, len(reducer.buckets))},
-                "samples_per_s_per_gpu": sps / world,
+                "samples_per_s_per_gpu": sps / world, "rccl_ranks": n_ranks,
                 "host_enqueue_ms_per_step": host_enqueue_ms,
                 "loss_first_last": [float(losses[0]), float(losses[-1])],
                 "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (every haff_gemm_bf16 launch with M > 64 of the step: forward, dX and dW products)",
@@ -516,10 +517,12 @@ def stub_main(args):
     for _ in range(args.warmup):
         step()
     elapsed = hdist.timed_steps(step, args.steps, None)
+    n_ranks = rccl_ranks(None)
     if rank == 0:
         line = base_line(world * B * args.steps / elapsed, world, args.steps, args.warmup, 1e3 * elapsed / args.steps,
                          "stub (sleep %.0f ms per step)" % args.stub_step_ms, B, {"stub": True})
         line["cpu_baseline"] = None
+        line["rccl_ranks"] = n_ranks
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -527,8 +530,41 @@ def stub_main(args):
         dist.destroy_process_group()
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves — the reference launches with
+    `deepspeed --master_port=24999 train_ds.py` (2Haff/README.md:69), i.e. one command. The parent has touched no GPU at this point
+    (no HIP call, no torch.cuda.is_available(): a process that initialised the GPU must not be the one that forks / execs rank
+    processes); it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same
+    flags>` as a CHILD, forwards rank 0's JSON line (the children inherit stdout) and exits with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // args.gpus)))
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %d ranks (%s)" % (args.gpus, args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rccl_ranks(device):
+    """Ranks that took part in one real all-reduce on the benchmark's process group (RCCL on the GPU node): every rank adds 1."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return 1
+    one = torch.ones((1,), dtype=torch.float32, device=device if device is not None else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    n = int(round(float(one.item())))
+    assert n == dist.get_world_size(), (n, dist.get_world_size())
+    return n
+
+
 def main(argv=None):
     exit_code = 0
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -563,6 +599,16 @@ def main(argv=None):
                          "over gloo on the CPU, to exercise the multi-rank fence / timing / reporting path without GPUs")
     args = ap.parse_args(argv)
 
+    # --gpus N must mean N ranks: under torchrun WORLD_SIZE says so; bare, this process becomes the launcher. Never an n_gpus: 1
+    # line for --gpus 8.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        return self_launch(args, argv)
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %s: refusing to report a line for a different rank "
+                         "count than the one asked for" % (args.gpus, env_world))
     if args.stub_step_ms is not None:
         return stub_main(args)
     if not torch.cuda.is_available():
@@ -607,6 +653,7 @@ def main(argv=None):
     out = outs[-1]
     ms_per_step = 1e3 * elapsed / args.steps
     fps = world * B * args.steps / elapsed
+    n_ranks = rccl_ranks(device)   # one real all-reduce over the group the timing fence used: the rank count that actually ran
 
     if rank == 0:
         flops_frame = SURVEY_FLOPS.get(cfg.name) or hflops.frame_flops(cfg, args.text_tokens, args.n_gen)["total"]
@@ -684,6 +731,7 @@ def main(argv=None):
                          "uint8 frames on the device inside the step" % (cfg.name, B, S, S, args.text_tokens, T_exp, args.n_gen),
                          B, {"hip_streams": 2 if model.overlap_streams else 1, "fp32_decoder_tail": bool(model.fp32_tail)})
         line["roofline"] = roofline
+        line["rccl_ranks"] = n_ranks
         # sanity of the produced masks (finite, right shapes)
         ok = all(m.shape == (1, S, S) and bool(torch.isfinite(m).all()) for m in out[1] + out[2])
         line["outputs_finite"] = ok

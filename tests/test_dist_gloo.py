@@ -153,7 +153,7 @@ def _half(batch, lo, hi):
     return out
 
 
-def _model_grad_worker(rank, world, port, q):
+def _model_grad_worker(rank, world, port, q, divergent=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     torch.set_num_threads(2)
@@ -174,13 +174,18 @@ def _model_grad_worker(rank, world, port, q):
     for micro in range(2):
         reducer.begin(sync=micro == 1)
         out = O.lisa_model_forward(osd, cfg, _half(batch, rank, rank + 1), lora=lora, lora_alpha=8.0)
-        (out["loss"] * 0.5).backward()
+        # divergent: rank 1's graph is the one a micro-batch without [SEG] / without masks produces — the language-model loss
+        # only, so text_hidden_fcs and both mask decoders never see a gradient (their hooks never fire on this rank)
+        loss = out["ce_loss"] if (divergent and rank == 1) else out["loss"]
+        (loss * 0.5).backward()
         if micro == 0:
             assert fired_in_backward == []
     n_hook = len(fired_in_backward)
     reducer.finish()
-    if rank == 0:
-        names = [b["names"] for b in reducer.buckets]
+    names = [b["names"] for b in reducer.buckets]
+    if divergent:
+        q.put((rank, {k: p.grad.detach().numpy().copy() for k, p in named}, n_hook, list(reducer.launch_order), names))
+    elif rank == 0:
         q.put(({k: p.grad.detach().numpy().copy() for k, p in named}, n_hook, list(reducer.launch_order), names))  # numpy: no fd passing
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -228,6 +233,62 @@ def test_two_rank_model_gradients_equal_single_process_on_the_concatenated_batch
     assert flat_names.index("model.layers.1.self_attn.q_proj.lora_A") < flat_names.index("model.layers.0.self_attn.q_proj.lora_A")
 
 
+def test_two_rank_reducer_with_rank_divergent_graphs_issues_the_same_collective_sequence():
+    """A rank whose micro-batch reaches a different parameter set (no [SEG], a missing hand: here rank 1 back-propagates the
+    language-model loss only) must issue its all-reduces in the same order as its peers: bucket-index order, whatever the hooks'
+    arrival order was (the reference's ZeRO-2 engine reduces fixed buckets in a fixed order, train_ds.py:372-393). Gradients ==
+    the mean of the two ranks' gradients computed in one process."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from haff import config as hcfg, weights as hw
+    from oracle import lisa_oracle as O
+    from test_train_gpu import make_batch
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_grad_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, got, n_hook, order, names = q.get(timeout=600)
+        res[rank] = (got, n_hook, order, names)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n_buckets = len(res[0][3])
+    assert n_buckets >= 4
+    assert res[0][2] == list(range(n_buckets)) and res[1][2] == list(range(n_buckets))   # same sequence on both ranks
+    assert res[0][3] == res[1][3]
+    # rank 0 overlapped (its graph reaches everything); rank 1 could launch from hooks only up to the first bucket that holds a
+    # tensor its graph never reached (the decoders / fcs sit right behind lm_head): the rest left in finish()
+    assert res[0][1] >= 2 and res[1][1] < res[0][1]
+    cfg = hcfg.tiny()
+    sd = hw.make_state_dict(cfg, 21)
+    batch = make_batch(cfg, b=2, hw=(40, 36))
+    ref = {}
+    for rank in range(world):
+        osd, lora, named = _trainable_leaves(cfg, sd)
+        for _ in range(2):
+            out = O.lisa_model_forward(osd, cfg, _half(batch, rank, rank + 1), lora=lora, lora_alpha=8.0)
+            ((out["ce_loss"] if rank == 1 else out["loss"]) * 0.5).backward()
+        for k, p in named:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            ref[k] = ref.get(k, 0) + g / world
+    untouched = 0
+    for rank in range(world):
+        for k, want in ref.items():
+            gk = torch.from_numpy(res[rank][0][k])
+            scale = want.abs().max().item()
+            assert (gk - want).abs().max().item() <= 2e-4 * scale + 1e-7, (rank, k)
+    osd, lora, named = _trainable_leaves(cfg, sd)
+    out = O.lisa_model_forward(osd, cfg, _half(batch, 1, 2), lora=lora, lora_alpha=8.0)
+    out["ce_loss"].backward()
+    untouched = sum(1 for k, p in named if p.grad is None)
+    assert untouched >= 50, untouched     # the divergence is real: the decoders' and text_hidden_fcs' tensors saw no gradient on rank 1
+
+
 def _bench_stub_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -266,6 +327,29 @@ def test_bench_multi_rank_path_dry_run_with_stub_model():
     assert line["ms_per_step"] >= 50.0 and line["ms_per_step"] < 120.0
     assert abs(line["value"] - 2 * 5 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
     assert line["cpu_baseline"] is None and line["config"]["stub"] is True
+
+
+def test_bench_bare_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun environment must not print an n_gpus: 1 line: it starts the two ranks itself
+    (child `python -m torch.distributed.run`, before any GPU call in the parent) and forwards rank 0's line; a launcher whose
+    WORLD_SIZE disagrees with --gpus is refused with a non-zero exit (the reference is one command too: 2Haff/README.md:69)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--stub-step-ms", "30", "--batch", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 3
+    assert abs(line["value"] - 2 * 4 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step-ms", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
 
 
 def test_bucket_layout_with_alternating_dtypes():
