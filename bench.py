@@ -773,11 +773,18 @@ def main(argv=None):
                 # free the HIP model's host-side leftovers first? (none: weights live in HBM) — one REAL frame beside the sample
                 full = cpu_full_frame(cfg, args.text_tokens, args.n_gen, threads)
                 line["cpu_baseline"]["full_frame"] = full
-                if "frames_per_s" in full:   # the measured end-to-end frame IS the baseline; the layer-count extrapolation stays beside it
-                    line["cpu_baseline"]["extrapolated_value"] = line["cpu_baseline"]["value"]
-                    line["cpu_baseline"]["value"] = full["frames_per_s"]
-                    line["cpu_baseline"]["extrapolated"] = False
-                    line["cpu_baseline"]["sample"] = full["what"] + " — ONE measured end-to-end frame; extrapolated_value = " + line["cpu_baseline"]["sample"]
+                if "frames_per_s" in full:
+                    # the measured end-to-end frame IS the baseline: value and seconds_per_frame are that frame's; everything that
+                    # belongs to the layer-count extrapolation moves into its own sub-object
+                    cb = line["cpu_baseline"]
+                    cb["extrapolation"] = {"value": cb.pop("value"), "seconds_per_frame": cb.pop("seconds_per_frame"),
+                                           "parts_s": cb.pop("parts_s"), "sample": cb.pop("sample"), "note": cb.pop("extrapolation"),
+                                           "reference_semantics_value": cb.pop("reference_semantics_value"),
+                                           "reference_semantics_note": cb.pop("reference_semantics_note")}
+                    cb["value"] = full["frames_per_s"]
+                    cb["seconds_per_frame"] = full["seconds"]
+                    cb["extrapolated"] = False
+                    cb["sample"] = full["what"] + " - ONE measured end-to-end frame (the `extrapolation` object is the per-layer estimate beside it)"
         else:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_parity:
