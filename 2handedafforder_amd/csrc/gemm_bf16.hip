@@ -252,8 +252,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;             // 16x16 MFMA tiles per wave
   constexpr int WNC = BN / WN;                                    // columns per wave: 64, or 128 for the 4-wave 256^2 tile
   static_assert(WNC == 64, "wave tile width");
-  // [buf][A | W] (+ PP: the tile's bias 1 KB | folded-norm row statistics {mean, rstd} x 256 rows 2 KB | column sums 1 KB)
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS + (PP ? 2048 : 0)];
+  // [buf][A | W] (+ PP: the tile's bias 1 KB | folded-norm row statistics {mean, rstd} x 256 rows 2 KB | column sums 1 KB |
+  // output row map 1 KB)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS + (PP ? 2560 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -568,18 +569,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     // the one behind the first tile's prologue, has passed)
     // the tile's 256 bias values ride along as ONE more DMA instruction (wave 0), a whole K loop ahead of the epilogue that
     // reads them from LDS: a global load issued there sat in front of pass 0 with its full latency exposed, once per tile
-    if (p.bias && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && wave == 0)
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + n0 + lane * 4), (lptr_t)(smem + 2 * STAGE_ELEMS), 16, 0, 0);
+    // (round 4: a uniform base in SGPRs + the lane's 16-byte offset. With per-lane 64-bit addresses hipcc kept them alive across
+    // the tile loop, spilled them, and the reload's s_waitcnt vmcnt(0) drained the previous tile's stores in front of these
+    // requests)
+    auto dma_row16 = [&](const void* base, float* lds_dst) {
+      asm volatile("" : "+s"(base));
+      unsigned o = (unsigned)lane * 16u;
+      asm volatile("" : "+v"(o));
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(base) + o), (lptr_t)lds_dst, 16, 0, 0);
+    };
+    float* sXw = reinterpret_cast<float*>(smem + 2 * STAGE_ELEMS);
+    if (p.bias && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && wave == 0) dma_row16(p.bias + n0, sXw);
     // folded norm: the tile's 256 {mean, rstd} rows and 256 column sums the same way (waves 1-3, three DMA instructions):
     // loaded at the top of the epilogue they put a memory round trip in front of pass 0 of every tile (+0.35 % of the step,
     // norm-folded products 1100 -> 1108 TFLOP/s: bench.py `by_epilogue`, profiles/r3_ln_prefetch_ab.txt)
     if (p.ln_stats && m0 + BM <= p.M && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0) {
-      float* sLn = reinterpret_cast<float*>(smem + 2 * STAGE_ELEMS) + 256;
-      if (wave == 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.ln_stats + 2 * (long)m0 + lane * 4), (lptr_t)(sLn), 16, 0, 0);
-      if (wave == 2) __builtin_amdgcn_global_load_lds((gptr_t)(p.ln_stats + 2 * (long)(m0 + 128) + lane * 4), (lptr_t)(sLn + 256), 16, 0, 0);
-      if (wave == 3 && p.ln_colsum && (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0)
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.ln_colsum + n0 + lane * 4), (lptr_t)(sLn + 512), 16, 0, 0);
+      if (wave == 1) dma_row16(p.ln_stats + 2 * (long)m0, sXw + 256);
+      if (wave == 2) dma_row16(p.ln_stats + 2 * (long)(m0 + 128), sXw + 512);
+      if (wave == 3 && p.ln_colsum && (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0) dma_row16(p.ln_colsum + n0, sXw + 768);
     }
+    // round 4: the output row map of the tile's 256 rows the same way (wave 4). Read per lane from global memory at the top of the
+    // epilogue (orow_l below) it put a dependent memory round trip in front of pass 0 of every windowed q|k|v tile.
+    if (p.row_map && m0 + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0 && wave == 4) dma_row16(p.row_map + m0, sXw + 1024);
     if (nk > 1) {
       stage_w_q(buf0 ^ 1, BK, Q0{});
       stage_w_q(buf0 ^ 1, BK, Q1{});
@@ -804,10 +815,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   }
   // output row of wave-row (lane) and (lane + 64): -1 = dropped. Distributed to the read-back lanes by ds_bpermute.
   int orow_l[WROWS / 64];
+  const bool map_staged = PP && p.row_map && m0e + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0;   // (the DMA above)
 #pragma unroll
   for (int h = 0; h < WROWS / 64; ++h) {
     const int m = m_wave + h * 64 + lane;
-    orow_l[h] = m < p.M ? (p.row_map ? p.row_map[m] : m) : -1;
+    if (map_staged) orow_l[h] = reinterpret_cast<const int*>(smem + 2 * STAGE_ELEMS)[1024 + wm * WROWS + h * 64 + lane];
+    else orow_l[h] = m < p.M ? (p.row_map ? p.row_map[m] : m) : -1;
   }
 #ifndef HAFF_EPI_LDS   // -DHAFF_EPI_LDS: every tile through the LDS-staged epilogue below (A/B runs)
   // ---- register epilogue (interior tiles, 16-B aligned rows) ----
@@ -818,6 +831,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   // four lanes of a row cover 64 contiguous bytes of it: no LDS round trip, no wave barriers, no dependent
   // write -> read -> store chain per pass. (Measured on the LDS-staged form: its stores cost 8 % of a K = 1280 launch, the
   // staging around them 20 %: tools/gemm_variant.py nostore / noepi.)
+#ifdef HAFF_EXP_NOEPI   // timing experiment: the accumulators are kept alive, nothing is computed or written
+  if (fast) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(acc[ni][mi]));
+  } else
+#endif
   if (fast) {
     // ALL = every row of the wave tile is written (no row map, not the ragged last M-tile): the loads and stores below are
     // then unconditional, which lets hipcc wait for a prefetched residual with a COUNTED vmcnt (behind an exec-masked

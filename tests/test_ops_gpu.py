@@ -253,6 +253,87 @@ def test_gemm_folded_norm(dev, M, N, K, rms):
         _close(got, F.silu(xn @ wg.float().T) * (xn @ wu.float().T), 2e-2, "folded rmsnorm swiglu")
 
 
+@pytest.mark.parametrize("K", [128, 1280])
+def test_gemm_lean_register_epilogue_variants(dev, K):
+    """The 8-wave tile's lean register epilogue (round 4; csrc/gemm_bf16.hip `lean_epilogue`) in each of its instances, on whole
+    256 x 256 tiles: plain, bias, bias + exact GELU, folded LayerNorm (+ GELU), folded RMSNorm, an output row map with dropped
+    rows (the windowed q|k|v scatter of image_encoder.py:179-183), bf16 residual in place (proj / lin2, :186-193), residual +
+    row statistics. Against fp32 torch on the same bf16 operands AND against the 128 x 128 tile (generic epilogue): the two
+    tiles add the same bf16 products, in another order — equal to fp32 rounding, i.e. at most one bf16 ulp of the output."""
+    ops = _ops()
+    import haff.ops as hops
+    M, N = 4096, 2560   # (the folded-norm entry picks its tile by shape: 160 tiles of 256 x 256 beat 640 of 128 x 128)
+    x = (_rand((M, K), dev, torch.float32, 301, 1.5) + 0.4).to(torch.bfloat16)
+    w = _rand((N, K), dev, torch.bfloat16, 302, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 303)
+    gamma = _rand((K,), dev, torch.float32, 304, 0.2) + 1.0
+    beta = _rand((K,), dev, torch.float32, 305, 0.3)
+    resid = _rand((M, N), dev, torch.bfloat16, 306, 2.0)
+    xf, wf32 = x.float(), w.float()
+    y = xf @ wf32.T
+
+    def both(ref, what, **kw):
+        big = ops.linear(x, kw.pop("w", w), tile_cfg=2, **kw)
+        _close(big, ref, 1.2e-2, what + " vs fp32")
+        return big
+    both(y, "plain")
+    b = both(y + bias, "bias", bias=bias)
+    small = ops.linear(x, w, bias=bias, tile_cfg=1)
+    _close(b, small.float(), 2.0 ** -7, "bias: 256 tile vs 128 tile")
+    g = both(F.gelu(y + bias), "bias + gelu", bias=bias, act=1)
+    _close(g, ops.linear(x, w, bias=bias, act=1, tile_cfg=1).float(), 2.0 ** -7, "gelu: 256 tile vs 128 tile")
+    # large arguments: the clamp of the polynomial's range (|x| > 3 sqrt 2) must give x and 0
+    wbig = (w.float() * 6.0).to(torch.bfloat16)
+    both(F.gelu(xf @ wbig.float().T + bias), "gelu, large arguments", w=wbig, bias=bias, act=1)
+    r = both(y + bias + resid.float(), "bias + residual", bias=bias, resid=resid)
+    _close(r, ops.linear(x, w, bias=bias, resid=resid, tile_cfg=1).float(), 2.0 ** -7, "residual: 256 tile vs 128 tile")
+    inplace = resid.clone()
+    ops.linear(x, w, bias=bias, resid=inplace, out=inplace, tile_cfg=2)
+    assert torch.equal(inplace, r), "in-place residual differs"
+    # folded norms
+    for rms in (False, True):
+        eps = 1e-6
+        if rms:
+            xn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * gamma
+        else:
+            xn = F.layer_norm(xf, (K,), gamma, beta, eps)
+        stats = ops.row_stats(x, eps, rms=rms)
+        wfold, colsum, bf = ops.fold_norm(w, gamma, None if rms else beta, bias)
+        yn = xn @ wf32.T + bias
+        for act, ref in ((0, yn), (1, F.gelu(yn))):
+            got = ops.linear(x, wfold, bias=bf, act=act, ln_stats=stats, ln_colsum=None if rms else colsum, tile_cfg=2)
+            _close(got, ref, 2e-2, f"folded {'rms' if rms else 'layer'}norm act{act}")
+        # scatter with dropped rows
+        gperm = torch.Generator(device="cpu").manual_seed(307)
+        perm = torch.randperm(M + 200, generator=gperm)[:M].to(torch.int32)
+        perm[::37] = -1
+        perm = perm.to(dev)
+        out = torch.full((M + 200, N), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.linear(x, wfold, bias=bf, row_map=perm, out=out, ln_stats=stats, ln_colsum=None if rms else colsum, tile_cfg=2)
+        ref = torch.full((M + 200, N), 7.0, dtype=torch.float32, device=dev)
+        keep = perm >= 0
+        ref[perm[keep].long()] = yn[keep]
+        _close(out, ref, 2e-2, "folded norm + row map with dropped rows")
+        out2 = torch.full((M + 200, N), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.linear(x, wfold, bias=bf, act=1, row_map=perm, out=out2, ln_stats=stats, ln_colsum=None if rms else colsum, tile_cfg=2)
+        ref[perm[keep].long()] = F.gelu(yn)[keep]
+        _close(out2, ref, 2e-2, "folded norm + gelu + row map")
+    # residual + statistics of the stored rows
+    if K % 64 == 0:
+        lib = hops.load_library()
+        out = resid.clone()
+        part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=dev)
+        stats = torch.empty((M, 2), dtype=torch.float32, device=dev)
+        rc = lib.haff_gemm_bf16_rowstats(x.data_ptr(), x.stride(0), None, 0, w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                                         bias.data_ptr(), out.data_ptr(), out.stride(0), M, N, K, part.data_ptr(), None)
+        assert rc == 0
+        assert lib.haff_row_stats_finalize(part.data_ptr(), stats.data_ptr(), M, N // 64, N, 1e-6, None) == 0
+        assert torch.equal(out, r), "rowstats product differs from the residual product"
+        want = ops.row_stats(out, 1e-6)
+        assert (stats[:, 0] - want[:, 0]).abs().max().item() <= 2e-3 * want[:, 0].abs().max().item() + 1e-4
+        assert ((stats[:, 1] - want[:, 1]).abs() / want[:, 1]).max().item() <= 2e-3
+
+
 def test_gemm_bf16_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a swapped C layout (cdna guide §3)."""
     ops = _ops()
