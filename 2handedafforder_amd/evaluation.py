@@ -106,10 +106,10 @@ def score_frame(bench_dir, comp_dir, orig_shape_wh, take_intersection=False):
             return np.logical_or(a, b)
         return a if a.size else b
     bench_union, comp_union = union(b_left, b_right), union(c_left, c_right)
+    if bench_union.size and comp_union.size and bench_union.shape != comp_union.shape:
+        return None   # (the reference's np.logical_and raises here: e.g. --cropped with full-resolution masks; the frame is skipped)
     iou, iocm = calculate_iou(bench_union, comp_union), calculate_iocm(bench_union, comp_union)
     if iou is None or iocm is None:
-        return None
-    if bench_union.shape != comp_union.shape:
         return None
     dhd, hd = calculate_hausdorff(bench_union, comp_union)
     return iou, iocm, dhd, hd

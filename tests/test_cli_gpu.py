@@ -168,3 +168,51 @@ def test_inference_cli_batches_a_directory(dev, tmp_path, monkeypatch):
     assert len(outs[1]) >= 15 and set(outs[1]) == set(outs[3])
     diff = [k for k in outs[1] if outs[1][k] != outs[3][k]]
     assert not diff, f"batched CLI wrote different files for {diff}"
+
+
+def test_inference_cli_on_the_reference_benchmark_sample_and_rescoring(dev, tmp_path, monkeypatch):
+    """inference.py --benchmark-dir over the leaf folders the reference ships (tests/golden/actaffordance_sample, copied from
+    ActAffordance/data_zipped/masks by oracle/make_actaffordance_sample.py: 256 x 256 inpainting.png, 855 x 855 masks), then the
+    written aff_{left,right}.png planes scored by evaluation.py the way calculate_iou.py:117-337 scores a prediction tree:
+    predictions are 256 x 256 (the frame's size), the benchmark masks 855 x 855 -> the resize path; --map sweeps the five
+    threshold folders. Random-init weights: the numbers only have to be well-formed."""
+    import haff  # noqa: F401
+    from haff import evaluation, inference, lisa
+    sample = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "actaffordance_sample")
+    orig = lisa.LisaMI355.evaluate
+
+    def forced(self, *a, **kw):
+        import torch
+        B = a[2].shape[0]
+        kw["forced_answer"] = torch.tensor([[5, self.cfg.seg_token_idx, self.cfg.eos_token_id]]).expand(B, -1)
+        kw["max_new_tokens"] = 3
+        return orig(self, *a, **kw)
+    monkeypatch.setattr(lisa.LisaMI355, "evaluate", forced)
+    out = tmp_path / "pred" / "th"
+    inference.main(["--synthetic", "tiny", "--benchmark-dir", sample, "--vis_save_path", str(out), "--image_size", "224",
+                    "--batch-size", "3"])
+    from PIL import Image
+    th_dirs = sorted(os.listdir(tmp_path / "pred"))
+    assert th_dirs == ["th0.1", "th0.2", "th0.3", "th0.5", "th0.7"]
+    n_files = 0
+    for th in th_dirs:
+        for sub, leaf in (("P14_05", "0003558"), ("P14_05", "0001413"), ("P14_05", "0002976"), ("8f91bc0d-9ce7-4b31-aba7-dd59791917df", "00000029")):
+            d = tmp_path / "pred" / th / sub / leaf
+            assert d.is_dir(), d
+            for f in os.listdir(d):
+                arr = np.asarray(Image.open(d / f))
+                assert f in ("aff_left.png", "aff_right.png") and arr.shape == (256, 256) and set(np.unique(arr)) <= {0, 255}
+                n_files += 1
+    assert n_files >= 20                                               # at least one hand per frame and threshold
+    res = evaluation.evaluate_folders(sample, str(tmp_path / "pred"), calc_map=True, verbose=False)
+    assert [r["threshold"] for r in res["per_threshold"]] == th_dirs
+    for r in res["per_threshold"]:
+        assert r["count"] == 4 and 0.0 <= r["iou"] <= 1.0 and 0.0 <= r["iocm"] <= 1.0 and 0.0 <= r["directed_hd"] <= r["hd"] <= 2 ** 0.5 * 855
+    areas = []                                                         # a higher threshold can only shrink a predicted region
+    for th in th_dirs:
+        tot = 0
+        for d, _, fs in os.walk(tmp_path / "pred" / th):
+            tot += sum(int((np.asarray(Image.open(os.path.join(d, f))) > 0).sum()) for f in fs)
+        areas.append(tot)
+    assert areas == sorted(areas, reverse=True)
+    assert 0.0 <= res["mean_average_precision"] <= 1.0 and res["best"]["iocm"] == max(r["iocm"] for r in res["per_threshold"])
