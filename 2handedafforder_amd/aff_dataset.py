@@ -13,8 +13,8 @@ any mask are skipped), the same 12-tuple with `inference=True`.
 
 Contours are filled by `cvlite.draw_contours_filled`, a restatement of `cv2.drawContours(..., FILLED)` from OpenCV's published
 sources (this image has no cv2; tests/test_cvlite_cpu.py holds hand-derived fixtures — parity with cv2 itself is unpinned).
-The local h5/json layout (`_load_from_local`, :152-183) needs h5py, which is not installed — `from_local` raises with that
-message.
+The local h5/json layout (`_load_from_local`, :152-183, :307-338) is `AffRecordsDataset.from_local`: all of its index / ordering
+logic is here; the HDF5 reader itself is h5py, which is not installed in this image (ImportError naming it unless `h5_open=` is given).
 """
 import random
 
@@ -80,9 +80,85 @@ class AffRecordsDataset(torch.utils.data.Dataset):
         return cls(load_dataset(name, split="train"), cfg, **kw)
 
     @classmethod
-    def from_local(cls, base_image_dir, cfg, **kw):
-        raise ImportError("the local 2HANDS layout (h5/ + jsons/, aff_dataset.py:152-183) needs h5py, which this image "
-                          "does not have; export the records (narration, inpainted, taxonomy, masks) and use AffRecordsDataset")
+    def from_local(cls, base_image_dir, cfg, h5_open=None, **kw):
+        """The local 2HANDS layout of `_load_from_local` / `extract_index_from_h5` (aff_dataset.py:152-183, 307-338):
+
+            <dir>/h5/<start>-<end>_*.h5     group `data` with datasets `inpainted` [n, H, W, 3] uint8, `narration` [n] bytes,
+                                            `taxonomy` [n]; a file holds the samples start..end (inclusive) of the global index
+            <dir>/jsons/<start>-<end>_*.json  {"0": {"original_size": [h, w], "aff_left": [contours], "aff_right": [contours]}, ...}
+
+        Everything the reference does with it is here: the json files are read in the order of the first number in their names
+        and their entries appended in key order to ONE global list of contour masks (:160-183), `original_size` comes from entry
+        "0" of the first file, the number of samples is the sum of the `inpainted` lengths, and sample i is fetched from the
+        file whose name range contains i (:307-321) at row i - start. The one thing this image lacks is the HDF5 reader:
+        `h5_open(path)` must return a mapping like `h5py.File(path, "r")`; left None it is h5py's, and its absence raises
+        ImportError naming the dependency (h5py, any version that reads the files written by 2HANDS/scripts)."""
+        import json
+        import os
+        import re
+        if h5_open is None:
+            try:
+                import h5py
+            except ImportError as e:
+                raise ImportError("the local 2HANDS layout (<dir>/h5/*.h5 + <dir>/jsons/*.json, aff_dataset.py:152-183) is read "
+                                  "through h5py, which is not installed here: `pip install h5py`, or pass h5_open=, or export "
+                                  "the records and use AffRecordsDataset / from_hf") from e
+            h5_open = lambda path: h5py.File(path, "r")   # noqa: E731
+        image_dir, json_dir = os.path.join(base_image_dir, "h5"), os.path.join(base_image_dir, "jsons")
+
+        def first_number(name):
+            m = re.search(r"(\d+)", name)
+            return int(m.group(1)) if m else float("inf")
+        h5_names = [f for f in os.listdir(image_dir) if f.endswith(".h5")]
+        ranges = []
+        for f in h5_names:
+            m = re.match(r"(\d+)-(\d+)_", f)
+            if m:
+                ranges.append((int(m.group(1)), int(m.group(2)), os.path.join(image_dir, f)))
+        size = 0
+        for f in h5_names:
+            h = h5_open(os.path.join(image_dir, f))
+            size += int(h["data"]["inpainted"].shape[0])
+            if hasattr(h, "close"):
+                h.close()
+        masks_left, masks_right, original_size = [], [], None
+        for name in sorted(os.listdir(json_dir), key=first_number):
+            with open(os.path.join(json_dir, name)) as fh:
+                data = json.load(fh)
+            if original_size is None:
+                original_size = [int(x) for x in data["0"]["original_size"]]
+            for key in data:
+                masks_left.append(data[key].get("aff_left", []))
+                masks_right.append(data[key].get("aff_right", []))
+        if len(masks_left) < size:
+            raise ValueError(f"{size} samples in h5/ but contours for only {len(masks_left)} in jsons/")
+
+        class _LocalRecords:
+            """records[i] for AffRecordsDataset: fetched from the h5 file whose name range holds i (extract_index_from_h5)."""
+
+            def __len__(self):
+                return size
+
+            def __getitem__(self, i):
+                for lo, hi, path in ranges:
+                    if lo <= i <= hi:
+                        h = h5_open(path)
+                        d = h["data"]
+                        rec = {"narration": d["narration"][i - lo], "inpainted": np.asarray(d["inpainted"][i - lo]),
+                               "taxonomy": d["taxonomy"][i - lo],
+                               "masks": {"original_size": original_size, "aff_left": masks_left[i], "aff_right": masks_right[i]}}
+                        if hasattr(h, "close"):
+                            h.close()
+                        return rec
+                raise ValueError(f"Index {i} not found in any file in {image_dir}.")
+
+            def __iter__(self):
+                return (self[i] for i in range(size))
+        ds = cls.__new__(cls)
+        ds.records = _LocalRecords()
+        ds.cfg, ds.samples_per_epoch, ds.inference = cfg, kw.get("samples_per_epoch", 500 * 8 * 2 * 10), kw.get("inference", False)
+        ds.size, ds.original_size, ds.rng = size, tuple(original_size), random.Random(kw.get("seed"))
+        return ds
 
     def __len__(self):
         return self.samples_per_epoch
