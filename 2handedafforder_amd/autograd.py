@@ -25,6 +25,19 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+def scale_dev(a, alpha, per_row=False):
+    """a * alpha with alpha a DEVICE fp32 scalar (or one value per row of the 2-D a): the multiply runs in fp32 inside the kernel —
+    a torch multiply would first round the 0-dim upstream gradient to a's dtype (bf16)."""
+    lib = load_library()
+    a = a.contiguous()
+    alpha = alpha.detach().to(torch.float32).contiguous()
+    rows, cols = (a.shape[0], a.numel() // a.shape[0]) if per_row else (1, a.numel())
+    assert alpha.numel() == (rows if per_row else 1) and alpha.device == a.device
+    out = torch.empty_like(a)
+    check(lib.haff_scale_dev(a.data_ptr(), out.data_ptr(), rows, cols, alpha.data_ptr(), 1 if per_row else 0, _dt(a), _s()), "haff_scale_dev")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # raw (non-differentiable) wrappers of csrc/train.hip
 # ------------------------------------------------------------------------------------------------------------------
@@ -631,7 +644,7 @@ class CrossEntropyFn(Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
-        return dlogits * g.to(dlogits.dtype), None, None   # the upstream scalar stays on the device (no read-back at the head of backward)
+        return scale_dev(dlogits, g), None, None   # the upstream scalar stays on the device AND in fp32 (no read-back, no bf16 rounding)
 
 
 def cross_entropy(logits, labels, n_valid=None):
@@ -731,7 +744,7 @@ class TaxonomyCEFn(Function):
     @staticmethod
     def backward(ctx, g, _gp):
         (dz,) = ctx.saved_tensors
-        return dz * g.to(dz.dtype)[:, None], None   # per-row upstream scalar, applied on the device
+        return scale_dev(dz, g, per_row=True), None   # per-row upstream scalar, applied on the device in fp32
 
 
 taxonomy_ce = TaxonomyCEFn.apply

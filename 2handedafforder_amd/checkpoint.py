@@ -47,6 +47,48 @@ def config_from_dir(path):
     return cfg
 
 
+def added_token_ids(path):
+    """{"[SEG]": id, "<im_start>": id, "<im_end>": id} from the directory's added_tokens.json (what HF's save_pretrained writes
+    for tokens added with add_tokens, train_ds.py:142-149), or None when the file or one of the three is missing."""
+    fn = os.path.join(path, "added_tokens.json")
+    if not os.path.exists(fn):
+        return None
+    with open(fn) as f:
+        d = json.load(f)
+    want = ("[SEG]", "<im_start>", "<im_end>")
+    return {k: int(d[k]) for k in want} if all(k in d for k in want) else None
+
+
+def sentencepiece_vocab_size(path):
+    """Pieces in the directory's tokenizer.model (the base Llama vocabulary: 32000), or None without the file."""
+    fn = os.path.join(path, "tokenizer.model")
+    if not os.path.exists(fn):
+        return None
+    import sentencepiece as spm
+    sp = spm.SentencePieceProcessor()
+    sp.Load(fn)
+    return int(sp.GetPieceSize())
+
+
+def resolve_added_tokens(path, rows):
+    """Ids of [SEG] / <im_start> / <im_end> for a checkpoint directory whose embedding has `rows` rows (LisaMI355.from_pretrained
+    documents the order of authority); ValueError when they cannot be told."""
+    ids = added_token_ids(path)
+    if ids is None:
+        base = sentencepiece_vocab_size(path)
+        with open(os.path.join(path, "config.json")) as f:
+            n_cfg = int(json.load(f).get("vocab_size", rows))
+        if (base is not None and rows == base + 3) or (base is None and rows in (n_cfg, n_cfg + 3)):
+            ids = {"[SEG]": rows - 3, "<im_start>": rows - 2, "<im_end>": rows - 1}
+        else:
+            raise ValueError(f"{path}: embed_tokens has {rows} rows, config.json says vocab_size {n_cfg}, the tokenizer's base "
+                             f"vocabulary is {base}: cannot tell which rows are [SEG] / <im_start> / <im_end> (expected base + 3 "
+                             "rows, or an added_tokens.json)")
+    if max(ids.values()) >= rows:
+        raise ValueError(f"added token ids {ids} do not fit the {rows} embedding rows")
+    return ids
+
+
 def _load_file(fn):
     if fn.endswith(".safetensors"):
         from safetensors.torch import load_file

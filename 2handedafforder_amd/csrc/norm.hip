@@ -281,15 +281,19 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* pa
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   const float2* p = reinterpret_cast<const float2*>(part) + (long)r * slots;
-  float s1 = 0.f, s2 = 0.f;
+  // E[x^2] - mean^2 cancels when |mean| >> std: the slot sums arrive as fp32 (each the sum of 64 fp32 products: ~5e-7
+  // relative), so the variance carries ~5e-7 * (mean / std)^2 whatever is done here — adding the slots and forming the
+  // difference in double at least contributes nothing more (fp32 here doubled it; the two-pass haff_row_stats has no such
+  // term). tests/test_ops_gpu.py::test_linear_rowstats_with_a_large_row_mean holds the bound at mean / std = 30 and 100.
+  double s1 = 0.0, s2 = 0.0;
   for (int i = 0; i < slots; ++i) {
     const float2 v = p[i];
-    s1 += v.x;
-    s2 += v.y;
+    s1 += (double)v.x;
+    s2 += (double)v.y;
   }
-  const float mean = s1 * inv_c;
-  const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
-  reinterpret_cast<float2*>(stats)[r] = float2{mean, rsqrtf(var + eps)};
+  const double mean = s1 * (double)inv_c;
+  const double var = fmax(s2 * (double)inv_c - mean * mean, 0.0);
+  reinterpret_cast<float2*>(stats)[r] = float2{(float)mean, (float)(1.0 / sqrt(var + (double)eps))};
 }
 }  // namespace
 

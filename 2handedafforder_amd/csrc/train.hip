@@ -89,6 +89,14 @@ __global__ void axpby_kernel(const T* a, const T* b, T* out, long n, float alpha
     elem<T>::st(out + i, alpha * elem<T>::ld(a + i) + (b ? beta * elem<T>::ld(b + i) : 0.f));
 }
 
+// out[r][c] = a[r][c] * alpha[r * alpha_stride]  (alpha: DEVICE fp32; alpha_stride 0 = one scalar for the whole tensor)
+template <typename T>
+__global__ void scale_dev_kernel(const T* a, T* out, long rows, long cols, const float* alpha, long alpha_stride) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    elem<T>::st(out + i, elem<T>::ld(a + i) * alpha[(i / cols) * alpha_stride]);
+}
+
 template <typename T>
 __global__ void mul_kernel(const T* a, const T* b, T* out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -606,6 +614,18 @@ extern "C" int haff_axpby(const void* a, const void* b, void* out, long n, float
   dim3 g(grid_for(n, 256)), blk(256);
   DISPATCH_T(dtype, hipLaunchKernelGGL((axpby_kernel<bf16_t>), g, blk, 0, HS(stream), (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, alpha, beta),
              hipLaunchKernelGGL((axpby_kernel<float>), g, blk, 0, HS(stream), (const float*)a, (const float*)b, (float*)out, n, alpha, beta));
+  return haff_check_launch();
+}
+// out = a * alpha with alpha an fp32 scalar (alpha_stride = 0) or one fp32 value per row (alpha_stride = 1) in DEVICE memory: the
+// upstream gradient of a loss node applied without rounding it to the tensor's dtype and without a host read (a bf16 upstream
+// scalar skews the CE gradient by up to 0.4 % against the mask gradients once a loss weight is not a power of two: ADVICE r3;
+// LISA.py:417-422 weights ce / bce / dice by 1.0 / 2.0 / 0.5 by default, train_ds.py:92-94 makes them flags)
+extern "C" int haff_scale_dev(const void* a, void* out, long rows, long cols, const float* alpha, long alpha_stride, int dtype,
+                              void* stream) {
+  if (rows <= 0 || cols <= 0 || !alpha || (alpha_stride != 0 && alpha_stride != 1)) return HAFF_ERR_BAD_ARG;
+  dim3 g(grid_for(rows * cols, 256)), blk(256);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((scale_dev_kernel<bf16_t>), g, blk, 0, HS(stream), (const bf16_t*)a, (bf16_t*)out, rows, cols, alpha, alpha_stride),
+             hipLaunchKernelGGL((scale_dev_kernel<float>), g, blk, 0, HS(stream), (const float*)a, (float*)out, rows, cols, alpha, alpha_stride));
   return haff_check_launch();
 }
 // out = a * b elementwise (LoRA dropout mask, peft lora_dropout, train_ds.py:224)

@@ -111,6 +111,7 @@ _PROTOS = {
     "haff_swiglu_fwd": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "haff_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "haff_axpby": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_int, c_void_p],
+    "haff_scale_dev": [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_int, c_void_p],
     "haff_mul": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "haff_norm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_colsum": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],

@@ -12,6 +12,9 @@ Differences from the reference that do NOT change results:
   * frames / prompts are batched through the SAM encoder and decoders (reference: python loops, :157-168,494-532).
 Extension for synthetic benchmarking: `forced_answer` overrides the appended tokens (argmax still computed).
 """
+import json
+import os
+
 import torch
 
 from . import ops
@@ -413,12 +416,16 @@ class LisaMI355:
         if seg_token_idx is not None:
             cfg.seg_token_idx = int(seg_token_idx)
         sd = checkpoint.load_state_dict(pretrained_model_name_or_path, vision_tower, sam_checkpoint, cfg=cfg)
-        # the vocabulary is what the checkpoint's embedding holds (a merged 2HAff model carries the three added rows,
-        # train_ds.py:231-233); config.json's vocab_size is only a hint (config_from_dir's modulo rule fits 32003, not every size)
+        # The reference takes [SEG] / <im_start> / <im_end> from the TOKENIZER (inference.py:115-131, train_ds.py:142-149); here, in
+        # order of authority: the directory's added_tokens.json; else the three rows behind the sentencepiece vocabulary when the
+        # embedding has exactly base + 3 rows; else (directories without tokenizer files: this repo's synthetic checkpoints) the
+        # last three rows when the embedding has config.json's vocab_size or vocab_size + 3 rows. Anything else — a plain base
+        # without the added rows, a vocabulary padded to a multiple of 64 — is refused instead of silently reading ordinary or
+        # padding rows as [SEG]. An explicit seg_token_idx is kept as given.
         rows = sd["model.embed_tokens.weight"].shape[0]
-        if rows != cfg.llm.vocab:
-            cfg.llm.vocab = rows
-            cfg.im_start_idx, cfg.im_end_idx = rows - 2, rows - 1
-            if seg_token_idx is None:
-                cfg.seg_token_idx = rows - 3
+        ids = checkpoint.resolve_added_tokens(pretrained_model_name_or_path, rows)
+        cfg.llm.vocab = rows
+        cfg.im_start_idx, cfg.im_end_idx = int(ids["<im_start>"]), int(ids["<im_end>"])
+        if seg_token_idx is None:
+            cfg.seg_token_idx = int(ids["[SEG]"])
         return cls(cfg, sd, dtype=torch_dtype, device=device, **kw)

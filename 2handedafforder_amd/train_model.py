@@ -245,12 +245,12 @@ class LisaTrainable:
         # the Llama forward, whose M = conversations x tokens products leave CUs idle (2808 x 4096 outputs = 176 tiles of
         # 256 x 256 on 256 CUs), and is joined in front of the decoders.
         cur = torch.cuda.current_stream(dev)
-        side = base._sam_stream if (self.overlap_sam and dev.type == "cuda") else cur
+        sam_stream = base._sam_stream if (self.overlap_sam and dev.type == "cuda") else cur
         with torch.no_grad():
             images = images.to(dev)
-            if side is not cur:
-                side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            if sam_stream is not cur:
+                sam_stream.wait_stream(cur)
+            with torch.cuda.stream(sam_stream):
                 emb = base.get_visual_embs(images)                                # frozen SAM encoder (LISA.py:191)
             n_conv = input_ids.shape[0]
             reps = [off_host[i + 1] - off_host[i] for i in range(len(off_host) - 1)]
@@ -278,8 +278,8 @@ class LisaTrainable:
         pred = A.linear(h, P["model.text_hidden_fcs.0.2.weight"], P["model.text_hidden_fcs.0.2.bias"])
         Pn = pred.shape[0]
         N, C = emb.shape[1], emb.shape[2]
-        if side is not cur:
-            cur.wait_stream(side)
+        if sam_stream is not cur:
+            cur.wait_stream(sam_stream)
             emb.record_stream(cur)
         with torch.no_grad():
             src = emb.index_select(0, frame_idx).reshape(Pn * N, C)

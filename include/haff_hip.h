@@ -311,6 +311,9 @@ int haff_swiglu_fwd(const void* gu, void* y, long M, int F, int dtype, void* str
 int haff_swiglu_bwd(const void* gu, const void* dy, void* dgu, long M, int F, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be null) */
 int haff_axpby(const void* a, const void* b, void* out, long n, float alpha, float beta, int dtype, void* stream);
+/* out[r][c] = a[r][c] * alpha[r * alpha_stride]: alpha fp32 in DEVICE memory, one scalar (alpha_stride 0) or one per row (1).
+ * The upstream gradient of the loss nodes of LISA.py:414-422 (ce / taxonomy CE) applied in fp32 without a host read. */
+int haff_scale_dev(const void* a, void* out, long rows, long cols, const float* alpha, long alpha_stride, int dtype, void* stream);
 /* out = a * b elementwise (LoRA dropout mask) */
 int haff_mul(const void* a, const void* b, void* out, long n, int dtype, void* stream);
 /* LayerNorm (rms=0) / RMSNorm (rms=1) adjoint: dx; dyx (f32 [rows][C], may be null) = dy*xhat for the weight grad */

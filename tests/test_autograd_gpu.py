@@ -453,3 +453,28 @@ def test_adamw_matches_torch(dev):
     _close(s_dev.master, s_host.master, 1e-6, "adamw with a device clip coefficient")
     _close(s_dev.v, s_host.v, 1e-5, "adamw v with a device clip coefficient")
     assert abs(T.grad_norm([g, g]).item() - math.sqrt(2) * g.norm().item()) < 1e-2
+
+
+def test_loss_upstream_scalars_stay_in_fp32(dev):
+    """the gradient a loss weight sends into CrossEntropyFn / TaxonomyCEFn is applied by haff_scale_dev in fp32 from
+    DEVICE memory — not rounded to bf16 first (0.3 -> 0.30078125: 0.26 % off against the mask gradients of the same step)."""
+    import haff  # noqa: F401
+    from haff import autograd as A
+    g = torch.Generator(device="cpu").manual_seed(5)
+    logits = (torch.randn((37, 323), generator=g) * 2).to(torch.bfloat16).to(dev).requires_grad_(True)
+    labels = torch.randint(0, 323, (37,), generator=g).to(dev)
+    labels[::5] = -100
+    w = torch.tensor(0.3, device=dev)
+    (A.cross_entropy(logits, labels) * w).backward()
+    ref_logits = logits.detach().float().requires_grad_(True)
+    (torch.nn.functional.cross_entropy(ref_logits, labels, ignore_index=-100) * 0.3).backward()
+    got, ref = logits.grad.float(), ref_logits.grad
+    # against the fp32 gradient: only the bf16 rounding of each stored element (2^-9 relative), no common 0.26 % scale error
+    ratio = (got * ref).sum() / (ref * ref).sum()
+    assert abs(float(ratio) - 1.0) < 5e-4, float(ratio)
+    assert (got - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    # per-row form
+    a = torch.randn((6, 40), generator=g).to(dev)
+    alpha = torch.tensor([0.3, -1.7, 0.0, 2.5, 1e-3, 1.0], device=dev)
+    assert torch.equal(A.scale_dev(a, alpha, per_row=True), a * alpha[:, None])
+    assert torch.equal(A.scale_dev(a, alpha[3]), a * 2.5)

@@ -147,3 +147,36 @@ def test_tokenizer_against_transformers_and_sentencepiece():
     assert ids.count(320) == 1 and tk.decode(ids, skip_special_tokens=True).replace(" ", "") == "Sure,[SEG]."
     ids = tk("<im_start><image><im_end>\nhold the pan").input_ids
     assert ids[1] == 321 and 322 in ids
+
+
+def test_added_token_ids_come_from_the_tokenizer_files(tmp_path):
+    """from_pretrained's special-token rule: added_tokens.json first, else base + 3 rows behind the sentencepiece
+    vocabulary, else (no tokenizer files) config.json's vocab_size or vocab_size + 3 rows; a plain base or a padded vocabulary is
+    refused instead of reading ordinary / padding rows as [SEG]. The reference reads the ids from the tokenizer
+    (inference.py:115-131, train_ds.py:142-149)."""
+    import shutil
+    import pytest
+    import haff  # noqa: F401
+    from haff import checkpoint
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"vocab_size": 32000, "hidden_size": 4096}))
+    # no tokenizer files: the synthetic directories of this repo
+    assert checkpoint.resolve_added_tokens(str(d), 32003) == {"[SEG]": 32000, "<im_start>": 32001, "<im_end>": 32002}
+    assert checkpoint.resolve_added_tokens(str(d), 32000)["[SEG]"] == 31997      # vocab_size already counts them
+    with pytest.raises(ValueError):
+        checkpoint.resolve_added_tokens(str(d), 32064)
+    # a sentencepiece model: base + 3 or nothing
+    tok = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_tiny", "tokenizer.model")
+    shutil.copy(tok, d / "tokenizer.model")
+    base = checkpoint.sentencepiece_vocab_size(str(d))
+    assert base and base > 100
+    assert checkpoint.resolve_added_tokens(str(d), base + 3) == {"[SEG]": base, "<im_start>": base + 1, "<im_end>": base + 2}
+    for rows in (base, base + 64, 32003):
+        with pytest.raises(ValueError, match="cannot tell"):
+            checkpoint.resolve_added_tokens(str(d), rows)
+    # added_tokens.json is authoritative, wherever the rows sit
+    (d / "added_tokens.json").write_text(json.dumps({"<im_end>": base + 5, "<im_start>": base + 4, "[SEG]": base + 1, "<extra>": base}))
+    assert checkpoint.resolve_added_tokens(str(d), base + 64) == {"[SEG]": base + 1, "<im_start>": base + 4, "<im_end>": base + 5}
+    with pytest.raises(ValueError, match="do not fit"):
+        checkpoint.resolve_added_tokens(str(d), base + 5)

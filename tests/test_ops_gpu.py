@@ -711,6 +711,23 @@ def test_linear_rowstats(dev, M, N, K, gather):
     assert torch.equal(o1, o2) and torch.equal(s1, s2)
 
 
+@pytest.mark.parametrize("ratio", [30.0, 100.0])
+def test_linear_rowstats_with_a_large_row_mean(dev, ratio):
+    """the producer's statistics are {sum, sum of squares} of fp32 values, so the variance is a difference of two
+    numbers of size mean^2 — rows whose mean is `ratio` standard deviations away from zero lose ~5e-7 * ratio^2 of it. The bound
+    held here: rstd within 3e-6 * ratio^2 (relative) of the two-pass haff_row_stats on the stored rows, mean within 1e-5."""
+    ops = _ops()
+    M, N, K = 2048, 1280, 1280
+    x = _rand((M, K), dev, torch.bfloat16, 190)
+    w = _rand((N, K), dev, torch.bfloat16, 191, K ** -0.5)
+    resid = (_rand((M, N), dev, torch.float32, 192) + ratio).to(torch.bfloat16)     # product ~ N(0, 1), residual ~ N(ratio, 1): std ~ 1.4
+    out, stats = ops.linear_rowstats(x, w, None, resid, 1e-6)
+    want = ops.row_stats(out, 1e-6)
+    assert (stats[:, 0] - want[:, 0]).abs().max().item() <= 1e-5 * ratio + 2e-3    # (+ the bf16 rounding of the stored rows)
+    rel = ((stats[:, 1] - want[:, 1]).abs() / want[:, 1]).max().item()
+    assert rel <= 3e-6 * ratio * ratio + 2e-3, rel
+
+
 @pytest.mark.parametrize("B,H", [(1, 16), (2, 3)])
 def test_global_attention_fused_relpos(dev, B, H):
     """haff_global_attention_bf16 (rel_h / rel_w computed in the kernel's prologue from the bf16 parameter tables) against
