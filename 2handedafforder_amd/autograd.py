@@ -110,11 +110,28 @@ def gemm_tn(a, b, out_dtype=None):
     return out
 
 
+ORDERED_REDUCTIONS = True   # False: the fp32-atomic forms of rounds 1-3 (A/B; run-to-run differences in the last bits and beyond)
+
+
+def _reduce_partials(partials, out, n_out, n_parts, out_inner, part_stride, group_stride, accumulate):
+    check(load_library().haff_reduce_partials(partials.data_ptr(), out.data_ptr(), n_out, n_parts, out_inner, part_stride, group_stride,
+                                              1 if accumulate else 0, _s()), "haff_reduce_partials")
+
+
 def colsum(x2d):
+    """Column sums (bias / norm-weight gradients), fp32 [C]. Ordered form: per-row-block partial sums, added in block order."""
     lib = load_library()
     x2d = x2d.contiguous()
-    out = torch.zeros((x2d.shape[1],), dtype=torch.float32, device=x2d.device)
-    check(lib.haff_colsum(x2d.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1], _dt(x2d), _s()), "haff_colsum")
+    R, C = x2d.shape
+    if not ORDERED_REDUCTIONS:
+        out = torch.zeros((C,), dtype=torch.float32, device=x2d.device)
+        check(lib.haff_colsum(x2d.data_ptr(), out.data_ptr(), R, C, _dt(x2d), _s()), "haff_colsum")
+        return out
+    parts = lib.haff_colsum_parts(R)
+    partials = torch.empty((parts, C), dtype=torch.float32, device=x2d.device)
+    check(lib.haff_colsum_partials(x2d.data_ptr(), partials.data_ptr(), R, C, _dt(x2d), _s()), "haff_colsum_partials")
+    out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
+    _reduce_partials(partials, out, C, parts, C, C, 0, False)
     return out
 
 
@@ -613,8 +630,13 @@ class EmbedFn(Function):
         dy = dy.contiguous()
         acc = torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device)
         flat = ids.reshape(-1).contiguous()
-        check(lib.haff_scatter_add_rows(flat.data_ptr(), dy.data_ptr(), acc.data_ptr(), flat.numel(), ctx.shape[1], _dt(dy), _s()),
-              "haff_scatter_add_rows")
+        if ORDERED_REDUCTIONS:   # rows that share an id are added in row order (stable sort on the device: no host read)
+            sorted_ids, order = torch.sort(flat, stable=True)
+            check(lib.haff_scatter_add_rows_sorted(sorted_ids.data_ptr(), order.data_ptr(), dy.data_ptr(), acc.data_ptr(), flat.numel(),
+                                                   ctx.shape[1], _dt(dy), _s()), "haff_scatter_add_rows_sorted")
+        else:
+            check(lib.haff_scatter_add_rows(flat.data_ptr(), dy.data_ptr(), acc.data_ptr(), flat.numel(), ctx.shape[1], _dt(dy), _s()),
+                  "haff_scatter_add_rows")
         return acc.to(ctx.wdtype), None
 
 
@@ -660,9 +682,19 @@ class MaskLossFn(Function):
         x, t = x.contiguous(), t.contiguous()
         n, hw = x.shape
         stats = torch.zeros((n, 4), dtype=torch.float32, device=x.device)
-        for i in range(n):  # per-sample weight is a host scalar (taxonomy one-hot sums)
-            check(lib.haff_mask_loss_stats(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), 1, hw, float(wgts[i]), _s()),
-                  "haff_mask_loss_stats")
+        if ORDERED_REDUCTIONS:
+            import ctypes
+            partials = torch.empty((n, 256, 4), dtype=torch.float32, device=x.device)
+            n_parts = ctypes.c_int(0)
+            for i in range(n):  # per-sample weight is a host scalar (taxonomy one-hot sums)
+                check(lib.haff_mask_loss_stats_partials(x[i].data_ptr(), t[i].data_ptr(), partials[i].data_ptr(), 1, hw, float(wgts[i]),
+                                                        ctypes.byref(n_parts), _s()), "haff_mask_loss_stats_partials")
+            # stats[i][k] = sum over the parts of sample i, in index order (one launch for all samples)
+            _reduce_partials(partials, stats, 4 * n, n_parts.value, 4, 4, 256 * 4, False)
+        else:
+            for i in range(n):
+                check(lib.haff_mask_loss_stats(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), 1, hw, float(wgts[i]), _s()),
+                      "haff_mask_loss_stats")
         ctx.save_for_backward(x, t, stats)
         ctx.wgts = [float(w) for w in wgts]
         # four sums per sample -> {bce, dice}: a handful of n-element device ops (scalar plumbing; a host round trip here

@@ -526,6 +526,93 @@ __global__ void taxonomy_ce_kernel(const float* z, const float* t, float* probs,
   }
 }
 
+// ---- ordered reductions (round 4) ----------------------------------------------------------------------------------
+// The fp32 atomicAdd forms above (column sums, loss statistics, the embedding scatter, the gradient norm) add in whatever order
+// the blocks finish: a repeated fine-tune step differed by up to 1.4e-2 of a gradient tensor's scale. The forms below have no
+// atomics: every block writes its partial result (threads stride in a fixed pattern, wave_sum and the cross-wave sum are fixed
+// trees), and reduce_partials_kernel adds a block's partials in index order — bitwise repeatable for a given launch geometry.
+__device__ __forceinline__ float block_sum_256(float a, float* red) {   // every thread of a 256-thread block calls; result in thread 0
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  const float s = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const T* g, float* partials, long n) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = elem<T>::ld(g + i);
+    a += v * v;
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(256) void mask_loss_stats_partials_kernel(const float* x, const float* t, float* partials, long n, float wgt) {
+  __shared__ float red[4];
+  const long s = blockIdx.y;
+  const float* xs = x + s * n;
+  const float* ts = t + s * n;
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float z = wgt * xs[i], tt = ts[i];
+    const float p = 1.0f / (1.0f + expf(-z));
+    a += fmaxf(z, 0.f) - z * tt + log1pf(expf(-fabsf(z)));
+    b += p * tt; c += p; d += tt;
+  }
+  a = block_sum_256(a, red); b = block_sum_256(b, red); c = block_sum_256(c, red); d = block_sum_256(d, red);
+  if (threadIdx.x == 0) {
+    float* o = partials + (s * gridDim.x + blockIdx.x) * 4;
+    o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+  }
+}
+// column sums of a row block into partials[blockIdx.y][C]; a thread owns one column (coalesced rows), rows in index order
+template <typename T>
+__global__ void colsum_partials_kernel(const T* x, float* partials, long R, int C, long rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = min(r0 + rows_per_block, R);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four independent chains (fixed assignment: row index mod 4)
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += elem<T>::ld(x + r * C + c); a1 += elem<T>::ld(x + (r + 1) * C + c);
+    a2 += elem<T>::ld(x + (r + 2) * C + c); a3 += elem<T>::ld(x + (r + 3) * C + c);
+  }
+  for (; r < r1; ++r) a0 += elem<T>::ld(x + r * C + c);
+  partials[(long)blockIdx.y * C + c] = (a0 + a1) + (a2 + a3);
+}
+// out[j] (+)= sum over p < n_parts, in index order, of partials[(j / out_inner) * group_stride + p * part_stride + j % out_inner].
+// One wave per output: lane l adds parts l, l + 64, ... then a fixed wave_sum tree.
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* partials, float* out, int n_out, int n_parts, int out_inner,
+                                                             long part_stride, long group_stride, int accumulate) {
+  const int j = blockIdx.x;
+  if (j >= n_out) return;
+  const float* base = partials + (long)(j / out_inner) * group_stride + (j % out_inner);
+  float a = 0.f;
+  for (int p = threadIdx.x; p < n_parts; p += 64) a += base[(long)p * part_stride];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) out[j] = accumulate ? out[j] + a : a;
+}
+// embedding gradient without atomics: rows visited in the order of a STABLE sort of their ids (order[k] = row, sorted_ids[k] =
+// its id); the block at the head of a run of equal ids adds the run's rows in that order into dE[id]. Negative ids are skipped.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_rows_sorted_kernel(const long* sorted_ids, const long* order, const T* dx, float* dE,
+                                                                      long rows, int C) {
+  const long k = blockIdx.x;
+  const long id = sorted_ids[k];
+  if (id < 0 || (k > 0 && sorted_ids[k - 1] == id)) return;
+  long end = k + 1;
+  while (end < rows && sorted_ids[end] == id) ++end;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = dE[id * C + c];
+    for (long q = k; q < end; ++q) a += elem<T>::ld(dx + order[q] * C + c);
+    dE[id * C + c] = a;
+  }
+}
+
 // ---- optimiser ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void sumsq_kernel(const T* g, float* out, long n) {
@@ -738,6 +825,55 @@ extern "C" int haff_scatter_add_rows(const long* ids, const void* dx, float* dE,
   dim3 g(grid_for(rows * C, 256)), b(256);
   DISPATCH_T(dtype, hipLaunchKernelGGL((scatter_add_rows_kernel<bf16_t>), g, b, 0, HS(stream), ids, (const bf16_t*)dx, dE, rows, C),
              hipLaunchKernelGGL((scatter_add_rows_kernel<float>), g, b, 0, HS(stream), ids, (const float*)dx, dE, rows, C));
+  return haff_check_launch();
+}
+// ---- ordered (atomic-free, bitwise repeatable) forms; partial buffers are caller-provided DEVICE fp32 ----
+extern "C" int haff_reduce_partials(const float* partials, float* out, int n_out, int n_parts, int out_inner, long part_stride,
+                                    long group_stride, int accumulate, void* stream) {
+  if (!partials || !out || n_out <= 0 || n_parts <= 0 || out_inner <= 0) return HAFF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_out), dim3(64), 0, HS(stream), partials, out, n_out, n_parts, out_inner, part_stride,
+                     group_stride, accumulate);
+  return haff_check_launch();
+}
+// partials: >= 1024 floats; *n_parts (host) = how many were written
+extern "C" int haff_sumsq_partials(const void* g, float* partials, long n, int dtype, int* n_parts, void* stream) {
+  if (n <= 0 || !partials || !n_parts) return HAFF_ERR_BAD_ARG;
+  const int nb = grid_for(n, 256) > 1024 ? 1024 : grid_for(n, 256);
+  *n_parts = nb;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((sumsq_partials_kernel<bf16_t>), dim3(nb), dim3(256), 0, HS(stream), (const bf16_t*)g, partials, n),
+             hipLaunchKernelGGL((sumsq_partials_kernel<float>), dim3(nb), dim3(256), 0, HS(stream), (const float*)g, partials, n));
+  return haff_check_launch();
+}
+// partials: >= n_samples * 256 * 4 floats, laid out [sample][part][4]; *n_parts = parts per sample
+extern "C" int haff_mask_loss_stats_partials(const float* x, const float* t, float* partials, int n_samples, long n, float wgt,
+                                             int* n_parts, void* stream) {
+  if (n_samples <= 0 || n <= 0 || !partials || !n_parts) return HAFF_ERR_BAD_ARG;
+  const int nb = grid_for(n, 256) > 256 ? 256 : grid_for(n, 256);
+  *n_parts = nb;
+  hipLaunchKernelGGL(mask_loss_stats_partials_kernel, dim3(nb, n_samples), dim3(256), 0, HS(stream), x, t, partials, n, wgt);
+  return haff_check_launch();
+}
+// row blocks of the column sums: haff_colsum_parts(R) blocks, partials [parts][C]
+extern "C" int haff_colsum_parts(long R) {
+  if (R <= 0) return 0;
+  const long rpb = R <= 4096 ? 64 : (R + 255) / 256;   // <= 256 row blocks for tall inputs, 64-row blocks for short ones
+  return (int)((R + rpb - 1) / rpb);
+}
+extern "C" int haff_colsum_partials(const void* x, float* partials, long R, int C, int dtype, void* stream) {
+  if (R <= 0 || C <= 0 || !partials) return HAFF_ERR_BAD_ARG;
+  const int parts = haff_colsum_parts(R);
+  const long rpb = (R + parts - 1) / parts;
+  dim3 g((C + 63) / 64, parts), b(64);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_partials_kernel<bf16_t>), g, b, 0, HS(stream), (const bf16_t*)x, partials, R, C, rpb),
+             hipLaunchKernelGGL((colsum_partials_kernel<float>), g, b, 0, HS(stream), (const float*)x, partials, R, C, rpb));
+  return haff_check_launch();
+}
+// sorted_ids / order: a STABLE ascending sort of the rows' ids and the permutation that produced it (DEVICE int64 [rows])
+extern "C" int haff_scatter_add_rows_sorted(const long* sorted_ids, const long* order, const void* dx, float* dE, long rows, int C,
+                                            int dtype, void* stream) {
+  if (rows <= 0 || C <= 0 || !sorted_ids || !order) return HAFF_ERR_BAD_ARG;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((scatter_add_rows_sorted_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, HS(stream), sorted_ids, order, (const bf16_t*)dx, dE, rows, C),
+             hipLaunchKernelGGL((scatter_add_rows_sorted_kernel<float>), dim3((unsigned)rows), dim3(256), 0, HS(stream), sorted_ids, order, (const float*)dx, dE, rows, C));
   return haff_check_launch();
 }
 extern "C" int haff_sumsq(const void* g, float* out, long n, int dtype, void* stream) {

@@ -112,6 +112,12 @@ _PROTOS = {
     "haff_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "haff_axpby": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_int, c_void_p],
     "haff_scale_dev": [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_int, c_void_p],
+    "haff_reduce_partials": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_int, c_void_p],
+    "haff_sumsq_partials": [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p],
+    "haff_mask_loss_stats_partials": [c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p, c_void_p],
+    "haff_colsum_parts": [c_long],
+    "haff_colsum_partials": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "haff_scatter_add_rows_sorted": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "haff_mul": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "haff_norm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_colsum": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],

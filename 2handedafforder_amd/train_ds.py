@@ -301,8 +301,9 @@ def main(argv):
     if rank == 0:
         print(f"trainable params: {n_train:,d} (LoRA {n_lora:,d}) | world_size {world} | micro-batch {args.batch_size} "
               f"x accum {args.grad_accumulation_steps}")
-    states = {k: T.AdamWState(p) for k, p in model.named_parameters()}
     reducer = T.GradBucketReducer(model.named_parameters())   # p.grad become views into flat per-dtype buckets
+    opt = T.BucketAdamW(reducer, model.named_parameters())    # fp32 master / moments per bucket, one fused launch each
+    states = opt.states
     ckpt_dir = os.path.join(args.log_base_dir, args.exp_name, "ckpt_model")
     global_step, best_score, start_epoch = 0, 0.0, args.start_epoch
     resume = args.resume or (ckpt_dir if args.auto_resume and os.path.exists(os.path.join(ckpt_dir, "latest.pt")) else "")
@@ -311,6 +312,7 @@ def main(argv):
         model.load_state_dict(blob["params"])
         for k, st in blob["optim"].items():
             states[k].master.copy_(st["master"]); states[k].m.copy_(st["m"]); states[k].v.copy_(st["v"]); states[k].step = st["step"]
+        opt.refresh_lp()
         global_step, best_score = blob["global_step"], blob["best_score"]
         start_epoch = global_step // args.steps_per_epoch
         if rank == 0:
@@ -371,10 +373,7 @@ def main(argv):
             # optimizer launches queue up behind backward; no host read of the norm)
             clip = T.clip_coef_device(T.grad_norm(grads) * gscale, 1.0)
             lr = T.warmup_decay_lr(global_step, total_steps, args.lr)
-            for k, p in model.named_parameters():
-                if p.grad is not None:
-                    T.adamw_step(states[k], p.grad, lr=lr, betas=(args.beta1, args.beta2), eps=1e-8, wd=0.0, gscale=gscale,
-                                 param_lp=p.data, gscale_dev=clip)
+            opt.step(lr=lr, betas=(args.beta1, args.beta2), eps=1e-8, wd=0.0, gscale=gscale, gscale_dev=clip)
             global_step += 1
             meters[0].update(time.time() - end)
             end = time.time()

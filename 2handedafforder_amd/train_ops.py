@@ -45,10 +45,21 @@ def adamw_step(state, grad, lr, betas=(0.9, 0.95), eps=1e-8, wd=0.0, gscale=1.0,
 def grad_norm(grads):
     """Global L2 norm of a list of gradient tensors (device scalar)."""
     lib = load_library()
+    from . import autograd as A
     acc = torch.zeros((1,), dtype=torch.float32, device=grads[0].device)
+    if not A.ORDERED_REDUCTIONS:
+        for g in grads:
+            g = g.contiguous()
+            check(lib.haff_sumsq(g.data_ptr(), acc.data_ptr(), g.numel(), _dt(g), _s()), "haff_sumsq")
+        return acc.sqrt()
+    # ordered: <= 1024 block partials per tensor, added in index order, tensors in list order (bitwise repeatable)
+    import ctypes
+    partials = torch.empty((1024,), dtype=torch.float32, device=grads[0].device)
+    n_parts = ctypes.c_int(0)
     for g in grads:
         g = g.contiguous()
-        check(lib.haff_sumsq(g.data_ptr(), acc.data_ptr(), g.numel(), _dt(g), _s()), "haff_sumsq")
+        check(lib.haff_sumsq_partials(g.data_ptr(), partials.data_ptr(), g.numel(), _dt(g), ctypes.byref(n_parts), _s()), "haff_sumsq_partials")
+        A._reduce_partials(partials, acc, 1, n_parts.value, 1, 1, 0, True)
     return acc.sqrt()
 
 
@@ -204,3 +215,72 @@ class GradBucketReducer:
 
     def grads(self):
         return [b["flat"] for b in self.buckets]
+
+
+class _StateView:
+    """One parameter's slice of a BucketAdamW bucket: the fields train_ds.py's checkpoint code reads and writes per key."""
+
+    def __init__(self, opt, master, m, v):
+        self._opt, self.master, self.m, self.v = opt, master, m, v
+
+    @property
+    def step(self):
+        return self._opt.step_count
+
+    @step.setter
+    def step(self, value):
+        self._opt.step_count = int(value)
+
+
+class BucketAdamW:
+    """AdamW over the flat gradient buckets of a GradBucketReducer: ONE fused launch per bucket (<= 16 for the 7B trainable set)
+    instead of one per tensor (237). The reference's engine steps a flattened fp32 partition the same way (DeepSpeed's bf16
+    optimizer behind train_ds.py:344-393: AdamW lr / betas (0.9, 0.95) / wd 0, fp32 master weights, gradient clipping 1.0).
+
+    * per bucket: fp32 master / m / v as flat buffers in the bucket's parameter order;
+    * bf16 parameters are RE-POINTED (p.data) at views of one flat bf16 buffer per bucket, which the kernel refreshes from the
+      master values; fp32 parameters alias their master slice directly. Build it before anything caches parameter storage;
+    * `states[name]` exposes each parameter's {master, m, v, step} as views (checkpoint / resume code keeps working per key)."""
+
+    def __init__(self, reducer, named_params):
+        names = {id(p): k for k, p in named_params}
+        self.step_count = 0
+        self.buckets, self.states = [], {}
+        for b in reducer.buckets:
+            n = b["flat"].numel()
+            dev = b["flat"].device
+            master = torch.empty((n,), dtype=torch.float32, device=dev)
+            off = 0
+            for p in b["params"]:
+                master[off:off + p.numel()] = p.detach().reshape(-1).to(torch.float32)
+                off += p.numel()
+            m, v = torch.zeros_like(master), torch.zeros_like(master)
+            lp = None if b["dtype"] == torch.float32 else master.to(b["dtype"])
+            off = 0
+            for p in b["params"]:
+                k = p.numel()
+                src = master if lp is None else lp
+                p.data = src[off:off + k].view(p.shape)
+                self.states[names[id(p)]] = _StateView(self, master[off:off + k].view(p.shape), m[off:off + k].view(p.shape),
+                                                       v[off:off + k].view(p.shape))
+                off += k
+            self.buckets.append({"master": master, "m": m, "v": v, "lp": lp, "grad": b["flat"]})
+
+    def refresh_lp(self):
+        """After master values were written from outside (resume): the bf16 parameter copies follow."""
+        for b in self.buckets:
+            if b["lp"] is not None:
+                b["lp"].copy_(b["master"])
+
+    def step(self, lr, betas=(0.9, 0.95), eps=1e-8, wd=0.0, gscale=1.0, gscale_dev=None):
+        lib = load_library()
+        self.step_count += 1
+        for b in self.buckets:
+            g = b["grad"]
+            lp_ptr, lp_dt = (b["lp"].data_ptr(), 0) if b["lp"] is not None else (0, -1)
+            args = (b["master"].data_ptr(), b["m"].data_ptr(), b["v"].data_ptr(), g.data_ptr(), lp_ptr, g.numel(), float(lr),
+                    float(betas[0]), float(betas[1]), float(eps), float(wd), self.step_count, float(gscale))
+            if gscale_dev is not None:
+                check(lib.haff_adamw_step_dev(*args, gscale_dev.data_ptr(), _dt(g), lp_dt, _s()), "haff_adamw_step_dev")
+            else:
+                check(lib.haff_adamw_step(*args, _dt(g), lp_dt, _s()), "haff_adamw_step")

@@ -440,8 +440,8 @@ def train_main(args):
     b = args.batch if args.batch != 64 else 8
     batch = make_train_batch(cfg, b, args.train_ids, (args.train_mask, args.train_mask), device, seed=1234 + rank)
     named = list(model.named_parameters())
-    states = {k: T.AdamWState(p) for k, p in named}
     reducer = T.GradBucketReducer(named)
+    opt = T.BucketAdamW(reducer, named)   # one fused AdamW launch per gradient bucket
     losses = []
 
     def step():
@@ -453,8 +453,7 @@ def train_main(args):
         # clip_grad_norm's coefficient (train_ds.py:381) stays on the device: the optimizer launches queue up behind backward
         # instead of waiting for a host read of the norm (the timed region's host reads are the step-start copies of the ids)
         clip = T.clip_coef_device(T.grad_norm(reducer.grads()), 1.0)
-        for k, p in named:
-            T.adamw_step(states[k], p.grad, lr=3e-4, gscale=1.0, param_lp=p.data, gscale_dev=clip)
+        opt.step(lr=3e-4, gscale=1.0, gscale_dev=clip)
         losses.append(out["loss"].detach())
     for _ in range(args.warmup):
         step()

@@ -311,6 +311,21 @@ int haff_swiglu_fwd(const void* gu, void* y, long M, int F, int dtype, void* str
 int haff_swiglu_bwd(const void* gu, const void* dy, void* dgu, long M, int F, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be null) */
 int haff_axpby(const void* a, const void* b, void* out, long n, float alpha, float beta, int dtype, void* stream);
+/* ---- ordered reductions of the fine-tune step: no atomics, bitwise repeatable for a given launch geometry (round 4). Each
+ * producer writes per-block partial sums into a caller-provided DEVICE fp32 buffer; haff_reduce_partials adds them in index
+ * order: out[j] (+)= sum_{p < n_parts} partials[(j / out_inner) * group_stride + p * part_stride + j % out_inner].
+ * Replaces the atomic forms haff_sumsq / haff_mask_loss_stats / haff_colsum / haff_scatter_add_rows inside train_ops / autograd
+ * (global gradient norm of train_ds.py:381, the loss sums of LISA.py:16-59, bias gradients, the embedding gradient). ---- */
+int haff_reduce_partials(const float* partials, float* out, int n_out, int n_parts, int out_inner, long part_stride,
+                         long group_stride, int accumulate, void* stream);
+int haff_sumsq_partials(const void* g, float* partials /* >= 1024 */, long n, int dtype, int* n_parts, void* stream);
+int haff_mask_loss_stats_partials(const float* x, const float* t, float* partials /* [n_samples][*n_parts][4], n_parts <= 256 */,
+                                  int n_samples, long n, float wgt, int* n_parts, void* stream);
+int haff_colsum_parts(long R);   /* row blocks haff_colsum_partials writes: partials is [parts][C] */
+int haff_colsum_partials(const void* x, float* partials, long R, int C, int dtype, void* stream);
+/* dE[id] += sum of the rows with that id, in the order of a STABLE sort (sorted_ids ascending, order = the permutation) */
+int haff_scatter_add_rows_sorted(const long* sorted_ids, const long* order, const void* dx, float* dE, long rows, int C, int dtype,
+                                 void* stream);
 /* out[r][c] = a[r][c] * alpha[r * alpha_stride]: alpha fp32 in DEVICE memory, one scalar (alpha_stride 0) or one per row (1).
  * The upstream gradient of the loss nodes of LISA.py:414-422 (ce / taxonomy CE) applied in fp32 without a host read. */
 int haff_scale_dev(const void* a, void* out, long rows, long cols, const float* alpha, long alpha_stride, int dtype, void* stream);

@@ -478,3 +478,85 @@ def test_loss_upstream_scalars_stay_in_fp32(dev):
     alpha = torch.tensor([0.3, -1.7, 0.0, 2.5, 1e-3, 1.0], device=dev)
     assert torch.equal(A.scale_dev(a, alpha, per_row=True), a * alpha[:, None])
     assert torch.equal(A.scale_dev(a, alpha[3]), a * 2.5)
+
+
+def test_bucket_adamw_equals_the_per_tensor_update(dev):
+    """train_ops.BucketAdamW (one fused launch per gradient bucket, parameters re-pointed at flat buffers) against
+    train_ops.adamw_step per tensor on the same gradients: bit-identical master weights, moments and bf16 parameter copies
+    over several steps, with the device clip coefficient; `states[name]` are views the checkpoint code can read and write."""
+    import haff  # noqa: F401
+    from haff import train_ops as T
+    shapes = [("lm_head.weight", (37, 64), torch.bfloat16), ("model.text_hidden_fcs.0.0.bias", (64,), torch.float32),
+              ("model.layers.1.self_attn.q_proj.lora_A", (8, 64), torch.bfloat16), ("model.layers.0.self_attn.q_proj.lora_B", (64, 8), torch.bfloat16),
+              ("model.visual_model.mask_decoder_left.x.bias", (5,), torch.float32), ("model.embed_tokens.weight", (323, 64), torch.bfloat16)]
+    named = [(k, _rand(s, dev, torch.float32, 100 + i).to(dt).requires_grad_(True)) for i, (k, s, dt) in enumerate(shapes)]
+    ref_p = {k: p.detach().clone() for k, p in named}
+    ref_s = {k: T.AdamWState(p.detach().clone()) for k, p in named}
+    red = T.GradBucketReducer(named, bucket_bytes=4096)
+    opt = T.BucketAdamW(red, named)
+    assert len(opt.buckets) == len(red.buckets) >= 3
+    for k, p in named:                                        # re-pointed, values kept
+        assert torch.equal(p.detach(), ref_p[k]) and torch.equal(opt.states[k].master, ref_p[k].float())
+    for step in range(1, 4):
+        for i, (k, p) in enumerate(named):
+            p.grad.copy_(_rand(p.shape, dev, torch.float32, 200 + 10 * step + i).to(p.dtype))
+        clip = T.clip_coef_device(T.grad_norm(red.grads()), 1.0)
+        for k, p in named:
+            T.adamw_step(ref_s[k], p.grad.clone(), lr=1e-3, gscale=0.5, param_lp=ref_p[k], gscale_dev=clip)
+        opt.step(lr=1e-3, gscale=0.5, gscale_dev=clip)
+        for k, p in named:
+            st = opt.states[k]
+            assert torch.equal(st.master, ref_s[k].master) and torch.equal(st.m, ref_s[k].m) and torch.equal(st.v, ref_s[k].v), (step, k)
+            assert torch.equal(p.detach(), ref_p[k]), (step, k)      # the parameter the model reads follows the master copy
+            assert st.step == step
+    # resume: values written through the per-key views reach the flat buffers and, after refresh_lp, the parameters
+    opt.states["lm_head.weight"].master.fill_(0.25)
+    opt.refresh_lp()
+    assert float(named[0][1].detach().float().mean()) == 0.25
+
+
+def test_ordered_reductions_are_bitwise_repeatable_and_right(dev):
+    """Round 4: column sums, the mask-loss sums, the embedding scatter and the gradient norm without atomics (per-block partials
+    added in index order / rows of one id added in row order): equal to fp64 references to fp32 rounding and IDENTICAL over
+    repeated launches (the atomic forms of rounds 1-3 differed run to run)."""
+    import haff  # noqa: F401
+    from haff import autograd as A, train_ops as T
+    assert A.ORDERED_REDUCTIONS
+    g = torch.Generator(device="cpu").manual_seed(9)
+    # column sums: tall bf16 (the decoders' 65536 x 256 image-token rows), short fp32, ragged sizes
+    for (R, C, dt) in ((65536, 256, torch.bfloat16), (300, 37, torch.float32), (5000, 1280, torch.bfloat16), (1, 8, torch.float32)):
+        x = (torch.randn((R, C), generator=g) + 0.3).to(dt).to(dev)
+        outs = [A.colsum(x) for _ in range(3)]
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        ref = x.double().sum(0)
+        assert (outs[0].double() - ref).abs().max().item() <= 2e-6 * x.double().abs().sum(0).max().item() + 1e-6
+    # gradient norm over several buckets of different dtypes
+    grads = [torch.randn((1 << 20,), generator=g).to(torch.bfloat16).to(dev), torch.randn((777,), generator=g).to(dev),
+             torch.randn((3_000_001,), generator=g).to(torch.bfloat16).to(dev)]
+    norms = [T.grad_norm(grads) for _ in range(3)]
+    assert torch.equal(norms[0], norms[1]) and torch.equal(norms[0], norms[2])
+    ref = sum(float(t.double().pow(2).sum()) for t in grads) ** 0.5
+    assert abs(float(norms[0]) - ref) <= 2e-6 * ref
+    # mask-loss statistics
+    x = (torch.randn((3, 1024 * 1024), generator=g) * 3).to(dev)
+    t = (torch.rand((3, 1024 * 1024), generator=g) > 0.5).float().to(dev)
+    wg = [1.0, 0.0, 2.0]
+    a = [A.mask_losses(x, t, wg) for _ in range(3)]
+    assert torch.equal(a[0], a[1]) and torch.equal(a[0], a[2])
+    z = x.double() * torch.tensor(wg, dtype=torch.float64, device=dev)[:, None]
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(z, t.double(), reduction="none").mean(1)
+    p = torch.sigmoid(z)
+    dice = 1 - (2 * (p / 1000 * t.double()).sum(1) + 1e-6) / ((p / 1000).sum(1) + (t.double() / 1000).sum(1) + 1e-6)
+    assert (a[0][:, 0].double() - bce).abs().max().item() <= 1e-5 and (a[0][:, 1].double() - dice).abs().max().item() <= 1e-5
+    # embedding scatter with repeated ids and ignored rows
+    ids = torch.tensor([[5, 7, 5, 5, 0, 319, 7, 5]] * 4).to(dev)
+    w = torch.randn((320, 64), generator=g).to(torch.bfloat16).to(dev).requires_grad_(True)
+    dy = torch.randn((4, 8, 64), generator=g).to(torch.bfloat16).to(dev)
+    gs = []
+    for _ in range(3):
+        w.grad = None
+        A.embed(w, ids).backward(dy)
+        gs.append(w.grad.clone())
+    assert torch.equal(gs[0], gs[1]) and torch.equal(gs[0], gs[2])
+    ref = torch.zeros((320, 64), dtype=torch.float64, device=dev).index_add_(0, ids.reshape(-1), dy.double().reshape(-1, 64))
+    assert (gs[0].double() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
