@@ -461,8 +461,10 @@ def test_loss_upstream_scalars_stay_in_fp32(dev):
     import haff  # noqa: F401
     from haff import autograd as A
     g = torch.Generator(device="cpu").manual_seed(5)
-    logits = (torch.randn((37, 323), generator=g) * 2).to(torch.bfloat16).to(dev).requires_grad_(True)
-    labels = torch.randint(0, 323, (37,), generator=g).to(dev)
+    # (4096 rows: the gradient's big entries — the -1 at each label — are rounded to bf16 one by one, +-0.2 % each; their mean
+    # error over 3277 valid rows is ~4e-5, far below the 0.26 % a bf16 upstream scalar would add to every element)
+    logits = (torch.randn((4096, 323), generator=g) * 2).to(torch.bfloat16).to(dev).requires_grad_(True)
+    labels = torch.randint(0, 323, (4096,), generator=g).to(dev)
     labels[::5] = -100
     w = torch.tensor(0.3, device=dev)
     (A.cross_entropy(logits, labels) * w).backward()
@@ -471,7 +473,7 @@ def test_loss_upstream_scalars_stay_in_fp32(dev):
     got, ref = logits.grad.float(), ref_logits.grad
     # against the fp32 gradient: only the bf16 rounding of each stored element (2^-9 relative), no common 0.26 % scale error
     ratio = (got * ref).sum() / (ref * ref).sum()
-    assert abs(float(ratio) - 1.0) < 5e-4, float(ratio)
+    assert abs(float(ratio) - 1.0) < 4e-4, float(ratio)
     assert (got - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
     # per-row form
     a = torch.randn((6, 40), generator=g).to(dev)
