@@ -415,6 +415,64 @@ def make_train_batch(cfg, b, n_ids, mask_hw, device, seed=0):
                 taxonomies_list=torch.eye(4)[torch.arange(b) % 4].to(device), inference=False)
 
 
+def cpu_train_baseline(cfg, n_ids, mask_hw, threads):
+    """cpu_baseline of the --mode train line: ONE fine-tune step (forward + backward of model_forward, LISA.py:175-430) of the CPU
+    oracle under torch autograd on ONE sample at FULL WIDTH and REDUCED DEPTH (2 ViT-H blocks, 2 CLIP layers; 1 and 2 Llama
+    layers), fp32, `threads` host threads; the full-depth step is extrapolated from the per-layer differences and labelled so.
+    The reference's trainable set (LoRA r = 8 on q/v_proj + embed_tokens, lm_head, text_hidden_fcs, both mask decoders)."""
+    import copy
+    from oracle import lisa_oracle as O
+    torch.set_num_threads(threads)
+    V = "model.visual_model"
+    g = torch.Generator().manual_seed(0)
+
+    def one(llm_layers):
+        small = copy.deepcopy(cfg)
+        small.sam.depth, small.sam.global_idx = 2, (1,)
+        small.clip.layers, small.clip.select_layer = 2, 2
+        small.llm.layers = llm_layers
+        sd = hw.make_state_dict(small, 99)
+        lora = {}
+        for i in range(llm_layers):
+            for n in ("q_proj", "v_proj"):
+                k = f"model.layers.{i}.self_attn.{n}"
+                lora[k + ".lora_A"] = (torch.randn((8, small.llm.hidden), generator=g) * 0.02).requires_grad_(True)
+                lora[k + ".lora_B"] = (torch.randn((small.llm.hidden, 8), generator=g) * 0.02).requires_grad_(True)
+        for k in list(sd):
+            if k in ("lm_head.weight", "model.embed_tokens.weight") or "text_hidden_fcs" in k or "mask_decoder_" in k:
+                sd[k] = sd[k].requires_grad_(True)
+        batch = make_train_batch(small, 1, n_ids, mask_hw, "cpu", seed=5)
+        batch = {k: (v.float() if torch.is_tensor(v) and v.dtype == torch.bfloat16 else v) for k, v in batch.items()}
+        t0 = time.perf_counter()
+        out = O.lisa_model_forward(sd, small, batch, lora=lora, lora_alpha=16.0)
+        t1 = time.perf_counter()
+        out["loss"].backward()
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, float(out["loss"].detach())
+    f1, b1, _ = one(1)
+    f2, b2, loss = one(2)
+    per_llm = max((f2 + b2) - (f1 + b1), 1e-6)
+    # the frozen towers run forward only: per-block times of the encoder / CLIP from the inference baseline's recipe
+    s = copy.deepcopy(cfg.sam)
+    s.depth, s.global_idx = 2, (1,)
+    sd = hw.make_state_dict(copy.deepcopy(cfg), 98, {k: v for k, v in hw.all_shapes(cfg).items() if ".image_encoder.blocks.0." in k or ".image_encoder.blocks.7." in k})
+    x = torch.randn((1, s.grid, s.grid, s.embed_dim), generator=g)
+    with torch.no_grad():
+        t = time.perf_counter(); O.sam_block(sd, V + ".image_encoder.blocks.0", x, s.heads, s.window); t_win = time.perf_counter() - t
+        t = time.perf_counter(); O.sam_block(sd, V + ".image_encoder.blocks.7", x, s.heads, 0); t_glob = time.perf_counter() - t
+    n_glob = len(cfg.sam.global_idx)
+    extra_sam = (cfg.sam.depth - n_glob - 1) * t_win + (n_glob - 1) * t_glob
+    t_full = (f1 + b1) + (cfg.llm.layers - 1) * per_llm + extra_sam
+    return {"value": 1.0 / t_full, "unit": "samples/s", "cores": threads, "kind": "port", "extrapolated": True,
+            "sample": ("CPU oracle (oracle/lisa_oracle.py under torch autograd, fp32) — ONE sample, %d-id conversation, %dx%d masks, full "
+                       "width, reduced depth: measured forward + backward with 1 and 2 Llama layers (2 ViT-H blocks, 2 CLIP layers), "
+                       "full depth = that + (layers - 1) x the difference + the remaining frozen ViT-H blocks forward" %
+                       (n_ids, mask_hw[0], mask_hw[1])),
+            "measured_s": {"fwd_1_layer": f1, "bwd_1_layer": b1, "fwd_2_layers": f2, "bwd_2_layers": b2, "vit_h_window_block_fwd": t_win,
+                           "vit_h_global_block_fwd": t_glob},
+            "seconds_per_sample_full_depth_extrapolated": t_full, "loss_of_the_reduced_model": loss}
+
+
 def train_main(args):
     """--mode train: BASELINE.json configs[3] — LoRA fine-tune (train_ds.py path), bf16, 8 synthetic 2HANDS samples per GPU per
     step (global batch 64 on 8 GPUs), 96-id conversations (351 expanded tokens), 1024^2 masks. A step = forward + backward of
@@ -497,6 +555,8 @@ def train_main(args):
                              "by_shape": meter.shape_summary(top=24)},
                 "cpu_baseline": None,
                 "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_train_baseline(cfg, args.train_ids, (args.train_mask, args.train_mask), min(len(os.sched_getaffinity(0)), 32))
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
