@@ -206,9 +206,24 @@ def parity_vs_oracle(device):
                 n_pix += dis.numel()
                 if dis.any():
                     margins.append((r[dis].abs().max() / r.std()).item())
+            # IoU over the pixels OUTSIDE a thin band around the oracle's threshold (|oracle logit| >= 1 % / 2 % of its maximum):
+            # on a trained checkpoint's two-plateau field that band is the object boundary and nothing else; here it says
+            # whether every disagreement is a near-zero logit (1.0) or a real difference (< 1)
+            band = {}
+            for tau in (0.01, 0.02):
+                ib, fr = [], []
+                for got, ref in pairs:
+                    gg, r = got.float().cpu(), ref
+                    keep = r.abs() >= tau * r.abs().max()
+                    a, b = (gg > 0) & keep, (r > 0) & keep
+                    union = (a | b).sum().item()
+                    ib.append((a & b).sum().item() / union if union else 1.0)
+                    fr.append(1.0 - keep.float().mean().item())
+                band["%g" % tau] = {"mask_iou": min(ib), "band_pixel_frac": max(fr)}
             return {"mask_iou_vs_oracle": min(ious), "mask_logit_max_err_rel": max(errs),
                     "pixels_disagreeing_frac": flips / n_pix,
-                    "max_oracle_logit_at_disagreeing_pixels_in_logit_std": max(margins) if margins else 0.0}
+                    "max_oracle_logit_at_disagreeing_pixels_in_logit_std": max(margins) if margins else 0.0,
+                    "mask_iou_outside_threshold_band": band}
         res = {"iou_floor_exact_pipeline_with_bf16_rounded_embedding": stats(((fl_l, r_left[0]), (fl_r, r_right[0])))["mask_iou_vs_oracle"]}
         for name, dt, tail in (("bf16", torch.bfloat16, True), ("bf16_all", torch.bfloat16, False), ("fp32", torch.float32, True)):
             model = LisaMI355(cfg, sd, dtype=dt, device=device, fp32_tail=tail)
@@ -223,6 +238,27 @@ def parity_vs_oracle(device):
             res[name] = st
             del model
         out[cfg_name] = res
+    # Round 4: a frame of two flat regions + the hypernetwork bias re-aimed along Fisher's direction between
+    # the two clusters of the oracle's upscaled embedding, plateaus at +-10 (tools/parity_bimodal.py; profiles/r4_parity_bimodal_cpu.txt
+    # lists 12 seeds x 2 hands: no collapse — 45..59 % positive — but the clusters of a RANDOM encoder are only ~3 scatter widths
+    # apart, so the field is still far from a trained checkpoint's: the number is reported beside the Gaussian-field one, not
+    # instead of it)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import parity_bimodal as PB
+        case = PB.build_case("tiny", 3)
+        cfgb, S = case["cfg"], case["cfg"].sam.img_size
+        model = LisaMI355(cfgb, case["sd"], dtype=torch.bfloat16, device=device, fp32_tail=True)
+        o_ids, left, right, tax = model.evaluate(case["images_clip"].to(device), case["images"].to(device), case["ids"].to(device),
+                                                 [(S, S)], [(S, S)], max_new_tokens=4, forced_answer=case["forced"])
+        r_ids, r_left, r_right, _ = case["oracle"]
+        st = stats(((left[0], r_left[0]), (right[0], r_right[0])))
+        st["token_ids_equal"] = bool(torch.equal(o_ids.cpu(), r_ids))
+        st["oracle_field"] = case["diag"]
+        out["two_region_tiny_bf16"] = st
+        del model
+    except Exception as e:   # the extra case must not take the benchmark line down
+        out["two_region_tiny_bf16"] = {"error": repr(e)}
     # the keys round 1 reported, for continuity: configs[0]
     out["config"] = "BASELINE.json configs[0] (tiny) and the mid geometry, 1 frame each, forced answer with one [SEG]"
     out["bf16"], out["fp32"] = out["tiny"]["bf16"], out["tiny"]["fp32"]

@@ -240,6 +240,8 @@ def sam_mask_decoder(sd, pfx, image_embeddings, image_pe, sparse, dense, taxonom
     if taps is not None:
         taps["upscaled"] = up.clone()
     hyper = torch.stack([_mlp(sd, f"{pfx}.output_hypernetworks_mlps.{i}", mask_toks[:, i, :], 3) for i in range(4)], dim=1)
+    if taps is not None:
+        taps["hyper"] = hyper.clone()
     b, c, h, w = up.shape
     masks = (hyper @ up.view(b, c, h * w)).view(b, 4, h, w)
     iou = _mlp(sd, pfx + ".iou_prediction_head", iou_tok, 3)

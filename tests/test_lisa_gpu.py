@@ -94,6 +94,11 @@ def test_evaluate_matches_oracle(dev, cfg_name, mode):
                 assert err <= 1.5e-2 * scale, f"{name} logits rel err {err / scale}"
                 assert err <= 3.0 * floor + 2e-3 * scale, f"{name}: {err / scale:.3e} vs floor {floor / scale:.3e}"
                 assert iou >= 0.985
+                # every pixel the bf16 path decides differently is a near-zero logit of the exact forward: outside a band of 2 % of
+                # the logit scale around the threshold the two masks are IDENTICAL (on a trained checkpoint's two-plateau field
+                # that band is the object boundary; on these Gaussian fields it holds ~1-2 % of the pixels)
+                keep = ref.abs() >= 0.02 * scale
+                assert torch.equal((g > 0)[keep], (ref > 0)[keep]), f"{name}: a disagreement at |logit| >= 2 % of the scale"
         terr = (tax[i].cpu() - ref_t[i]).abs().max().item()
         print(f"{cfg_name}/{mode} frame{i} taxonomy err {terr:.3e}")
         assert terr <= (1e-4 if mode == "f32" else 1e-3)   # measured 1.1e-4 ... 2.4e-4 in bf16 mode
@@ -380,3 +385,35 @@ def test_free_running_greedy_tokens_match_oracle(dev):
             ref, rh = O.lisa_generate(sd, cfg, images_clip, ids, 6, None, use_cache=True)
         assert torch.equal(got.cpu(), ref), (cfg_name, got.cpu(), ref)
         assert (hid.float().cpu() - rh).abs().max().item() <= 2e-4 * rh.abs().max().item()
+
+
+def test_two_region_frame_with_aimed_hypernetwork_bias(dev):
+    """VERDICT r3 item 7 — parity on a field with two plateaus: a frame of two flat regions, the last bias of
+    output_hypernetworks_mlps.0 of each decoder shifted (from the ORACLE's own fp32 forward) so that the mask logits sit around
+    +10 / -10 on the two regions (tools/parity_bimodal.py; Fisher's direction between the two clusters of the upscaled
+    embedding). Both sides run the same modified weights. The construction is robust (12 seeds x 2 hands without a collapsed
+    mask, profiles/r4_parity_bimodal_cpu.txt) but a RANDOM encoder separates the clusters by only ~3 scatter widths, so the field
+    is not a trained checkpoint's: held here are the same bounds as on the Gaussian fields plus the band rule."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_bimodal as PB
+    from haff.lisa import LisaMI355
+    case = PB.build_case("tiny", 3)
+    cfg, S = case["cfg"], case["cfg"].sam.img_size
+    for side in ("left", "right"):
+        d = case["diag"][side]
+        assert 0.35 <= d["positive_frac"] <= 0.65 and 8.0 <= d["plateau_median_abs_logit"] <= 14.0, d   # two regions, plateaus near +-10
+    model = LisaMI355(cfg, case["sd"], dtype=torch.bfloat16, device=dev)
+    o_ids, left, right, tax = model.evaluate(case["images_clip"].to(dev), case["images"].to(dev), case["ids"].to(dev), [(S, S)], [(S, S)],
+                                             max_new_tokens=4, forced_answer=case["forced"])
+    r_ids, r_left, r_right, _ = case["oracle"]
+    assert torch.equal(o_ids.cpu(), r_ids)
+    for got, ref, name in ((left[0], r_left[0], "left"), (right[0], r_right[0], "right")):
+        g = got.cpu()
+        scale = ref.abs().max().item()
+        err = (g - ref).abs().max().item()
+        iou = _iou(g > 0, ref > 0)
+        print(f"two-region {name}: max|err| {err / scale:.3e} of scale {scale:.1f}, IoU {iou:.5f}")
+        assert err <= 1.5e-2 * scale and iou >= 0.985
+        keep = ref.abs() >= 0.02 * scale
+        assert torch.equal((g > 0)[keep], (ref > 0)[keep])
