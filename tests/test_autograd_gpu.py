@@ -474,7 +474,7 @@ def test_loss_upstream_scalars_stay_in_fp32(dev):
     # against the fp32 gradient: only the bf16 rounding of each stored element (2^-9 relative), no common 0.26 % scale error
     ratio = (got * ref).sum() / (ref * ref).sum()
     assert abs(float(ratio) - 1.0) < 4e-4, float(ratio)
-    assert (got - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()   # (two bf16 roundings: the stored dlogits, the scaled result)
     # per-row form
     a = torch.randn((6, 40), generator=g).to(dev)
     alpha = torch.tensor([0.3, -1.7, 0.0, 2.5, 1e-3, 1.0], device=dev)

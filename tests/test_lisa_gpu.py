@@ -8,6 +8,8 @@ Tolerances (stated per BASELINE.json north_star):
     activations bounds the error by a few percent of the logit scale, checked as rel <= 6e-2 of the max |logit|
     and mask IoU >= 0.97 on these random-weight models (random logits are dense around 0; SURVEY §7 hard part 3).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
