@@ -69,7 +69,9 @@ typedef __attribute__((address_space(3))) bf16x4* lds_v4_ptr;
 template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false, bool FULL = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   static_assert(!FULL || (!CAUSAL && BIAS != 3), "FULL tiles only");
-  constexpr int KSTRIDE = DP * 2 + 16;  // bytes
+  // K rows: the fragment read (lane = (key fr, d-chunk fh): 16 B at row fr, column 16 fh) is conflict-free exactly for row strides
+  // of 32 modulo 64 bytes (tools/probes/lds_b128_pattern.hip; the DP * 2 + 16 of rounds 1-3 ran every K read at half rate)
+  constexpr int KSTRIDE = (DP * 2) % 64 == 32 ? DP * 2 : DP * 2 + 32;  // bytes
   constexpr int VSTRIDE = DP * 2 + 32;
   constexpr int NCH = DP / 32;          // 16-B chunks per thread per operand per tile
   constexpr int CPR = DP / 8;           // chunks per row
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
 template <int DP, int BIAS, bool CAUSAL, int NDT = DP / 16, bool LSUM = false, bool FULL = false>
 int launch_attn(const AttnArgs& p, hipStream_t s) {
-  constexpr int KSTRIDE = DP * 2 + 16, VSTRIDE = DP * 2 + 32;
+  constexpr int KSTRIDE = (DP * 2) % 64 == 32 ? DP * 2 : DP * 2 + 32, VSTRIDE = DP * 2 + 32;   // (the kernel's)
   size_t lds = 2 * ((size_t)KT * KSTRIDE + (size_t)KT * VSTRIDE);
   if (BIAS == 1) lds += (size_t)QB * (2 * 32 + 1) * sizeof(float);
   dim3 grid(((p.Nq + QB - 1) / QB) * p.H * p.B), block(256);
@@ -501,9 +503,8 @@ int launch_attn(const AttnArgs& p, hipStream_t s) {
 //     2t+2        softmax(t)        [VALU]      PV(t-1) + QK(t)   [MFMA]
 //
 // so each SIMD always has one wave on the matrix pipe and one on the VALU. K/V tiles come in by LDS-DMA
-// (global_load_lds_dwordx4, slot-linear image: K rows 11 x 16 B = 10 data chunks + 1 pad chunk, V rows 10 chunks — the
-// window kernel's layout; the pad chunk re-reads chunk 0 of its row and is never consumed), four stages each; the request /
-// wait schedule is written out at `tile` below.
+// (global_load_lds_dwordx4, slot-linear image: K and V rows of 10 x 16 B, no padding — see PP_KSTR), four stages each; the
+// request / wait schedule is written out at `tile` below.
 // rel_h of the workgroup's 256 queries (256 x 64 fp32, contiguous in the table) is copied to LDS once: the tile loop then
 // holds no global load except the DMA, so the counted waits are exactly the ones written here.
 // The softmax denominator comes out of one extra MFMA per (k-step, q-tile) against a register fragment of ones (the same
@@ -520,7 +521,13 @@ int launch_attn(const AttnArgs& p, hipStream_t s) {
 // accumulator / score registers on the common path.
 constexpr int PPQ = 256;                         // queries per workgroup
 constexpr int PP_D = 80, PP_CPR = PP_D / 8;      // head dim, 16-B chunks per row
-constexpr int PP_KSTR = (PP_CPR + 1) * 16, PP_VSTR = PP_CPR * 16;
+// Round 4: K rows UNPADDED (160 B). The 176-byte rows of round 3 (one pad chunk, borrowed from the window kernel) made every K
+// fragment read — lane (key fr, d-chunk fh): 16 B at row fr, column 16 fh — a 2-way bank conflict: PMC counted 3.4 conflict cycles
+// per ds_read_b128 of K and none on the V^T reads (profiles/r4_pmc_attn_global_lds.txt), and tools/probes/lds_b128_pattern.hip
+// shows why: that access pattern runs at the LDS's full rate exactly when the row stride is 32 modulo 64 bytes (160, 224, 288:
+// 18 clocks per read and wave with 4 waves reading) and at half of it for 144 / 176 / 192 / 208 / 240 / 272 (32 clocks).
+constexpr int PP_KSTR = PP_CPR * 16, PP_VSTR = PP_CPR * 16;
+static_assert(PP_KSTR % 64 == 32, "K fragment reads are conflict-free for row strides of 32 mod 64 bytes");
 constexpr int PP_KBYTES = KT * PP_KSTR, PP_VBYTES = KT * PP_VSTR;
 constexpr int PP_KINS = PP_KBYTES / 1024, PP_VINS = PP_VBYTES / 1024;   // DMA instructions (64 lanes x 16 B) per tile
 constexpr int PP_NST = 4;
@@ -590,8 +597,8 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  // ---- DMA plan: combined instruction index n = wave + 8 i (n < 11: K, else V), lane -> slot -> source byte offset ----
-  constexpr int NINS = PP_KINS + PP_VINS;   // 21
+  // ---- DMA plan: combined instruction index n = wave + 8 i (n < 10: K, else V), lane -> slot -> source byte offset ----
+  constexpr int NINS = PP_KINS + PP_VINS;   // 20
   unsigned d_off[3];
   const unsigned v_minus_k = (unsigned)((p.v - p.k) * 2);   // bytes; host checked: same for every (batch, head), >= 0
   int n_kins = 0, n_vins = 0;                                // this wave's instructions per K tile / per V tile
@@ -600,8 +607,8 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
     const int n = wave + 8 * i;
     unsigned off = 0;
     if (n < PP_KINS) {
-      const int g = n * 64 + lane, row = g / (PP_CPR + 1), c = g - row * (PP_CPR + 1);
-      off = (unsigned)(row * p.k_st * 2) + (c < PP_CPR ? c * 16 : 0);
+      const int g = n * 64 + lane, row = g / PP_CPR, c = g - row * PP_CPR;
+      off = (unsigned)(row * p.k_st * 2) + c * 16;
       ++n_kins;
     } else if (n < NINS) {
       const int g = (n - PP_KINS) * 64 + lane, row = g / PP_CPR, c = g - row * PP_CPR;
@@ -792,6 +799,9 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
   // LDS -> fragment loads. Stage bases are compile-time, so each is one ds_read with an immediate offset.
   auto load_v = [&](auto stage, auto ks_tag, bf16x8 (&vf)[ND]) {   // V^T fragments of k-step ks (keys 32ks .. 32ks+31)
     constexpr int ST = decltype(stage)::value, ks = decltype(ks_tag)::value;
+#if defined(HAFF_TUNING) && defined(HAFF_PP_NOVREAD)   // counter / timing experiment: the V^T fragment reads are left out (wrong results)
+    if (ST >= 0) return;
+#endif
     const unsigned char* v0 = smem_raw + PP_NST * PP_KBYTES + ST * PP_VBYTES + v_lane + (32 * ks) * PP_VSTR;
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) {
@@ -802,6 +812,9 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
   };
   auto load_k = [&](auto stage, auto kd_tag, bf16x8 (&kf)[4]) {    // K fragments of head-dim step kd, the 4 key tiles
     constexpr int ST = decltype(stage)::value, kd = decltype(kd_tag)::value;
+#if defined(HAFF_TUNING) && defined(HAFF_PP_NOKREAD)   // counter / timing experiment: the K fragment reads are left out (wrong results)
+    if (ST >= 0) return;
+#endif
     const unsigned char* k0 = smem_raw + ST * PP_KBYTES + (kd < 2 ? k_lane01 + kd * 64 : k_lane2);
 #pragma unroll
     for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(k0 + 16 * t * PP_KSTR);
@@ -834,6 +847,10 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
   // slot X-3 and waits at the end of its VALU slot X-1 (two newer batches in flight). The stages those requests overwrite
   // (K[X-3], V[X-4]) were last read two or more barriers earlier by both groups.
   bf16x8 vf0[ND], vf1[ND], kf0[4];
+#if defined(HAFF_TUNING) && (defined(HAFF_PP_NOVREAD) || defined(HAFF_PP_NOKREAD))
+  for (int i = 0; i < ND; ++i) { vf0[i] = ones; vf1[i] = ones; }
+  for (int i = 0; i < 4; ++i) kf0[i] = ones;
+#endif
   f32x4 sacc[4][2];
   auto batch_cnt = [&](int x) { return (x + 1 < nkt ? n_kins : 0) + (x < nkt ? n_vins : 0); };
   auto wait_vm = [&](int n) {   // wave-uniform n: at most n of my requests still in flight
@@ -863,6 +880,9 @@ __global__ __launch_bounds__(512, 1) void attn_global_pp_kernel(AttnArgs p) {
     PP_STAMP(0);
     // ================= MFMA slot =================
     bf16x8 kf1[4], kf2[4];
+#if defined(HAFF_TUNING) && defined(HAFF_PP_NOKREAD)
+    for (int i = 0; i < 4; ++i) { kf1[i] = ones; kf2[i] = ones; }
+#endif
     __builtin_amdgcn_s_setprio(1);
 #if !(defined(HAFF_TUNING) && defined(HAFF_PP_NOMFMA))
     auto qk = [&](auto kd_tag, const bf16x8 (&kf)[4]) {   // S^T += K . Q^T over head-dim step kd

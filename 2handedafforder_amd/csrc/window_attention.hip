@@ -10,8 +10,8 @@
 // fp32 tables per (query, head). This path is HBM-bound (98 flop/B), so the design goal is: q, k, v read once, out
 // written once, nothing else touches HBM.
 //
-// An item is one (window, head). Its K and V are staged once into LDS (K rows padded to 176 B -> conflict-light
-// ds_read_b128; V rows unpadded 160 B, which is conflict-free for ds_read_b64_tr_b16: 8 consecutive rows x 40 dwords
+// An item is one (window, head). Its K and V are staged once into LDS (K rows 160 B since round 4 — see WinCfg::KSTR;
+// V rows unpadded 160 B, which is conflict-free for ds_read_b64_tr_b16: 8 consecutive rows x 40 dwords
 // hit 8 disjoint 8-bank groups). 7 waves share an item, each taking query-grid rows qh = wave and wave+7: a q-tile is
 // ONE grid row (14 real queries + 2 masked lanes), keys are visited as 14 tiles = 14 grid rows of 16 virtual columns
 // (kw >= 14 masked), so
@@ -61,14 +61,21 @@ struct WinCfg {
   static constexpr int NKD = (D + 31) / 32;     // 32-deep k-steps over the head dim (last one zero-padded in Q)
   static constexpr int ND = D / 16;             // output d-tiles
   static constexpr int CPR = D / 8;             // 16-B chunks per row
-  static constexpr int KSTR = D * 2 + 16;       // bytes; the 16 pad bytes are zeroed (read by the padded k-step)
+  // K rows (round 4): the fragment read — lane (key column fr, d-chunk fh): 16 B at row fr, column 16 fh — runs at the LDS's
+  // full rate exactly for row strides of 32 modulo 64 bytes (tools/probes/lds_b128_pattern.hip: 160, 224, 288 -> 18 clocks per
+  // read and wave, 176 -> 32). d = 80 needs no pad chunk at all: the 176-byte rows of rounds 1-3 made every K read a 2-way bank
+  // conflict. KPC pad chunks (0 for d = 80, 2 otherwise) re-read chunk 0 of their row: finite, multiplied by zero Q columns. The
+  // padded third k-step of d = 80 reads the first chunks of the NEXT row (or of V behind the last K row) there instead: finite
+  // data against the same zero Q columns.
+  static constexpr int KPC = (D * 2) % 64 == 32 ? 0 : 2;
+  static constexpr int KSTR = D * 2 + 16 * KPC;   // bytes
   static constexpr int VSTR = D * 2;
   static constexpr int NKS = (S + 1) / 2;       // P.V k-steps: two key tiles (grid rows) each
   static constexpr int RS = 36;                 // scratch row stride in floats
   static constexpr int QPW = 2;                 // q-tiles (query-grid rows) per wave per item
   static constexpr int NWAVES = (S + QPW - 1) / QPW;   // 7 waves cover the 14 grid rows exactly
   static constexpr int NTHREADS = 64 * NWAVES;
-  static constexpr int KSLOTS = N * (CPR + 1), VSLOTS = N * CPR;   // 16-B DMA slots: K rows carry one pad slot
+  static constexpr int KSLOTS = N * (CPR + KPC), VSLOTS = N * CPR;   // 16-B DMA slots
   static constexpr int K_BYTES = N * KSTR, V_BYTES = N * VSTR;
   static constexpr int PAD_SLOTS = (KSLOTS + VSLOTS + 63) / 64 * 64;   // whole DMA instructions; the tail slots hold zeros
   static constexpr int BUF_BYTES = PAD_SLOTS * 16;
@@ -110,10 +117,10 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
 
   // Staging is HBM -> LDS DMA (global_load_lds_dwordx4: no VGPR round trip, nothing to write back after the
   // compute): the LDS image is slot-linear (lane i of an instruction lands at base + 16*i), each lane picks the source
-  // chunk of its slot. K rows are 11 slots (10 data + 1 pad fed from a zero page), V rows 10 slots.
+  // chunk of its slot. K rows are CPR + KPC slots, V rows CPR slots.
   constexpr int TOTAL_SLOTS = C::KSLOTS + C::VSLOTS;
   constexpr int NDMA = (C::PAD_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
-  static_assert((C::K_BYTES % 16) == 0 && C::KSTR == (C::CPR + 1) * 16 && C::VSTR == C::CPR * 16, "slot layout");
+  static_assert((C::K_BYTES % 16) == 0 && C::KSTR == (C::CPR + C::KPC) * 16 && C::VSTR == C::CPR * 16 && C::KSTR % 64 == 32, "slot layout");
   // byte offset of each slot's source relative to the item's K view (V = K + a constant for the fused qkv layout the
   // caller passes; checked on the host). Pad / tail slots re-read chunk 0 of a K row: they only have to be finite
   // (the matching Q columns are zero).
@@ -128,7 +135,7 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
     if (sl >= TOTAL_SLOTS) {
       off = 0;
     } else if (sl < C::KSLOTS) {
-      const int row = sl / (C::CPR + 1), c = sl - row * (C::CPR + 1);
+      const int row = sl / (C::CPR + C::KPC), c = sl - row * (C::CPR + C::KPC);
       off = (long)row * p.k_st + (c < C::CPR ? c * 8 : 0);
       pad = ((unsigned)(row / S) << 28) | ((unsigned)(row % S) << 24) | (unsigned)((c < C::CPR ? c : 0) * 16);
     } else {
