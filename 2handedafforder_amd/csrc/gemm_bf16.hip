@@ -1521,153 +1521,6 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(GemmArgs p) {
   }
 }
 
-// ---- weight-stationary tile for 65..320 rows (round 4): Llama prefill / CLIP / [SEG] products of ONE frame ----
-// (LlamaDecoderLayer / CLIPEncoderLayer as reached from llava_llama.py:93-102 at batch 1: 257..291 rows against 4096..22016
-// weight rows.) The 128x128 tile cut such a product into three row tiles, the last a quarter full: every weight tile went from
-// L2 to LDS three times and a quarter of the MFMAs multiplied padding (288 x 12288 x 4096: 69 us = 1.45 TB/s on the weight
-// stream, 419 TFLOP/s). Here a workgroup takes ALL rows of A (up to 320) and 128 weight rows over one K slice: a weight byte is
-// fetched once by one workgroup, the activations (2.4 MB) come from L2. 8 waves = 4 (80 rows) x 2 (64 columns), 80
-// accumulators per lane; K-tiles of 32 in a 5-stage LDS ring (28 KiB per stage: rows of 64 B, 16-B chunks XOR-placed so the
-// MFMA fragment read is conflict-free in each of ds_read_b128's four lane groups: tools/probes/gemm_w4.hip), four K-tiles of
-// LDS-DMA in flight behind ONE counted wait and ONE barrier per K-tile. fp32 partial tiles go to ws[slice][M][N];
-// skinny_reduce_kernel adds the slices in index order and applies the epilogue (deterministic, like the split-K tile path).
-constexpr int MID_ROWS = 320, MID_BN = 128, MID_BK = 32, MID_STAGES = 5;
-constexpr int MID_A_BYTES = MID_ROWS * MID_BK * 2;                    // 20 KiB
-constexpr int MID_STAGE_BYTES = MID_A_BYTES + MID_BN * MID_BK * 2;   // 28 KiB
-
-__global__ __launch_bounds__(512) void gemm_mid_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[MID_STAGES * MID_STAGE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wmr = wave & 3, wnc = wave >> 2;
-  const int fr = lane & 15, fh = lane >> 4;
-  const int n0 = blockIdx.x * MID_BN;
-  const int zi = blockIdx.y;
-  const int k_begin = zi * p.K;                                  // p.K = K columns per slice, p.k_total = all of them
-  const int nkt = min(p.K, p.k_total - k_begin) / MID_BK;
-
-  // four requests per wave and K-tile: A rows 0-127, 128-255, 256-319 (waves 0-3; waves 4-7 repeat their W request instead, so
-  // that every wave counts the same), W rows 0-127. LDS position pos = i * 512 + tid; row = pos >> 2; physical chunk pos & 3 holds
-  // logical chunk (pos & 3) ^ ((-(row >> 2)) & 3)
-  unsigned g_off[4];
-  unsigned l_off[4];
-  bool is_w[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool w_req = i == 3 || (i == 2 && wave >= 4);
-    const int pos = w_req ? tid : i * 512 + tid;
-    const int row = pos >> 2;
-    const int lch = (pos & 3) ^ ((-(row >> 2)) & 3);
-    is_w[i] = w_req;
-    if (w_req) {
-      g_off[i] = ((unsigned)min(n0 + row, p.N - 1) * (unsigned)p.ldw + lch * 8) * 2u;
-      l_off[i] = MID_A_BYTES + wave * 1024;
-    } else {
-      g_off[i] = ((unsigned)min(row, p.M - 1) * (unsigned)p.lda + lch * 8) * 2u;
-      l_off[i] = (i * 512 + wave * 64) * 16;
-    }
-  }
-  auto request = [&](int kt, int st) {
-    const bf16_t* a_base = p.A + k_begin + kt * MID_BK;
-    const bf16_t* w_base = p.W + k_begin + kt * MID_BK;
-    asm volatile("" : "+s"(a_base));
-    asm volatile("" : "+s"(w_base));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned o = g_off[i];
-      asm volatile("" : "+v"(o));
-      const char* g = reinterpret_cast<const char*>(is_w[i] ? w_base : a_base) + o;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(smem + st * MID_STAGE_BYTES + l_off[i]), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][5];   // [ni][mi]
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const unsigned sw = (unsigned)((fh ^ ((-(fr >> 2)) & 3)) << 4);
-  const unsigned rd_a = (wmr * 80 + fr) * 64 + sw;
-  const unsigned rd_w = MID_A_BYTES + (wnc * 64 + fr) * 64 + sw;
-
-#pragma unroll
-  for (int kt = 0; kt < MID_STAGES - 1; ++kt)
-    if (kt < nkt) request(kt, kt);
-  int st = 0;   // stage of K-tile kt
-  for (int kt = 0; kt < nkt; ++kt) {
-    // my share of K-tile kt has landed; up to three later K-tiles stay in flight (four requests each)
-    const int later = nkt - 1 - kt;
-    if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();   // every wave's share is there, and every wave is done with K-tile kt - 1 (its MFMAs were issued)
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + MID_STAGES - 1 < nkt) {
-      const int st_free = st == 0 ? MID_STAGES - 1 : st - 1;   // the stage of K-tile kt - 1
-      request(kt + MID_STAGES - 1, st_free);
-    }
-    const unsigned char* sb = smem + st * MID_STAGE_BYTES;
-    bf16x8 af[5], wf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(sb + rd_w + t * 1024);
-#pragma unroll
-    for (int t = 0; t < 5; ++t) af[t] = *reinterpret_cast<const bf16x8*>(sb + rd_a + t * 1024);
-#pragma unroll
-    for (int mi = 0; mi < 5; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-    st = st == MID_STAGES - 1 ? 0 : st + 1;
-  }
-  // fp32 partial tile: lane holds D[n = 4 * fh + r][m = fr] of each 16x16 tile
-  float* wsz = p.ws + (long)zi * p.M * p.N;
-#pragma unroll
-  for (int mi = 0; mi < 5; ++mi) {
-    const int m = wmr * 80 + mi * 16 + fr;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wnc * 64 + ni * 16 + 4 * fh;
-      if (n + 3 < p.N) *reinterpret_cast<f32x4*>(wsz + (long)m * p.N + n) = acc[ni][mi];
-    }
-  }
-}
-
-// Picks the K split of the weight-stationary launch: whole rounds of the 256 CUs, slices of at least 16 K-tiles, partial
-// tiles that fit the workspace. Returns false when the shape is not this kernel's.
-static bool launch_mid(GemmArgs& p, void* workspace, long workspace_bytes, hipStream_t s) {
-  const int M = p.M, N = p.N, K = p.K;
-  if (M <= 64 || M > MID_ROWS || !workspace || p.ln_stats || p.a_map || (K % MID_BK) || (N % 4) || N < 512 || K < 512) return false;
-  if ((long)N * p.ldw * 2 >= (1L << 32) || (long)M * p.lda * 2 >= (1L << 32)) return false;
-  const int nt = (N + MID_BN - 1) / MID_BN, nkt = K / MID_BK;
-  int best_ks = 0, best_kc = 0;
-  double best_t = 1e30;
-  for (int ks = 1; ks <= 16; ++ks) {
-    const int kc = (nkt + ks - 1) / ks;            // K-tiles per slice
-    const int n_sl = (nkt + kc - 1) / kc;          // slices that are not empty
-    if (n_sl != ks || (kc < 16 && ks > 1)) continue;
-    if (4L * n_sl * M * N > workspace_bytes) continue;
-    const long wgs = (long)nt * n_sl;
-    const long rounds = (wgs + 255) / 256;
-    // per round: the slice's K-tiles at ~0.35 us (640 MFMA cycles per SIMD) + fill / drain; partials written and read back at ~4 TB/s
-    const double t = rounds * (kc * 0.35 + 4.0) + 2.0 * 4.0 * n_sl * M * N / 4.0e6 + (n_sl > 1 ? 0.0 : 0.0);
-    if (t < best_t) { best_t = t; best_ks = n_sl; best_kc = kc; }
-  }
-  if (!best_ks) return false;
-  GemmArgs q = p;
-  q.ws = reinterpret_cast<float*>(workspace);
-  q.K = best_kc * MID_BK;
-  q.k_total = K;
-  hipLaunchKernelGGL(gemm_mid_kernel, dim3(nt, best_ks), dim3(512), 0, s, q);
-  p.ws = reinterpret_cast<float*>(workspace);
-  p.ksplit = best_ks;
-  const long n_thr = p.swiglu ? (long)M * (N / 8) : (long)M * ((N + 3) / 4);
-  hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, p);
-  return true;
-}
-
 // Split-K launch for the 64-row decode products on narrow weights (N <= 8192: o_proj, down_proj): with 16 weight rows per
 // workgroup every workgroup re-reads the whole activation matrix from L2 (4x the weight bytes at K = 4096, 1.4 MB per
 // workgroup at K = 11008) and the fabric, not HBM, sets the time. 64 (or 32) rows per workgroup and 4 (or 2) K slices keep
@@ -1796,15 +1649,6 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
     else if (M <= 32) launch_skinny<2>(p, N, swiglu, s);
     else launch_skinny<4>(p, N, swiglu, s);
     return haff_check_launch();
-  }
-  // 65..320 rows: the weight-stationary tile (one frame's prefill / CLIP / decoder products)
-  {
-    bool mid_on = tile_cfg == 0;
-#ifdef HAFF_TUNING   // HAFF_GEMM_NO_MID=1: the round-3 paths, for A/B
-    static const bool no_mid = [] { const char* e = getenv("HAFF_GEMM_NO_MID"); return e && atoi(e); }();
-    mid_on = mid_on && !no_mid;
-#endif
-    if (mid_on && M > 64 && M <= MID_ROWS && launch_mid(p, workspace, workspace_bytes, s)) return haff_check_launch();
   }
   // Few output tiles, long K (prefill-sized o_proj / down_proj, the CLIP tower at one frame): K is split over
   // blockIdx.y so that the 128x128 kernel's 512 resident-workgroup slots are used (96 tiles of 288x4096x4096 ran one

@@ -93,12 +93,10 @@ def test_linear_rms_carries_the_norm(dev, M, H, N2):
                                    (100, 520, 2048), (1000, 256, 1280), (291, 12288, 4096), (320, 640, 1056), (129, 5120, 5120),
                                    (65, 512, 512), (321, 4096, 4096)])
 def test_gemm_bf16_split_k_tiles(dev, M, N, K):
-    """Few-tile products (one-frame prefill, the CLIP tower): ops.linear hands the library a workspace. 65..320 rows (N % 4 == 0,
-    K % 32 == 0, both >= 512) take the weight-stationary tile (gemm_mid_kernel: all rows x 128 weight rows per workgroup, K
-    slices chosen by the launcher); other shapes the 128x128 kernel with K slices as a batched launch. Either way the slices
-    are summed in slice order by the reduce kernel with the whole epilogue (bias, activation, residual, row map, fp32 / bf16
-    output, ragged N). Same tolerance as the unsplit kernel; repeatable bit for bit; identical to the unsplit kernel's result
-    up to fp32 summation order."""
+    """Few-tile products (one-frame prefill o_proj / down_proj, the CLIP tower): ops.linear hands the library a workspace and
+    the 128x128 kernel runs K slices as a batched launch, summed in slice order by the reduce kernel with the whole epilogue
+    (bias, activation, residual, row map, fp32 / bf16 output, ragged N). Same tolerance as the unsplit kernel; repeatable
+    bit for bit; identical to the unsplit kernel's result up to fp32 summation order."""
     ops = _ops()
     x = _rand((M, K), dev, torch.bfloat16, 21)
     w = _rand((N, K), dev, torch.bfloat16, 22, K ** -0.5)
