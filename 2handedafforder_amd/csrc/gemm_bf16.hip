@@ -241,10 +241,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //   <128,128,2,2>: 256 threads, 64 KiB LDS, 2 workgroups/CU  — small / ragged problems
 //   <256,256,2,4>: 512 threads, 128 KiB LDS, 1 workgroup/CU  — half the L2->LDS bytes per MFMA (the 128^2 tile needs
 //                  ~64 B/clk/CU from L2 at full MFMA rate, more than the ~56 B/clk/CU the L2 can deliver)
+//   <192,256,2,4>: the same ring loop on 96 x 64 per wave (round 4) for row counts that quantise badly into 256-row tiles:
+//                  the fine-tune step's 2808-row products are 11 x 16 = 176 tiles of 256^2 on 256 CUs but 15 x 16 = 240 of these
 template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr bool PP = (WM * WN == 8);   // the 8-wave tile runs the persistent ping-pong ring loop
-  static_assert((BM == 256 && BN == 256 && WM == 2 && WN == 4) || (BM == 128 && BN == 128 && WM == 2 && WN == 2), "two tiles");
+  static_assert((BM == 256 && BN == 256 && WM == 2 && WN == 4) || (BM == 192 && BN == 256 && WM == 2 && WN == 4) ||
+                (BM == 128 && BN == 128 && WM == 2 && WN == 2), "three tiles");
   constexpr int NTHREADS = 64 * WM * WN;
   constexpr int A_ELEMS = BM * BK, W_ELEMS = BN * BK;
   constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   // LDS position pos = i*NTHREADS + tid (lane-linear); row = pos>>3; logical chunk = (pos&7) ^ (row&7)
   // The 8-wave tile is only launched for K % 64 == 0 and operands under 4 GiB, so it keeps 32-bit offsets from a
   // uniform base (saves 16 VGPRs for the ping-pong loop); the 4-wave tile keeps pointers and the zero-page K tail.
-  constexpr bool OFF32 = (BM == 256);
+  constexpr bool OFF32 = PP;
   const bf16_t* a_src[OFF32 ? 1 : NA];
   const bf16_t* w_src[OFF32 ? 1 : NW];
   int a_kcol[OFF32 ? 1 : NA], w_kcol[OFF32 ? 1 : NW];
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       const bf16_t* a_base = p.A + k0;
       asm volatile("" : "+s"(a_base));
 #pragma unroll
-      for (int i = 2 * H; i < 2 * H + 2; ++i) {
+      for (int i = 2 * H; i < (2 * H + 2 < NA ? 2 * H + 2 : NA); ++i) {   // NA = 4 requests per K-tile (3 for the 192-row tile: 2 + 1)
         unsigned o = a_off[i];
         asm volatile("" : "+v"(o));
         const bf16_t* ga = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(a_base) + o);
@@ -425,7 +428,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     for (int j = 0; j < 16; ++j) accw[i][j] = 0.f;
 #endif
   bf16x8 wf[2][TN], af[2][TM];  // fragments of one K-tile: [32-deep k-step][16-row tile] (unused by the PP loop)
-  bf16x8 pa[2][4], pwl[2][2], pwh[2][2];   // PP loop: one half of the A fragments, both halves of the W fragments
+  constexpr int TMH = TM / 2;               // 16-row A tiles per half of the wave tile (4; 3 for the 192-row tile)
+  bf16x8 pa[2][TMH > 0 ? TMH : 1], pwl[2][2], pwh[2][2];   // PP loop: one half of the A fragments, both halves of the W fragments
   auto read_frags = [&](int buf, int ks) {
     const bf16_t* sA = smem + buf * STAGE_ELEMS;
     const bf16_t* sW = sA + A_ELEMS;
@@ -504,8 +508,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       for (int ks = 0; ks < 2; ++ks) {
         const int c = ks * 4 + fh;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int ra = wm * (BM / WM) + (H * 4 + t) * 16 + fr;
+        for (int t = 0; t < TMH; ++t) {
+          const int ra = wm * (BM / WM) + (H * TMH + t) * 16 + fr;
           pa[ks][t] = *reinterpret_cast<const bf16x8*>(sA + ra * BK + ((c ^ (ra & 7)) << 3));
         }
       }
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < TMH; ++t)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[N0 + j][M0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks][j], pa[ks][t], acc[N0 + j][M0 + t], 0, 0, 0);
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     };
     using I0 = std::integral_constant<int, 0>;
     using I2 = std::integral_constant<int, 2>;
-    using I4 = std::integral_constant<int, 4>;
+    using IH = std::integral_constant<int, TMH>;
     // W quarters of K-tile 1 (the buffer was the previous tile's epilogue staging; the barrier behind that epilogue, or
     // the one behind the first tile's prologue, has passed)
     // the tile's 256 bias values ride along as ONE more DMA instruction (wave 0), a whole K loop ahead of the epilogue that
@@ -583,14 +587,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     // folded norm: the tile's 256 {mean, rstd} rows and 256 column sums the same way (waves 1-3, three DMA instructions):
     // loaded at the top of the epilogue they put a memory round trip in front of pass 0 of every tile (+0.35 % of the step,
     // norm-folded products 1100 -> 1108 TFLOP/s: bench.py `by_epilogue`, profiles/r3_ln_prefetch_ab.txt)
-    if (p.ln_stats && m0 + BM <= p.M && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0) {
+    if (BM == 256 && p.ln_stats && m0 + BM <= p.M && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0) {   // (256 rows per request pair: the 192-row tile loads them in its epilogue)
       if (wave == 1) dma_row16(p.ln_stats + 2 * (long)m0, sXw + 256);
       if (wave == 2) dma_row16(p.ln_stats + 2 * (long)(m0 + 128), sXw + 512);
       if (wave == 3 && p.ln_colsum && (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0) dma_row16(p.ln_colsum + n0, sXw + 768);
     }
     // round 4: the output row map of the tile's 256 rows the same way (wave 4). Read per lane from global memory at the top of the
     // epilogue (orow_l below) it put a dependent memory round trip in front of pass 0 of every windowed q|k|v tile.
-    if (p.row_map && m0 + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0 && wave == 4) dma_row16(p.row_map + m0, sXw + 1024);
+    if (BM == 256 && p.row_map && m0 + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0 && wave == 4) dma_row16(p.row_map + m0, sXw + 1024);
     if (nk > 1) {
       stage_w_q(buf0 ^ 1, BK, Q0{});
       stage_w_q(buf0 ^ 1, BK, Q1{});
@@ -644,8 +648,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       close_load();
       // ---- multiply slot B: quadrants (A hi, W hi), (A hi, W lo) ----
       __builtin_amdgcn_s_setprio(1);
-      quad(pwh, I2{}, I4{});
-      quad(pwl, I0{}, I4{});
+      quad(pwh, I2{}, IH{});
+      quad(pwl, I0{}, IH{});
       __builtin_amdgcn_s_setprio(0);
       if (!(wm == 1 && kt == nk - 1)) slot_barrier();   // group 1 gives back the barrier it took at the top
     }
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   float* sStat = reinterpret_cast<float*>(smem + ebuf * STAGE_ELEMS) + WM * WN * 16 * RS + wave * (2 * WROWS + WNC);   // behind the staging images
   float* sCsum = sStat + 2 * WROWS;
   // (8-wave tile, interior tile: both came in by DMA at the top of the tile's K loop — see there)
-  const bool ln_pref = PP && p.ln_stats && m0e + BM <= p.M && n0e + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0 &&
+  const bool ln_pref = PP && BM == 256 && p.ln_stats && m0e + BM <= p.M && n0e + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0 &&
                        (!p.ln_colsum || (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0);
   if (ln_pref) {
     float* sLn = reinterpret_cast<float*>(smem + 2 * STAGE_ELEMS) + 256;
@@ -801,10 +805,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     }
   } else if (p.ln_stats) {
 #pragma unroll
-    for (int h = 0; h < WROWS / 64; ++h) {
+    for (int h = 0; h < (WROWS + 63) / 64; ++h) {
       const int m = min(m_wave + h * 64 + lane, p.M - 1);
       const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)m);
-      *reinterpret_cast<float2*>(sStat + 2 * (h * 64 + lane)) = st;
+      if (h * 64 + lane < WROWS) *reinterpret_cast<float2*>(sStat + 2 * (h * 64 + lane)) = st;
     }
 #pragma unroll
     for (int h = 0; h < WNC / 64; ++h) {
@@ -814,13 +818,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     __builtin_amdgcn_wave_barrier();
   }
   // output row of wave-row (lane) and (lane + 64): -1 = dropped. Distributed to the read-back lanes by ds_bpermute.
-  int orow_l[WROWS / 64];
-  const bool map_staged = PP && p.row_map && m0e + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0;   // (the DMA above)
+  int orow_l[(WROWS + 63) / 64];
+  const bool map_staged = PP && BM == 256 && p.row_map && m0e + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0;   // (the DMA above)
 #pragma unroll
-  for (int h = 0; h < WROWS / 64; ++h) {
+  for (int h = 0; h < (WROWS + 63) / 64; ++h) {
     const int m = m_wave + h * 64 + lane;
     if (map_staged) orow_l[h] = reinterpret_cast<const int*>(smem + 2 * STAGE_ELEMS)[1024 + wm * WROWS + h * 64 + lane];
-    else orow_l[h] = m < p.M ? (p.row_map ? p.row_map[m] : m) : -1;
+    else orow_l[h] = (m < p.M && h * 64 + lane < WROWS) ? (p.row_map ? p.row_map[m] : m) : -1;
   }
 #ifndef HAFF_EPI_LDS   // -DHAFF_EPI_LDS: every tile through the LDS-staged epilogue below (A/B runs)
   // ---- register epilogue (interior tiles, 16-B aligned rows) ----
@@ -1682,6 +1686,7 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
   // the 8-wave tile addresses operands with 32-bit byte offsets and has no K-tail path
   const bool big_ok = (K % BK == 0) && ((long)(a_map ? a_rows : M) * lda * 2 < (1L << 32)) && ((long)N * ldw * 2 < (1L << 32));
   bool big = tile_cfg == 2 && big_ok;
+  bool mid_tile = tile_cfg == 3 && big_ok;   // the 192 x 256 form of the 8-wave tile
   if (tile_cfg == 0 && big_ok) {
     // Pick the tile by wave-quantisation efficiency (tiles / slots rounded up) times the measured per-tile
     // advantage of the 256^2 kernel (tools/gemm_bench.py: ~1.2x at equal quantisation): 128^2 runs 2
@@ -1691,11 +1696,18 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
     const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
     const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256) * 1.22;
     big = (M >= 256 && N >= 256 && e256 > e128);
+    // 192-row tiles where they fill the chip's rounds better than 256-row ones by more than their smaller reuse costs (per
+    // tile they move 7/8 of the bytes for 3/4 of the flops: x 0.93, tools/gemm_bench.py SHAPESET=train): the fine-tune step's
+    // 2808 x 4096 outputs are 176 tiles = one round at 69 % with 256 rows, 240 = one round at 94 % with 192 (922 -> 980
+    // TFLOP/s; K = 22016: 986 -> 1207); 5000 x 4096: 1010 -> 1115
+    const long t192 = (long)((M + 191) / 192) * ((N + 255) / 256);
+    const double e192 = (double)t192 / (double)(((t192 + 255) / 256) * 256) * 1.22 * 0.93;
+    if (M >= 192 && N >= 256 && !ln_stats && e192 > 1.05 * (e256 > e128 ? e256 : e128)) { mid_tile = true; big = false; }
   }
   // Raster group depth: 8 M-tiles share their A panels across the N sweep; with a long K loop (>= 5120) and few N tiles
   // the concurrently running tiles drift apart and a 2-deep group keeps more of the sweep in the 4 MiB L2
   // (measured +5 % on 131072x1280x5120 and 18624x4096x11008, tools/gemm_variant.py).
-  if (big) {
+  if (big || mid_tile) {
     // (sweep of 1..32 on the bench shapes, tools/gemm_variant.py with HAFF_GEMM_GROUP_M: <= 5 N-tiles: 1 (+4 % on
     // 131072x1280x1280), <= 16 N-tiles: 4 (+1.4 % on 131072x3840x1280), 20 N-tiles: 8; all within 3 % of each other)
     // (round 3, ring loop: <= 5 N-tiles 1; long K with <= 8 N-tiles 2; <= 16 N-tiles 4 (18624x4096x11008: 1351 vs 1315 at 2); 8)
@@ -1713,10 +1725,11 @@ static int gemm_bf16_impl(const void* A, long lda, const int* a_map, long a_rows
 #ifndef HAFF_GEMM_NO_NT
   p.nt_out = (long)M * (swiglu ? N / 2 : N) * (out_f32 ? 4 : 2) >= (64L << 20);
 #endif
+  if (mid_tile) return launch_gemm<192, 256, 2, 4>(p, s);
   return big ? launch_gemm<256, 256, 2, 4>(p, s) : launch_gemm<128, 128, 2, 2>(p, s);
 }
 
-// tile_cfg: 0 = auto, 1 = force the 128x128 tile, 2 = force the 256x256 tile (tests and A/B measurements)
+// tile_cfg: 0 = auto, 1 = force the 128x128 tile, 2 = force the 256x256 tile, 3 = force the 192x256 tile (tests and A/B measurements)
 extern "C" int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                                   const float* bias, const void* resid, long ldr, const int* row_map,
                                   int M, int N, int K, int act, int out_f32, int swiglu, int tile_cfg, void* stream) {

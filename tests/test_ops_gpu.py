@@ -145,12 +145,12 @@ def test_gemm_bf16_split_k_swiglu(dev, M, N, K):
     _close(plain, y, 2e-3, "split-K wide plain")
 
 
-@pytest.mark.parametrize("tile_cfg", [1, 2])
+@pytest.mark.parametrize("tile_cfg", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 1003, 256), (300, 520, 64), (1111, 256, 1280), (5000, 4500, 64)])
 def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
-    """Both tiles of the template (128^2 / 4 waves; 256^2 / 8 waves with the ping-pong ring loop) through every epilogue
-    feature, ragged edges included (K = 64: the single-K-tile path of the ring loop, with and without a next tile); the auto
-    heuristic only picks the big tile on large problems."""
+    """The three tiles of the template (128^2 / 4 waves; 256^2 and 192 x 256 / 8 waves with the ping-pong ring loop) through
+    every epilogue feature, ragged edges included (K = 64: the single-K-tile path of the ring loop, with and without a next
+    tile); the auto heuristic only picks the 8-wave tiles on large problems."""
     ops = _ops()
     x = _rand((M, K), dev, torch.bfloat16, 11)
     w = _rand((N, K), dev, torch.bfloat16, 12, K ** -0.5)
@@ -175,6 +175,34 @@ def test_gemm_bf16_forced_tiles(dev, tile_cfg, M, N, K):
         wi = torch.stack([wg.reshape(F_ // 16, 16, K), wu.reshape(F_ // 16, 16, K)], dim=1).reshape(N, K).contiguous()
         got = ops.linear(x, wi, swiglu=True, tile_cfg=tile_cfg)
         _close(got, F.silu(x.float() @ wg.float().T) * (x.float() @ wu.float().T), 1.2e-2, f"cfg{tile_cfg} swiglu")
+
+
+@pytest.mark.parametrize("M,N,K", [(2808, 4096, 4096), (2808, 4096, 11008), (1500, 1280, 1280), (2808, 22016, 4096)])
+def test_gemm_bf16_192_row_tile(dev, M, N, K):
+    """Row counts that fill the chip's rounds badly in 256-row tiles (the fine-tune step's 2808-row products: 176 tiles of 256^2
+    on 256 CUs) take the 192 x 256 form of the 8-wave tile (240 tiles) by themselves: the auto choice equals the forced one bit
+    for bit, agrees with the fp32 reference like the other tiles, through the residual / SwiGLU / gather epilogues and over
+    the many-tiles-per-workgroup persistent path (22016 columns: 1290 tiles on 256 workgroups)."""
+    ops = _ops()
+    x = _rand((M, K), dev, torch.bfloat16, 71)
+    w = _rand((N, K), dev, torch.bfloat16, 72, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 73)
+    resid = _rand((M, N), dev, torch.bfloat16, 74)
+    y = x.float() @ w.float().T + bias
+    got = ops.linear(x, w, bias=bias, resid=resid)
+    _close(got, y + resid.float(), 1.2e-2, "192-row tile, auto")
+    assert torch.equal(got, ops.linear(x, w, bias=bias, resid=resid, tile_cfg=3))
+    _close(got, ops.linear(x, w, bias=bias, resid=resid, tile_cfg=2).float(), 1e-2, "192-row vs 256-row tile")
+    got32 = ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=3)
+    _close(got32, y, 2e-3, "192-row tile f32 out")
+    _close(got32, ops.linear(x, w, bias=bias, out_dtype=torch.float32, tile_cfg=2), 1e-5, "192-row vs 256-row tile, f32")
+    if N % 32 == 0 and N <= 8192:
+        F_ = N // 2
+        wi = torch.stack([w[:F_].reshape(F_ // 16, 16, K), w[F_:].reshape(F_ // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+        ys = x.float() @ w.float().T
+        _close(ops.linear(x, wi, swiglu=True, tile_cfg=3), F.silu(ys[:, :F_]) * ys[:, F_:], 1.5e-2, "192-row tile swiglu")
+    a_map = torch.randint(0, M, (M,), device=dev).to(torch.int32)
+    _close(ops.linear(x, w, bias=bias, a_map=a_map), x.float()[a_map.long()] @ w.float().T + bias, 1.2e-2, "192-row tile gather")
 
 
 @pytest.mark.parametrize("M", [1, 3, 8, 16, 17, 31, 32, 33, 50, 64])

@@ -36,8 +36,24 @@ SHAPES = [  # name, M, N, K, kind
 ]
 
 
+TRAIN_SHAPES = [  # the fine-tune step's Llama products (8 samples x 351 ids = 2808 rows): SHAPESET=train
+    ("ft o / dX     2808", 2808, 4096, 4096, "resid"),
+    ("ft qkv        2808", 2808, 12288, 4096, "none"),
+    ("ft gate/up    2808", 2808, 22016, 4096, "swiglu"),
+    ("ft down       2808", 2808, 4096, 11008, "resid"),
+    ("ft dX gate/up 2808", 2808, 4096, 22016, "none"),
+    ("ft dX down    2808", 2808, 11008, 4096, "none"),
+    ("ft lm_head    2808", 2808, 32003, 4096, "none"),
+    ("rows 1500", 1500, 4096, 4096, "none"),
+    ("rows 5000", 5000, 4096, 4096, "none"),
+]
+
+
 def main():
     dev = torch.device("cuda:0")
+    global SHAPES
+    if os.environ.get("SHAPESET") == "train":
+        SHAPES = TRAIN_SHAPES
     rounds = int(os.environ.get("ROUNDS", "5"))
     cfgs = [int(c) for c in os.environ.get("CFGS", "1,2,0").split(",")]
     print(f"{'shape':22s} {'M':>7s} {'N':>6s} {'K':>6s} | " + " | ".join(f"cfg{c}: us   TF/s" for c in cfgs))
