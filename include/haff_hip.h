@@ -34,7 +34,7 @@ extern "C" {
 int haff_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                    const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
                    int swiglu, void* stream);
-/* same, with an explicit tile choice for measurements: 0 auto, 1 = 128x128, 2 = 256x256 workgroup tile */
+/* same, with an explicit tile choice for measurements: 0 auto, 1 = 128x128, 2 = 256x256, 3 = 192x256 workgroup tile */
 int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                        const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
                        int swiglu, int tile_cfg, void* stream);
