@@ -11,8 +11,8 @@
 
 namespace {
 
-template <typename T, int NCH, bool RMS>
-__global__ __launch_bounds__(256) void norm_rows_kernel(const T* x, long ldx, T* y, long ldy, const float* w,
+template <typename T, int NCH, bool RMS, typename TO = T>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const T* x, long ldx, TO* y, long ldy, const float* w,
                                                        const float* bvec, const int* in_map, int rows, int C,
                                                        float eps) {
   const int lane = threadIdx.x & 63;
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T* x, long ldx, T*
 // Few wide rows (KV-cached decode steps: 1..64 rows of 4096 / 5120): one WORKGROUP per row — 256 lanes x 16-B loads cover
 // 4 KiB per pass, the two statistics meet in LDS. One wave per row left 1..16 workgroups on the chip with 8-10 dependent
 // loads each: 14 us per call at 64 x 4096, 7.8 us at 1 x 4096 — two calls per layer of every decode step.
-template <typename T, int NCH, bool RMS>
-__global__ __launch_bounds__(256) void norm_row_wg_kernel(const T* x, long ldx, T* y, long ldy, const float* w,
+template <typename T, int NCH, bool RMS, typename TO = T>
+__global__ __launch_bounds__(256) void norm_row_wg_kernel(const T* x, long ldx, TO* y, long ldy, const float* w,
                                                          const float* bvec, int C, float eps) {
   __shared__ float red[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,24 +157,24 @@ __global__ __launch_bounds__(256) void norm_row_wg_kernel(const T* x, long ldx, 
   }
 }
 
-template <typename T, bool RMS>
+template <typename T, bool RMS, typename TO = T>
 int launch_norm(const void* x, long ldx, void* y, long ldy, const float* w, const float* b, const int* in_map,
                 int rows, int C, float eps, hipStream_t s) {
   if (!in_map && rows <= 256 && C >= 2048 && C <= 3 * 2048) {
     const T* xp = reinterpret_cast<const T*>(x);
-    T* yp = reinterpret_cast<T*>(y);
-    if (C <= 2048) hipLaunchKernelGGL((norm_row_wg_kernel<T, 1, RMS>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
-    else if (C <= 4096) hipLaunchKernelGGL((norm_row_wg_kernel<T, 2, RMS>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
-    else hipLaunchKernelGGL((norm_row_wg_kernel<T, 3, RMS>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
+    TO* yp = reinterpret_cast<TO*>(y);
+    if (C <= 2048) hipLaunchKernelGGL((norm_row_wg_kernel<T, 1, RMS, TO>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
+    else if (C <= 4096) hipLaunchKernelGGL((norm_row_wg_kernel<T, 2, RMS, TO>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
+    else hipLaunchKernelGGL((norm_row_wg_kernel<T, 3, RMS, TO>), dim3(rows), dim3(256), 0, s, xp, ldx, yp, ldy, w, b, C, eps);
     return haff_check_launch();
   }
   const int nch = (C + 511) / 512;
   dim3 grid((rows + 3) / 4), block(256);
   const T* xp = reinterpret_cast<const T*>(x);
-  T* yp = reinterpret_cast<T*>(y);
+  TO* yp = reinterpret_cast<TO*>(y);
 #define HAFF_NORM_CASE(N)                                                                                   \
   if (nch <= N) {                                                                                           \
-    hipLaunchKernelGGL((norm_rows_kernel<T, N, RMS>), grid, block, 0, s, xp, ldx, yp, ldy, w, b, in_map, rows, C, eps); \
+    hipLaunchKernelGGL((norm_rows_kernel<T, N, RMS, TO>), grid, block, 0, s, xp, ldx, yp, ldy, w, b, in_map, rows, C, eps); \
     return haff_check_launch();                                                                             \
   }
   HAFF_NORM_CASE(1)
@@ -256,19 +256,22 @@ int launch_stats(const void* x, long ldx, float* stats, int rows, int C, float e
 
 }  // namespace
 
-// dtype: 0 = bf16, 1 = f32 (x and y). w, b fp32 [C]. C % 8 == 0, C <= 8192, ldx/ldy % 8 == 0.
+// dtype: 0 = bf16, 1 = f32 (x and y), 2 = f32 x -> bf16 y (an fp32 residual stream feeding a bf16 product: one rounding, of the
+// NORMALISED row). w, b fp32 [C]. C % 8 == 0, C <= 8192, ldx/ldy % 8 == 0.
 extern "C" int haff_layernorm(const void* x, long ldx, void* y, long ldy, const float* w, const float* b,
                               const int* in_map, int rows, int C, float eps, int dtype, void* stream) {
-  if (rows <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7) || !w || !b) return HAFF_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7) || !w || !b || dtype < 0 || dtype > 2) return HAFF_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == 2) return launch_norm<float, false, bf16_t>(x, ldx, y, ldy, w, b, in_map, rows, C, eps, s);
   return dtype == 0 ? launch_norm<bf16_t, false>(x, ldx, y, ldy, w, b, in_map, rows, C, eps, s)
                     : launch_norm<float, false>(x, ldx, y, ldy, w, b, in_map, rows, C, eps, s);
 }
 
 extern "C" int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const float* w, int rows, int C,
                             float eps, int dtype, void* stream) {
-  if (rows <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7) || !w) return HAFF_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7) || !w || dtype < 0 || dtype > 2) return HAFF_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == 2) return launch_norm<float, true, bf16_t>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s);   // (as haff_layernorm)
   return dtype == 0 ? launch_norm<bf16_t, true>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s)
                     : launch_norm<float, true>(x, ldx, y, ldy, w, nullptr, nullptr, rows, C, eps, s);
 }

@@ -26,7 +26,7 @@ N_IMG_PAD = 255  # LISA.py:461
 
 
 class LisaMI355:
-    def __init__(self, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", sam_chunk=8, fp32_tail=True):
+    def __init__(self, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", sam_chunk=8, fp32_tail=True, fp32_stream=False):
         if not torch.cuda.is_available():
             raise RuntimeError("LisaMI355 needs an MI355X (HIP device); there is no CPU fallback for the hot path")
         from .lib import load_library
@@ -64,6 +64,10 @@ class LisaMI355:
         self.sam_decoder = SamPromptDecoderHip(sd, cfg.sam, tail, dev)
         self.clip = ClipTowerHip(sd, cfg.clip, dtype, dev)
         self.llm = LlamaHip(sd, cfg.llm, dtype, dev)
+        # fp32 residual streams in the bf16 mode: True / "sam" / "llm" — the ViT-H and / or Llama hidden-state
+        # stream kept in fp32 between the bf16 MFMA products (2.8x closer to the reference on the image embedding at depth 32)
+        self.sam_encoder.fp32_stream = fp32_stream in (True, "sam", "both")
+        self.llm.fp32_stream = fp32_stream in (True, "llm", "both")
         self.w_proj = sd["model.mm_projector.weight"].to(dev, dtype).contiguous()
         self.b_proj = _f32(sd["model.mm_projector.bias"], dev)
         self.fc0 = (sd["model.text_hidden_fcs.0.0.weight"].to(dev, tail).contiguous(), _f32(sd["model.text_hidden_fcs.0.0.bias"], dev))

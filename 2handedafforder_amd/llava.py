@@ -131,6 +131,10 @@ class LlamaHip:
         # (ops.qkv_rope): the weights get a second, row-permuted copy on first use (+3.2 GB at 7B, +6.3 GB at 13B of 288)
         self.fused_qkv_rope = True    # ("force": any prefill; False: haff_gemm_bf16 + haff_rope_cache)
         self._wqkv_rope = None
+        # fp32 RESIDUAL STREAM (bf16 mode; round 5): the hidden-state stream lives in HBM as fp32 — o_proj /
+        # down_proj add their fp32 accumulators to it and write fp32, RMSNorm reads it and rounds the NORMALISED row to bf16 once
+        # for the bf16 MFMA products. Off by default (it gives up the norm-carrying 5-launch decode layer at <= 4 rows).
+        self.fp32_stream = False
 
     def _cos_sin(self, tmax):
         if self._cs is None or self._cs.shape[0] < tmax:
@@ -158,12 +162,16 @@ class LlamaHip:
         assert pos0 + T <= cache["tmax"]
         cs = self._cos_sin(cache["tmax"])
         x = x.reshape(B * T, H).clone() if not x.is_contiguous() else x.reshape(B * T, H)
+        s32 = bool(self.fp32_stream) and self.dtype == torch.bfloat16
+        nd = self.dtype if s32 else None     # norm output dtype: bf16 rows from the fp32 stream
+        if s32:
+            x = x.float()
         fused = self.fused_qkv_rope and T > 1 and \
             ops.qkv_rope_supported(B * T, nh, hd, H, self.dtype, 1 if self.fused_qkv_rope == "force" else 1024)
         if fused and self._wqkv_rope is None:
             self._wqkv_rope = [ops.rope_permute_rows(L["wqkv"]) for L in self.layers]
         for li, L in enumerate(self.layers):
-            h = ops.rmsnorm(x, L["n1"], l.rms_eps)
+            h = ops.rmsnorm(x, L["n1"], l.rms_eps, out_dtype=nd)
             kc, vc = cache["k"][li], cache["v"][li]
             tk = pos0 + T
             if fused:
@@ -176,11 +184,11 @@ class LlamaHip:
             v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)[:, :, :tk]
             a = ops.attention(q, k, v, hd ** -0.5, causal=T > 1, q_pos0=tk - T)
             x = ops.linear(a.view(B * T, H), L["wo"], resid=x, out=x)
-            h = ops.rmsnorm(x, L["n2"], l.rms_eps)
+            h = ops.rmsnorm(x, L["n2"], l.rms_eps, out_dtype=nd)
             g = ops.linear(h, L["wgu"], swiglu=True)
             x = ops.linear(g, L["wd"], resid=x, out=x)
         cache["len"] = pos0 + T
-        return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, T, H)
+        return ops.rmsnorm(x, self.norm, l.rms_eps, out_dtype=nd).view(B, T, H)
 
     def decode_rows(self, x1, cache):
         """One KV-cached position per row at PER-ROW positions: x1 [B,1,H] is the embedding of row b's next token, which
@@ -194,10 +202,14 @@ class LlamaHip:
         cs = self._cos_sin(cache["tmax"])
         pos, nk = cache["pos"], cache["nk"]
         x = x1.reshape(B, H).clone() if not x1.is_contiguous() else x1.reshape(B, H)
-        if self.carry_rms and B <= 4:
+        s32 = bool(self.fp32_stream) and self.dtype == torch.bfloat16
+        nd = self.dtype if s32 else None
+        if s32:
+            x = x.float()
+        elif self.carry_rms and B <= 4:
             return self._decode_rows_carry(x, cache, cs, nk)
         for li, L in enumerate(self.layers):
-            h = ops.rmsnorm(x, L["n1"], l.rms_eps)
+            h = ops.rmsnorm(x, L["n1"], l.rms_eps, out_dtype=nd)
             qkv = ops.linear(h, L["wqkv"])
             kc, vc = cache["k"][li], cache["v"][li]
             if self.dtype == torch.bfloat16 and hd == 128:
@@ -210,10 +222,10 @@ class LlamaHip:
                 v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)
                 a = ops.attention_decode_rows(q, k, v, hd ** -0.5, nk)
             x = ops.linear(a.view(B, H), L["wo"], resid=x, out=x)
-            h = ops.rmsnorm(x, L["n2"], l.rms_eps)
+            h = ops.rmsnorm(x, L["n2"], l.rms_eps, out_dtype=nd)
             g = ops.linear(h, L["wgu"], swiglu=True)
             x = ops.linear(g, L["wd"], resid=x, out=x)
-        return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, 1, H)
+        return ops.rmsnorm(x, self.norm, l.rms_eps, out_dtype=nd).view(B, 1, H)
 
     def _decode_rows_carry(self, x, cache, cs, nk):
         """decode_rows for <= 4 rows without norm kernels: o_proj / down_proj write, beside the residual stream, each

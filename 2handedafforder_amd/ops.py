@@ -373,29 +373,38 @@ def global_attention(q, k, v, scale, tab_h, tab_w, S, out=None):
     return out
 
 
-def layernorm(x, w, b, eps, in_map=None, out=None):
-    """x [R,C]; optional gather map (int32 [R_out], <0 -> zero row)."""
+def _norm_dt(x, out):
+    """dtype code of the norm kernels: 0 bf16, 1 f32, 2 = f32 rows in, bf16 rows out (fp32 residual stream -> bf16 product)."""
+    if x.dtype == torch.float32 and out.dtype == torch.bfloat16:
+        return 2
+    assert out.dtype == x.dtype, (x.dtype, out.dtype)
+    return _dt(x)
+
+
+def layernorm(x, w, b, eps, in_map=None, out=None, out_dtype=None):
+    """x [R,C]; optional gather map (int32 [R_out], <0 -> zero row). out_dtype=torch.bfloat16 on fp32 rows: one rounding, of the
+    normalised row."""
     lib = load_library()
     _req(x, "x")
     assert x.dim() == 2 and x.stride(1) == 1
     rows = x.shape[0] if in_map is None else in_map.numel()
     C = x.shape[1]
     if out is None:
-        out = torch.empty((rows, C), dtype=x.dtype, device=x.device)
+        out = torch.empty((rows, C), dtype=out_dtype or x.dtype, device=x.device)
     rc = lib.haff_layernorm(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), w.data_ptr(), b.data_ptr(),
-                            _p(in_map), rows, C, float(eps), _dt(x), _stream())
+                            _p(in_map), rows, C, float(eps), _norm_dt(x, out), _stream())
     check(rc, "haff_layernorm")
     return out
 
 
-def rmsnorm(x, w, eps, out=None):
+def rmsnorm(x, w, eps, out=None, out_dtype=None):
     lib = load_library()
     _req(x, "x")
     assert x.dim() == 2 and x.stride(1) == 1
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     rc = lib.haff_rmsnorm(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), w.data_ptr(), x.shape[0],
-                          x.shape[1], float(eps), _dt(x), _stream())
+                          x.shape[1], float(eps), _norm_dt(x, out), _stream())
     check(rc, "haff_rmsnorm")
     return out
 

@@ -78,6 +78,13 @@ class SamEncoderHip:
         # final LayerNorm2d runs in fp32, so the decoder tail (LisaMI355.fp32_tail) starts from un-rounded embeddings.
         # One bf16 rounding of the embedding ALONE costs 0.0005-0.0014 of mask IoU on random weights (tools/parity_sim.py).
         self.emb_f32 = False
+        # fp32 RESIDUAL STREAM (bf16 mode; round 5): the stream x lives in HBM as fp32 — proj / lin2 add
+        # their fp32 accumulators to it and write fp32 back, LayerNorm reads it and hands ONE bf16 rounding of the NORMALISED row
+        # to the bf16 MFMA products — so the 64 per-block roundings of the stream itself (the dominant term of the bf16 mode's
+        # distance to the reference at depth 32: tools/full_frame_parity.py) disappear. Costs the folded norms (LayerNorm kernels
+        # come back) and doubles the epilogue traffic of proj / lin2. Off by default.
+        self.fp32_stream = False
+        self._pos32 = None
 
     @staticmethod
     def _fit_rel_pos(table, S):
@@ -127,6 +134,13 @@ class SamEncoderHip:
         s = self.cfg
         C, g, H, hd = s.embed_dim, s.grid, s.heads, self.hd
         N = g * g
+        s32 = bool(self.fp32_stream) and self.dtype == torch.bfloat16
+        if s32:
+            if self._pos32 is None:
+                self._pos32 = self.pos.float()
+            x = ops.linear(rows, self.w_patch, bias=self.b_patch, out_dtype=torch.float32)
+            x = ops.add_bcast(x, self._pos32, mod=N, out=x)
+            return self._forward_rows_fp32_stream(x, B, taps)
         x = ops.linear(rows, self.w_patch, bias=self.b_patch)
         x = ops.add_bcast(x, self.pos, mod=N, out=x)
         scale = hd ** -0.5
@@ -211,6 +225,62 @@ class SamEncoderHip:
             if taps is not None:
                 taps[f"block{i}"] = x.float().view(B, g, g, C).cpu()
         y = ops.linear(x, self.w_neck0)
+        y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
+        cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
+        y = ops.linear(cols, self.w_neck2, out_dtype=torch.float32 if self.emb_f32 else None)
+        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6)
+        return y.view(B, N, s.out_chans)
+
+    def _forward_rows_fp32_stream(self, x, B, taps=None):
+        """The blocks on an fp32 residual stream x [B*N, C] (see fp32_stream): LayerNorm kernels fp32 -> bf16, bf16 MFMA products,
+        proj / lin2 with fp32 residual in and fp32 out (haff_gemm_bf16*'s out_f32 epilogue). image_encoder.py:177-193."""
+        s = self.cfg
+        C, g, H, hd = s.embed_dim, s.grid, s.heads, self.hd
+        N = g * g
+        scale = hd ** -0.5
+        bf = torch.bfloat16
+        for i, blk in enumerate(self.blocks):
+            compact = self.compact_windows and not blk["global"] and s.window == 14 and hd == 80
+            if compact:
+                _, nw2 = self._window_maps(B)
+                inv = self._compact_window_map(B)
+                nb, ntok, S = B * nw2, s.window * s.window, s.window
+                qkv = torch.empty((nb * ntok + 1, 3 * C), dtype=bf, device=x.device)
+                xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, out_dtype=bf)
+                ops.linear(xn, blk["wqkv"], bias=blk["bqkv"], row_map=inv, out=qkv[:-1])
+                qkv[-1].copy_(blk["bqkv"])
+                q5 = qkv[:-1].view(nb, ntok, 3, H, hd)
+                a = ops.window_attention(q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 1].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3),
+                                         scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=nb * ntok)
+                del qkv
+                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, a_map=inv, out=x)
+            else:
+                if blk["global"]:
+                    nb, ntok, S, row_map = B, N, g, None
+                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, out_dtype=bf)
+                else:
+                    win, nw2 = self._window_maps(B)
+                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, in_map=win, out_dtype=bf)
+                    nb, ntok, S, row_map = B * nw2, s.window * s.window, s.window, win
+                qkv = ops.linear(xn, blk["wqkv"], bias=blk["bqkv"])
+                q5 = qkv.view(nb, ntok, 3, H, hd)
+                q, k, v = q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 1].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3)
+                if not blk["global"] and ops.window_attention_supported(q, S):
+                    a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
+                elif blk["global"] and self.fused_global and ops.global_attention_supported(q, k, v, S):
+                    a = ops.global_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
+                else:
+                    relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
+                    a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
+                    del relh, relw
+                del qkv
+                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
+            h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, out_dtype=bf)
+            h = ops.linear(h, blk["w1"], bias=blk["b1"], act=ops.ACT_GELU)
+            ops.linear(h, blk["w2"], bias=blk["b2"], resid=x, out=x)
+            if taps is not None:
+                taps[f"block{i}"] = x.float().view(B, g, g, C).cpu()
+        y = ops.linear(x.to(bf), self.w_neck0)
         y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
         cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
         y = ops.linear(cols, self.w_neck2, out_dtype=torch.float32 if self.emb_f32 else None)

@@ -225,8 +225,10 @@ def parity_vs_oracle(device):
                     "max_oracle_logit_at_disagreeing_pixels_in_logit_std": max(margins) if margins else 0.0,
                     "mask_iou_outside_threshold_band": band}
         res = {"iou_floor_exact_pipeline_with_bf16_rounded_embedding": stats(((fl_l, r_left[0]), (fl_r, r_right[0])))["mask_iou_vs_oracle"]}
-        for name, dt, tail in (("bf16", torch.bfloat16, True), ("bf16_all", torch.bfloat16, False), ("fp32", torch.float32, True)):
-            model = LisaMI355(cfg, sd, dtype=dt, device=device, fp32_tail=tail)
+        for name, dt, tail in (("bf16", torch.bfloat16, True), ("bf16_all", torch.bfloat16, False), ("fp32", torch.float32, True),
+                               ("bf16_fp32_stream", torch.bfloat16, True)):
+            # bf16_fp32_stream: the bf16 mode with the ViT-H and Llama residual streams kept in fp32 (LisaMI355(fp32_stream=True))
+            model = LisaMI355(cfg, sd, dtype=dt, device=device, fp32_tail=tail, fp32_stream=name == "bf16_fp32_stream")
             o_ids, left, right, tax = model.evaluate(images_clip.to(device), images.to(device), ids.to(device), [(S, S)], [(S, S)],
                                                      max_new_tokens=4, forced_answer=forced)
             st = stats(((left[0], r_left[0]), (right[0], r_right[0])))
@@ -256,6 +258,13 @@ def parity_vs_oracle(device):
         st["token_ids_equal"] = bool(torch.equal(o_ids.cpu(), r_ids))
         st["oracle_field"] = case["diag"]
         out["two_region_tiny_bf16"] = st
+        del model
+        model = LisaMI355(cfgb, case["sd"], dtype=torch.bfloat16, device=device, fp32_tail=True, fp32_stream=True)
+        o_ids, left, right, tax = model.evaluate(case["images_clip"].to(device), case["images"].to(device), case["ids"].to(device),
+                                                 [(S, S)], [(S, S)], max_new_tokens=4, forced_answer=case["forced"])
+        st = stats(((left[0], r_left[0]), (right[0], r_right[0])))
+        st["token_ids_equal"] = bool(torch.equal(o_ids.cpu(), r_ids))
+        out["two_region_tiny_bf16_fp32_stream"] = st
         del model
     except Exception as e:   # the extra case must not take the benchmark line down
         out["two_region_tiny_bf16"] = {"error": repr(e)}
@@ -418,6 +427,177 @@ def cpu_full_frame(cfg, text_tokens, n_gen, threads):
             "what": "oracle.lisa_evaluate(use_cache=True) on one %dx%d frame, %d-id prompt, %d forced tokens, full depth (%d ViT-H blocks, "
                     "%d CLIP layers, %d Llama layers), fp32, %d threads" % (S, S, ids.shape[1], n_gen, cfg.sam.depth, cfg.clip.layers,
                                                                            cfg.llm.layers, threads)}
+
+
+def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf16", "fp32"), attribution=True, seed=1234,
+                      variants=None):
+    """The 'mask IoU vs ref' half of the metric AT THE HEADLINE GEOMETRY: ONE full-depth frame (BASELINE.json configs[1]: every
+    ViT-H block, CLIP layer and Llama layer; 1024^2 uint8 frame, 36-id prompt, n_gen forced answer tokens with one [SEG]) through
+    LisaMI355.evaluate in each numeric mode and through the CPU oracle ON THE SAME WEIGHTS — the set is generated once in HBM
+    (bf16 values, what the timed mode stores), handed to the HIP models as it is (fp32 mode: the same values widened) and copied
+    to the host as fp32 for the oracle (~31 GB at 7B). The oracle's inputs come from the reference's host recipe
+    (inference.preprocess for SAM, transformers' CLIPImageProcessor for CLIP: inference.py:229-256), the HIP path starts from the
+    uint8 frame like the timed step does. The oracle's exact pass is timed: it IS cpu_baseline's one real frame (no second CPU
+    frame in the run). attribution=True adds the oracle's bf16-points mode for one stack at a time and for all three (one stage
+    re-run per variant: oracle.lisa_evaluate(points=, memo=)). Returns {"parity": {...}, "cpu_frame": {...}} or {"skipped": why}.
+    variants: optional {name: callable(model)} applied to a bf16 model before its run (A/B of numeric options)."""
+    from collections import OrderedDict
+    import numpy as np
+    from oracle import lisa_oracle as O
+    shapes = hw.all_shapes(cfg)
+    n_par = sum(int(np.prod(sh)) for sh in shapes.values())
+    try:
+        import psutil
+        need = n_par * 4 * 1.25 + 8e9
+        if psutil.virtual_memory().available < need:
+            return {"skipped": "host memory: %.0f GB available, %.0f GB needed for the oracle's fp32 copy of the weights" %
+                               (psutil.virtual_memory().available / 1e9, need / 1e9)}
+    except ImportError:
+        pass
+    try:
+        from transformers import CLIPImageProcessor
+    except ImportError:
+        return {"skipped": "transformers (CLIPImageProcessor: the oracle's CLIP input) is not importable"}
+    torch.set_num_threads(threads)
+    S = cfg.sam.img_size
+    sizes = [(S, S)]
+    sd_dev = hw.make_state_dict_device(cfg, seed, device, torch.bfloat16)
+    frames, _, ids, forced = make_inputs(cfg, 1, text_tokens, n_gen, device, seed=seed)
+    frame_np = frames[0].cpu().numpy()
+    images = O.sam_preprocess(frame_np, S)[None]
+    clip = CLIPImageProcessor().preprocess(frame_np, return_tensors="pt")["pixel_values"].float()
+
+    if variants is None:   # the bf16 mode with both residual streams in fp32 rides along by default
+        def _streams(m):
+            m.sam_encoder.fp32_stream = m.llm.fp32_stream = True
+        variants = {"bf16_fp32_stream": _streams}
+    runs = [(m, None) for m in modes] + [(k, f) for k, f in variants.items()]
+    hip = {}
+    for name, tweak in runs:
+        dt = torch.float32 if name == "fp32" else torch.bfloat16
+        sd_m = sd_dev if dt == torch.bfloat16 else OrderedDict((k, v.float()) for k, v in sd_dev.items())
+        model = LisaMI355(cfg, sd_m, dtype=dt, device=device, sam_chunk=1)
+        del sd_m
+        if tweak is not None:
+            tweak(model)
+        t0 = time.perf_counter()
+        o_ids, left, right, tax = model.evaluate(None, None, ids, sizes, sizes, max_new_tokens=n_gen, forced_answer=forced,
+                                                 frames_u8=frames)
+        torch.cuda.synchronize()
+        first_call_s = time.perf_counter() - t0
+        # the stage outputs behind the masks (same kernels, same inputs: evaluate() is deterministic), for the per-stage distances
+        from haff.preprocess import SAM_MEAN, SAM_STD
+        ing = model.frame_ingest()
+        o2, hidden = model.generate(ing.clip_pixels(frames, cfg.clip.image, model.dtype), ids, n_gen, forced)
+        pred = model.seg_embeddings(o2, hidden)[0]
+        emb = model.get_visual_embs_u8(ing.sam_frames(frames, S)[0], SAM_MEAN, SAM_STD)
+        g = cfg.sam.grid
+        hip[name] = {"ids": o_ids.cpu(), "left": left[0].float().cpu(), "right": right[0].float().cpu(), "tax": tax[0].float().cpu(),
+                     "hidden": hidden.float().cpu(), "pred": pred.float().cpu(),
+                     "emb": emb.float().view(1, g, g, -1).permute(0, 3, 1, 2).contiguous().cpu(), "first_call_s": first_call_s}
+        del model, hidden, pred, emb, left, right
+        torch.cuda.empty_cache()
+
+    t0 = time.perf_counter()
+    sd = OrderedDict()
+    for k in list(sd_dev.keys()):
+        sd[k] = sd_dev.pop(k).cpu().float()
+    del sd_dev
+    torch.cuda.empty_cache()
+    t_copy = time.perf_counter() - t0
+    memo, taps = {}, {}
+    kw = dict(max_new_tokens=n_gen, forced_answer=forced.cpu(), use_cache=True, memo=memo)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        r_ids, r_left, r_right, r_tax = O.lisa_evaluate(sd, cfg, clip, images, ids.cpu(), sizes, sizes, taps=taps, **kw)
+        t_frame = time.perf_counter() - t0
+        ref = {"left": r_left[0], "right": r_right[0]}
+        oracle_variants = {}
+        if attribution:
+            t0 = time.perf_counter()
+            for tag, pts in (("sam", ("sam",)), ("llama", ("llama",)), ("clip", ("clip",)), ("all", ("sam", "clip", "llama"))):
+                _, vl, vr, _ = O.lisa_evaluate(sd, cfg, clip, images, ids.cpu(), sizes, sizes, points=pts, **kw)
+                oracle_variants[tag] = {"left": vl[0], "right": vr[0]}
+            t_attr = time.perf_counter() - t0
+    del sd, memo
+
+    def rel(a, b):
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+    def rms_rel(a, b):
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+    def mask_stats(got, want):
+        out = {}
+        for hand in ("left", "right"):
+            gm, r = got[hand], want[hand]
+            a, b = gm > 0, r > 0
+            inter, union = (a & b).sum().item(), (a | b).sum().item()
+            dis = a != b
+            err = (gm - r).abs()
+            st = {"mask_iou": inter / union if union else 1.0, "logit_max_abs_err": err.max().item(),
+                  "logit_max_rel_err": err.max().item() / r.abs().max().item(), "logit_rms_rel_err": rms_rel(gm, r),
+                  "pixels_disagreeing": int(dis.sum()), "pixels": dis.numel(),
+                  "max_abs_oracle_logit_at_disagreeing_pixels": r[dis].abs().max().item() if dis.any() else 0.0}
+            for band in (1e-3,):   # north_star: logits within 1e-3, binary masks bit-exact: exact outside the 1e-3 band around 0
+                keep = r.abs() >= band
+                st["masks_equal_outside_abs_band_%g" % band] = bool(((a == b) | ~keep).all())
+            for tau in (0.01,):
+                keep = r.abs() >= tau * r.abs().max()
+                u = ((a | b) & keep).sum().item()
+                st["mask_iou_outside_%g_of_scale_band" % tau] = ((a & b) & keep).sum().item() / u if u else 1.0
+            out[hand] = st
+        out["mask_iou_min"] = min(out["left"]["mask_iou"], out["right"]["mask_iou"])
+        out["logit_max_rel_err"] = max(out["left"]["logit_max_rel_err"], out["right"]["logit_max_rel_err"])
+        out["logit_max_abs_err"] = max(out["left"]["logit_max_abs_err"], out["right"]["logit_max_abs_err"])
+        return out
+
+    seg_rows = O.seg_token_mask(r_ids, cfg.seg_token_idx)
+    field = {h: {"std": ref[h].std().item(), "abs_max": ref[h].abs().max().item(), "positive_frac": (ref[h] > 0).float().mean().item()}
+             for h in ("left", "right")}
+    par = {"what": "ONE full-depth frame: %s, %dx%d uint8 frame, %d-id prompt (T = %d), %d forced answer tokens with one [SEG]; HIP "
+                   "path from the uint8 frame (device ingest), oracle from inference.preprocess + CLIPImageProcessor; ONE weight set "
+                   "(device generator, seed %d, bf16 values; fp32 mode and the oracle see the same values widened)" %
+                   (cfg.name, S, S, ids.shape[1], ids.shape[1] + 255, n_gen, seed),
+           "reference": "/root/reference/2Haff/model/LISA.py:432-534 (evaluate) restated in oracle/lisa_oracle.py",
+           "oracle_logit_field": field}
+    for name in hip:
+        h = hip[name]
+        st = mask_stats(h, ref)
+        st["token_ids_equal"] = bool(torch.equal(h["ids"], r_ids))
+        st["taxonomy_max_abs_err"] = (h["tax"] - r_tax[0]).abs().max().item()
+        st["stage_rel_err"] = {"image_embedding_max": rel(h["emb"], taps["image_embeddings"]),
+                               "image_embedding_rms": rms_rel(h["emb"], taps["image_embeddings"]),
+                               "seg_hidden_state_max": rel(h["hidden"][seg_rows], taps["hidden"][seg_rows]),
+                               "seg_hidden_state_rms": rms_rel(h["hidden"][seg_rows], taps["hidden"][seg_rows]),
+                               "text_embedding_max": rel(h["pred"], taps["pred_embeddings"][0]),
+                               "text_embedding_rms": rms_rel(h["pred"], taps["pred_embeddings"][0])}
+        st["first_call_seconds"] = h["first_call_s"]
+        if attribution and name != "fp32":
+            st["vs_oracle_bf16_points"] = {k: v for k, v in mask_stats(h, oracle_variants["all"]).items() if not isinstance(v, dict)}
+        par[name] = st
+    if attribution:
+        par["oracle_bf16_points_vs_exact"] = {
+            tag: {k: v for k, v in mask_stats(oracle_variants[tag], ref).items() if not isinstance(v, dict)}
+            for tag in ("sam", "llama", "clip", "all")}
+        par["oracle_bf16_points_vs_exact"]["note"] = ("the oracle with fp32 arithmetic and bf16 roundings at the HIP path's kernel "
+                                                      "boundaries, in ONE stack at a time / in all three (oracle.bf16_points): how "
+                                                      "much of the bf16 mode's distance is storage rounding, and where")
+        par["attribution_seconds"] = t_attr
+    fails = []
+    if "fp32" in hip:
+        f = par["fp32"]
+        ok = f["logit_max_abs_err"] <= 1e-3 and f["token_ids_equal"] and \
+            all(f[h]["masks_equal_outside_abs_band_0.001"] for h in ("left", "right"))
+        if not ok:
+            fails.append("full_frame/fp32")
+    par["gate"] = {"fp32": "mask logits within 1e-3 (absolute) of the oracle, binary masks equal wherever |oracle logit| >= 1e-3, ids equal",
+                   "failed": fails}
+    cpu = {"seconds": t_frame, "frames_per_s": 1.0 / t_frame, "weights_copy_seconds": t_copy, "outputs_finite": bool(torch.isfinite(ref["left"]).all()),
+           "what": "oracle.lisa_evaluate(use_cache=True) on one %dx%d frame, %d-id prompt, %d forced tokens, full depth (%d ViT-H blocks, "
+                   "%d CLIP layers, %d Llama layers), fp32, %d threads; the weights are the HIP model's (this frame is also the parity "
+                   "reference: parity.full_frame)" % (S, S, ids.shape[1], n_gen, cfg.sam.depth, cfg.clip.layers, cfg.llm.layers, threads)}
+    return {"parity": par, "cpu_frame": cpu}
 
 
 def base_line(fps, world, steps, warmup, ms_per_step, workload, B, extra_cfg):
@@ -681,6 +861,16 @@ def main(argv=None):
     ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: skip the one real end-to-end CPU frame (~31 GB host RAM, ~1 min)")
     ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency line (configs[1])")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
+                    help="numeric mode of the timed model: bf16 (bf16 MFMA stacks + fp32 decoder tail: the headline) or f32 (the "
+                         "parity mode, f32-input MFMA everywhere: what IoU >= 0.999 / logits within 1e-3 is measured in)")
+    ap.add_argument("--fp32-stream", default="off", choices=["off", "sam", "llm", "both"],
+                    help="bf16 mode with the ViT-H and / or Llama residual stream kept in fp32 between the bf16 MFMA products "
+                         "(LisaMI355(fp32_stream=...): 2-3x closer to the reference at depth 32; DESIGN.md section 2)")
+    ap.add_argument("--no-full-frame-parity", action="store_true",
+                    help="parity: skip the one full-depth frame against the oracle on shared weights (~31 GB host RAM, ~1 min of CPU)")
+    ap.add_argument("--no-attribution", action="store_true",
+                    help="full-frame parity: skip the oracle's per-stack bf16-points passes (~35 s of CPU)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: BASELINE configs[2] (the headline metric); train: configs[3], one LoRA fine-tune step per step")
     ap.add_argument("--materialised-attention", action="store_true",
@@ -714,10 +904,15 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b, "tiny": hcfg.tiny, "mid": hcfg.mid}[args.config]()
-    sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
+    run_dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)   # bf16 VALUES in either mode (f32: widened below)
+    if run_dtype == torch.float32:
+        for k in list(sd.keys()):
+            sd[k] = sd[k].float()
     if args.fold_norms:
         cfg.sam.fold_norms = True
-    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=device, sam_chunk=args.sam_chunk)
+    model = LisaMI355(cfg, sd, dtype=run_dtype, device=device, sam_chunk=args.sam_chunk,
+                      fp32_stream=False if args.fp32_stream == "off" else args.fp32_stream)
     if args.fold_norms:
         model.sam_encoder.fold_norms = True
     model.overlap_streams = not args.single_stream
@@ -789,10 +984,16 @@ def main(argv=None):
             if pmc.get("config") == cfg.name and pmc.get("batch") == B:
                 traffic = pmc["hbm_bytes_per_launch"]
                 traffic_src = "profiles/pmc_gemm_traffic.json (%s)" % pmc.get("collected", "")
+        f32_mode = run_dtype == torch.float32
+        if f32_mode:   # the parity mode: every product is gemm_f32_kernel (f32-input MFMA, 157.3 TFLOP/s dense)
+            n_launch, gemm_ms, gemm_fl = f32_n, f32_ms, f32_fl
+            gemm_bytes, traffic, traffic_src = 0.0, None, None
+        peak = 157.3 if f32_mode else PEAK_BF16_TFLOPS
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         roofline = {
-            "bound": "mfma", "kernel": "gemm_bf16_kernel (haff_gemm_bf16 with M > 64: the 256x256 / 128x128 MFMA tiles, all epilogue variants)",
-            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+            "bound": "mfma", "kernel": "gemm_f32_kernel (haff_gemm_f32: v_mfma_f32_16x16x4_f32 tiles; every product of the fp32 parity mode)" if f32_mode else
+                                       "gemm_bf16_kernel (haff_gemm_bf16 with M > 64: the 256x256 / 128x128 MFMA tiles, all epilogue variants)",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch_avg": gemm_bytes / n_launch,
             "launches_per_step": n_launch, "avg_launch_us": 1e3 * gemm_ms / n_launch,
@@ -813,20 +1014,24 @@ def main(argv=None):
                                        "unit": "TFLOP/s"},
             "whole_path": {"flops_per_frame": flops_frame, "flops_per_frame_source": "SURVEY.md 8(d) (counts the padded window rows)",
                            "achieved": fps / world * flops_frame / 1e12,
-                           "frac": fps / world * flops_frame / 1e12 / PEAK_BF16_TFLOPS,
+                           "frac": fps / world * flops_frame / 1e12 / peak,
                            "executed_flops_per_frame": executed_frame,
                            "executed_note": "every GEMM launch as issued (padded window rows skipped) + attention / rel-pos terms",
                            "executed_achieved": fps / world * executed_frame / 1e12,
-                           "executed_frac": fps / world * executed_frame / 1e12 / PEAK_BF16_TFLOPS},
+                           "executed_frac": fps / world * executed_frame / 1e12 / peak},
         }
         T_exp = 4 + args.text_tokens + cfg.clip.n_patches - 1
         line = base_line(fps, world, args.steps, args.warmup, ms_per_step,
                          "BASELINE.json configs[2]: %s, %d x %dx%d uint8 NHWC frames/step/GPU, %d-token prompt (T=%d), %d forced "
                          "answer tokens with [SEG], KV-cached greedy decode, random-init weights; CLIP + SAM preprocessing of the "
                          "uint8 frames on the device inside the step" % (cfg.name, B, S, S, args.text_tokens, T_exp, args.n_gen),
-                         B, {"hip_streams": 2 if model.overlap_streams else 1, "fp32_decoder_tail": bool(model.fp32_tail)})
+                         B, {"hip_streams": 2 if model.overlap_streams else 1, "fp32_decoder_tail": bool(model.fp32_tail),
+                             "fp32_residual_stream": args.fp32_stream})
         line["roofline"] = roofline
         line["rccl_ranks"] = n_ranks
+        if f32_mode:
+            line["dtype"] = "f32"
+            line["config"]["numeric_mode"] = "fp32 parity mode (f32-input MFMA products, fp32 attention / norms): the mode the IoU / 1e-3 targets are met in"
         # sanity of the produced masks (finite, right shapes)
         ok = all(m.shape == (1, S, S) and bool(torch.isfinite(m).all()) for m in out[1] + out[2])
         line["outputs_finite"] = ok
@@ -861,12 +1066,21 @@ def main(argv=None):
             line["decode_step_batch1"] = {"ms": step_ms, "weight_bytes": w_bytes, "bound": "hbm",
                                           "achieved_TBps": w_bytes / (step_ms * 1e-3) / 1e12, "peak_TBps": 8.0,
                                           "note": "a read-only streaming kernel reaches 6.25 TB/s on this part (tools/probes/lds_dma_bw.hip)"}
+        threads = min(len(os.sched_getaffinity(0)), 32)
+        full_parity = None
+        if world == 1 and not args.no_parity and not args.no_full_frame_parity and cfg.name in SURVEY_FLOPS:
+            # ONE full-depth frame through the HIP path (both numeric modes) and the oracle on shared weights: the parity object's
+            # full_frame entry AND cpu_baseline's one real frame (the oracle's exact pass is the timed CPU frame)
+            del model
+            model = None
+            torch.cuda.empty_cache()
+            full_parity = parity_full_frame(cfg, device, threads, args.text_tokens, args.n_gen, attribution=not args.no_attribution)
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(len(os.sched_getaffinity(0)), 32)
             line["cpu_baseline"] = cpu_baseline(cfg, args.text_tokens, args.n_gen, threads)
             if not args.no_cpu_full_frame:
-                # free the HIP model's host-side leftovers first? (none: weights live in HBM) — one REAL frame beside the sample
-                full = cpu_full_frame(cfg, args.text_tokens, args.n_gen, threads)
+                # one REAL frame beside the sample: the full-frame parity's oracle pass when that ran, else a pass of its own
+                full = full_parity["cpu_frame"] if full_parity and "cpu_frame" in full_parity else \
+                    cpu_full_frame(cfg, args.text_tokens, args.n_gen, threads)
                 line["cpu_baseline"]["full_frame"] = full
                 if "frames_per_s" in full:
                     # the measured end-to-end frame IS the baseline: value and seconds_per_frame are that frame's; everything that
@@ -885,6 +1099,9 @@ def main(argv=None):
         if world == 1 and not args.no_parity:
             del model
             line["parity"] = parity_vs_oracle(device)
+            if full_parity is not None:
+                line["parity"]["full_frame"] = full_parity.get("parity", full_parity)
+                line["parity"]["gate"]["failed"] += (full_parity.get("parity") or {}).get("gate", {}).get("failed", [])
         print(json.dumps(line), flush=True)
         if (line.get("parity") or {}).get("gate", {}).get("failed"):
             print("parity gate failed: " + ", ".join(line["parity"]["gate"]["failed"]), file=sys.stderr)

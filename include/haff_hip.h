@@ -204,7 +204,8 @@ int haff_global_attention_bf16(const void* q, long q_sb, long q_sh, long q_st, c
  * haff_layernorm: nn.LayerNorm / LayerNorm2d on channels-last rows (common.py:31-43; image_encoder.py:179,191;
  * transformer.py:134-144; CLIP layer norms). in_map (int32[rows], may be null): out row i normalises in row
  * in_map[i]; negative = zero row (window_partition's zero pad AFTER norm1, image_encoder.py:179-183,276-288).
- * haff_rmsnorm: LlamaRMSNorm (fp32 variance). w, b: f32[C]. C % 8 == 0, C <= 8192. */
+ * haff_rmsnorm: LlamaRMSNorm (fp32 variance). w, b: f32[C]. C % 8 == 0, C <= 8192.
+ * dtype: 0 = bf16 rows, 1 = f32 rows, 2 = f32 x -> bf16 y (an fp32 residual stream feeding a bf16 product). */
 int haff_layernorm(const void* x, long ldx, void* y, long ldy, const float* w, const float* b, const int* in_map,
                    int rows, int C, float eps, int dtype, void* stream);
 int haff_rmsnorm(const void* x, long ldx, void* y, long ldy, const float* w, int rows, int C, float eps, int dtype,

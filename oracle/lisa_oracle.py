@@ -376,11 +376,18 @@ def text_hidden_fcs(sd, h):
 # ----------------------------------------------------------------------------------------------------------
 # LISAForCausalLM.evaluate (model/LISA.py:432-534)
 # ----------------------------------------------------------------------------------------------------------
-def lisa_generate(sd, cfg, images_clip, input_ids, max_new_tokens, forced_answer=None, use_cache=False):
+def _stack_ctx(points, stack):
+    """bf16 points for ONE stack of the path ("sam" / "clip" / "llama"): points=None leaves the mode as the caller set it."""
+    import contextlib
+    return bf16_points() if points is not None and stack in points else contextlib.nullcontext()
+
+
+def lisa_generate(sd, cfg, images_clip, input_ids, max_new_tokens, forced_answer=None, use_cache=False, points=None):
     """Greedy generate (LISA.py:443-450). use_cache=False follows the reference exactly: config.use_cache=False
     (LISA.py:115) so EVERY step re-runs CLIP + projector + the full sequence (llava_llama.py:82-102).
     use_cache=True is the numerically equivalent KV-cached schedule. forced_answer [B,n] overrides the
     appended tokens (argmax is still computed) — synthetic random-init models never emit [SEG]/EOS.
+    points (test infrastructure): a subset of {"clip", "llama"} switches the bf16-points mode on for that stack only.
     Returns (output_ids [B,L+N], hidden [B,T+N-1,H] of the last step)."""
     B = input_ids.shape[0]
     out_ids = input_ids.clone()
@@ -389,15 +396,17 @@ def lisa_generate(sd, cfg, images_clip, input_ids, max_new_tokens, forced_answer
     img = None
     for step in range(max_new_tokens):
         if not use_cache or step == 0:
-            img = encode_images(sd, cfg, images_clip)
-        if not use_cache:
-            hidden_all = llama_forward(sd, splice_embeddings(sd, out_ids, img), cfg.llm)
-        elif step == 0:
-            cache = [None] * cfg.llm.layers
-            hidden_all = llama_forward(sd, splice_embeddings(sd, out_ids, img), cfg.llm, cache)
-        else:
-            h_new = llama_forward(sd, sd["model.embed_tokens.weight"][out_ids[:, -1:]], cfg.llm, cache)
-            hidden_all = torch.cat([hidden_all, h_new], dim=1)
+            with _stack_ctx(points, "clip"):
+                img = encode_images(sd, cfg, images_clip)
+        with _stack_ctx(points, "llama"):
+            if not use_cache:
+                hidden_all = llama_forward(sd, splice_embeddings(sd, out_ids, img), cfg.llm)
+            elif step == 0:
+                cache = [None] * cfg.llm.layers
+                hidden_all = llama_forward(sd, splice_embeddings(sd, out_ids, img), cfg.llm, cache)
+            else:
+                h_new = llama_forward(sd, sd["model.embed_tokens.weight"][out_ids[:, -1:]], cfg.llm, cache)
+                hidden_all = torch.cat([hidden_all, h_new], dim=1)
         logits = F.linear(hidden_all[:, -1], sd["lm_head.weight"])
         nxt = logits.argmax(-1)
         if forced_answer is not None:
@@ -411,9 +420,20 @@ def lisa_generate(sd, cfg, images_clip, input_ids, max_new_tokens, forced_answer
 
 
 def lisa_evaluate(sd, cfg, images_clip, images, input_ids, resize_list, original_size_list, max_new_tokens=32,
-                  forced_answer=None, use_cache=False, taps=None):
-    """LISAForCausalLM.evaluate (LISA.py:432-534) -> (output_ids, pred_masks_left, pred_masks_right, taxonomies)."""
-    output_ids, hidden = lisa_generate(sd, cfg, images_clip, input_ids, max_new_tokens, forced_answer, use_cache)
+                  forced_answer=None, use_cache=False, taps=None, points=None, memo=None):
+    """LISAForCausalLM.evaluate (LISA.py:432-534) -> (output_ids, pred_masks_left, pred_masks_right, taxonomies).
+    Test infrastructure on top of the reference's call: `points` (a subset of {"sam", "clip", "llama"}) runs ONE OR MORE stacks
+    in the bf16-points mode and the rest exactly (attribution of the bf16 path's distance to the stacks), and `memo` (a dict the
+    caller keeps across calls on the SAME inputs) re-uses the generate() result per (clip, llama) setting and the image
+    embedding per sam setting, so that an attribution at full depth costs one stage per variant instead of one frame."""
+    on = (lambda s: points is not None and s in points)
+    kg, ks = ("gen", on("clip"), on("llama")), ("sam", on("sam"))
+    if memo is not None and kg in memo:
+        output_ids, hidden = memo[kg]
+    else:
+        output_ids, hidden = lisa_generate(sd, cfg, images_clip, input_ids, max_new_tokens, forced_answer, use_cache, points)
+        if memo is not None:
+            memo[kg] = (output_ids, hidden)
     mask = seg_token_mask(output_ids, cfg.seg_token_idx)
     last = text_hidden_fcs(sd, hidden)
     pred = last[mask]
@@ -421,7 +441,13 @@ def lisa_evaluate(sd, cfg, images_clip, images, input_ids, resize_list, original
     offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(-1)], dim=0)
     pred_embeddings = [pred[offs[i]: offs[i + 1]] for i in range(len(offs) - 1)]
     V = "model.visual_model"
-    emb = torch.cat([sam_image_encoder(sd, V + ".image_encoder", images[i: i + 1], cfg.sam) for i in range(images.shape[0])], 0)
+    if memo is not None and ks in memo:
+        emb = memo[ks]
+    else:
+        with _stack_ctx(points, "sam"):
+            emb = torch.cat([sam_image_encoder(sd, V + ".image_encoder", images[i: i + 1], cfg.sam) for i in range(images.shape[0])], 0)
+        if memo is not None:
+            memo[ks] = emb
     grid = (cfg.sam.img_size // cfg.sam.patch,) * 2
     pe = sam_dense_pe(sd, V + ".prompt_encoder", grid)
     if taps is not None:

@@ -921,6 +921,26 @@ def test_norms(dev, C, dtype):
     assert (got[m < 0] == 0).all()
 
 
+@pytest.mark.parametrize("C,R", [(1280, 77), (1280, 8203), (4096, 5), (4096, 600), (5120, 3)])
+def test_norms_f32_rows_to_bf16(dev, C, R):
+    """dtype 2 of haff_layernorm / haff_rmsnorm: an fp32 residual stream normalised in fp32 and rounded to bf16 ONCE — bit-equal
+    to the fp32 kernel's result rounded to bf16 (both row kernels: one wave per row, one workgroup per row)."""
+    ops = _ops()
+    x = _rand((R, C), dev, torch.float32, 56, 2.0) + 0.3
+    w = _rand((C,), dev, torch.float32, 57) + 1.0
+    b = _rand((C,), dev, torch.float32, 58)
+    got = ops.layernorm(x, w, b, 1e-6, out_dtype=torch.bfloat16)
+    assert got.dtype == torch.bfloat16
+    assert torch.equal(got, ops.layernorm(x, w, b, 1e-6).to(torch.bfloat16))
+    _close(got, F.layer_norm(x, (C,), w, b, 1e-6), 1e-2, "layernorm f32 -> bf16")
+    got = ops.rmsnorm(x, w, 1e-5, out_dtype=torch.bfloat16)
+    assert got.dtype == torch.bfloat16 and torch.equal(got, ops.rmsnorm(x, w, 1e-5).to(torch.bfloat16))
+    m = torch.randint(0, R, (R + 9,), device=dev).to(torch.int32)
+    m[::5] = -1
+    got = ops.layernorm(x, w, b, 1e-6, in_map=m, out_dtype=torch.bfloat16)
+    assert torch.equal(got, ops.layernorm(x, w, b, 1e-6, in_map=m).to(torch.bfloat16)) and (got[m < 0] == 0).all()
+
+
 @pytest.mark.parametrize("C", [256, 1024, 1280])
 def test_norms_many_rows(dev, C):
     """>= 8192 rows take the 4-rows-per-wave kernel: ragged row count, gather map with dropped rows."""
