@@ -45,6 +45,7 @@
 #undef HAFF_EXP_SAMETILE
 #undef HAFF_GEMM_TRACE
 #undef HAFF_GEMM_TRACE2
+#undef HAFF_GEMM_TRACE3
 #undef HAFF_EPI_LDS
 #undef HAFF_GEMM_NO_NT
 #undef HAFF_GEMM_GELU_SCALAR
@@ -107,6 +108,11 @@ struct GemmArgs {
   const float* rope_cs;
   void *rope_k, *rope_v;
   int rope_t, rope_tmax, rope_pos0, rope_hd;
+  // HEAD-MAJOR scatter of the output (haff_gemm_bf16_heads; 8-wave tile, register epilogue, bf16, row map, no residual): product
+  // column n = part * hm_hd + h * hm_d + c of product row m is stored at C[part * hm_part + h * hm_head + row_map[m] * hm_d + c]
+  // (elements). hm_d == 0: off.
+  int hm_d, hm_hd;
+  long hm_part, hm_head;
 };
 
 // Epilogue activations of the throughput (bf16) path. GELU matters for the K=1280 SAM MLP GEMM, whose epilogue touches
@@ -173,6 +179,21 @@ extern "C" int haff_gemm_trace2_read(unsigned long long* host, int n_words) {
 }
 #else
 #define HAFF_TRACE2(i) do {} while (0)
+#endif
+#ifdef HAFF_GEMM_TRACE3  // round 5: 32 stamps per (workgroup, wave 0 / wave 4) of a MIDDLE tile (one that has a successor): tile start, the
+// last K-tile's slots and its wait for the next tile's first K-tile, the epilogue's passes (pass 0 and 4 in four sub-steps), the
+// barrier behind it. tools/gemm_trace3.py
+__device__ unsigned long long haff_gemm_trace3_buf[256 * 2 * 32];
+// stamps go to LDS (a global store per stamp sat in vmcnt and the next vmcnt(0) of the traced wave waited for it: "pre" read 1 us)
+// and are flushed once per tile, behind the barrier that follows the epilogue
+#define HAFF_TRACE3(i) do { __builtin_amdgcn_sched_barrier(0); if (has_next && (tid & 255) == 0) haff_t3s[tid >> 8][(i)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HAFF_TRACE3_FLUSH() do { if ((tid & 255) < 32 && blockIdx.x < 256 && blockIdx.y == 0) haff_gemm_trace3_buf[(blockIdx.x * 2 + (tid >> 8)) * 32 + (tid & 255)] = haff_t3s[tid >> 8][tid & 255]; } while (0)
+extern "C" int haff_gemm_trace3_read(unsigned long long* host, int n_words) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(haff_gemm_trace3_buf), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : 1;
+}
+#else
+#define HAFF_TRACE3(i) do {} while (0)
+#define HAFF_TRACE3_FLUSH() do {} while (0)
 #endif
 #ifdef HAFF_GEMM_TRACE  // phase timestamps (100 MHz wall clock) of each workgroup's first tile, for tools/gemm_trace.py
 __device__ unsigned long long haff_gemm_trace_buf[8192 * 8];
@@ -243,9 +264,36 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //                  ~64 B/clk/CU from L2 at full MFMA rate, more than the ~56 B/clk/CU the L2 can deliver)
 //   <192,256,2,4>: the same ring loop on 96 x 64 per wave (round 4) for row counts that quantise badly into 256-row tiles:
 //                  the fine-tune step's 2808-row products are 11 x 16 = 176 tiles of 256^2 on 256 CUs but 15 x 16 = 240 of these
-template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU>
+// Compile-time specialisation of the 8-wave tile's epilogue (round 5). One kernel instance served every epilogue variant at
+// run time until round 4: 33 000 instructions (250 KB of code for a 64 KB instruction cache), 92 spilled SGPRs, and ~0.9 us
+// between the end of a tile's K loop and the first pass of its epilogue spent finding the way through it
+// (profiles/r5_gemm_trace3_tile_boundary.txt). FLAGS = GF_SPEC | features: the launcher has checked on the HOST that every tile
+// is interior (M % BM == 0, N % BN == 0), every pointer 16-B aligned, ldc / ldr multiples of 8 and the launch not batched, so the
+// instance carries the register epilogue of exactly its feature set and nothing else (same arithmetic, same results; the
+// generic instance FLAGS = 0 keeps every path and serves the rest). Measured on plain products: +1.5 ... +3.9 % per launch.
+enum : unsigned {
+  GF_SPEC = 1u, GF_BIAS = 2u, GF_LN = 4u, GF_CSUM = 8u, GF_RES = 16u, GF_STAT = 32u, GF_MAP = 64u, GF_HM = 128u, GF_ROPE = 256u,
+  GF_RAGM = 512u,   // the row count need not be a multiple of BM: the M-side interior tests stay at run time (Llama's 64 x 291 rows)
+  GF_ACT_SHIFT = 16
+};
+
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool SWIGLU, unsigned FLAGS = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr bool PP = (WM * WN == 8);   // the 8-wave tile runs the persistent ping-pong ring loop
+  constexpr bool SPEC = (FLAGS & GF_SPEC) != 0;
+  constexpr bool MFULL = SPEC && !(FLAGS & GF_RAGM);   // every M-tile is whole
+  static_assert(!SPEC || (PP && BM == 256 && !OUT_F32), "specialised epilogues exist for the bf16 256 x 256 tile");
+  // feature tests: compile-time constants in a specialised instance, the argument block's pointers otherwise
+  const bool has_bias = SPEC ? (FLAGS & GF_BIAS) != 0 : p.bias != nullptr;
+  const bool has_ln = SPEC ? (FLAGS & GF_LN) != 0 : p.ln_stats != nullptr;
+  const bool has_csum = SPEC ? (FLAGS & GF_CSUM) != 0 : p.ln_colsum != nullptr;
+  const bool has_res = SPEC ? (FLAGS & GF_RES) != 0 : p.resid != nullptr;
+  const bool has_stat = SPEC ? (FLAGS & GF_STAT) != 0 : p.stat_out != nullptr;
+  const bool has_map = SPEC ? (FLAGS & GF_MAP) != 0 : p.row_map != nullptr;
+  const bool has_hm = SPEC ? (FLAGS & GF_HM) != 0 : p.hm_d != 0;
+  const bool has_rope = SPEC ? (FLAGS & GF_ROPE) != 0 : p.rope_cs != nullptr;
+  const int act = SPEC ? (int)((FLAGS >> GF_ACT_SHIFT) & 7u) : p.act;
+  auto al16 = [](const void* q) { return SPEC || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };   // (checked on the host for SPEC)
   static_assert((BM == 256 && BN == 256 && WM == 2 && WN == 4) || (BM == 192 && BN == 256 && WM == 2 && WN == 4) ||
                 (BM == 128 && BN == 128 && WM == 2 && WN == 2), "three tiles");
   constexpr int NTHREADS = 64 * WM * WN;
@@ -262,7 +310,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (p.nb_inner > 0) {
+#ifdef HAFF_GEMM_TRACE3
+  __shared__ unsigned long long haff_t3s[2][32];
+#endif
+#if defined(HAFF_TUNING) && defined(HAFF_EXP_FORCE_PLAIN)   // experiment: what a compile-time-specialised epilogue would cost (bias only, interior tiles)
+  p.act = 0; p.ln_stats = nullptr; p.ln_colsum = nullptr; p.resid = nullptr; p.row_map = nullptr; p.a_map = nullptr; p.rope_cs = nullptr;
+  p.stat_out = nullptr; p.hm_d = 0; p.nb_inner = 0; p.nt_out = 0;
+#endif
+  if (!SPEC && p.nb_inner > 0) {
     const int zo = blockIdx.y / p.nb_inner, zi = blockIdx.y - zo * p.nb_inner;
     p.A += zo * p.sAo + zi * p.sAi;
     p.W += zo * p.sWo + zi * p.sWi;
@@ -467,6 +522,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   int m0e = m0, n0e = n0;                       // this tile's origin (the PP loop moves m0 / n0 on to the next tile)
   const int tile_next = tile + (int)gridDim.x;
   const bool has_next = PP && tile_next < nwg;
+  HAFF_TRACE3(0);
   const bool pf_next = has_next && nk >= 2;   // the K loop requests the next tile's K-tile 0 (a single-K-tile product cannot: its
                                               // requests would have to go out before its own loop starts; see the loop's end)
   // K loop, software-pipelined ACROSS the workgroup barrier. One barrier per K-tile: after it every wave's share of
@@ -583,23 +639,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(base) + o), (lptr_t)lds_dst, 16, 0, 0);
     };
     float* sXw = reinterpret_cast<float*>(smem + 2 * STAGE_ELEMS);
-    if (p.bias && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && wave == 0) dma_row16(p.bias + n0, sXw);
+    if (has_bias && (SPEC || n0 + BN <= p.N) && al16(p.bias) && wave == 0) dma_row16(p.bias + n0, sXw);
     // folded norm: the tile's 256 {mean, rstd} rows and 256 column sums the same way (waves 1-3, three DMA instructions):
     // loaded at the top of the epilogue they put a memory round trip in front of pass 0 of every tile (+0.35 % of the step,
     // norm-folded products 1100 -> 1108 TFLOP/s: bench.py `by_epilogue`, profiles/r3_ln_prefetch_ab.txt)
-    if (BM == 256 && p.ln_stats && m0 + BM <= p.M && n0 + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0) {   // (256 rows per request pair: the 192-row tile loads them in its epilogue)
+    if (BM == 256 && has_ln && (MFULL || m0 + BM <= p.M) && (SPEC || n0 + BN <= p.N) && al16(p.ln_stats)) {   // (256 rows per request pair: the 192-row tile loads them in its epilogue)
       if (wave == 1) dma_row16(p.ln_stats + 2 * (long)m0, sXw + 256);
       if (wave == 2) dma_row16(p.ln_stats + 2 * (long)(m0 + 128), sXw + 512);
-      if (wave == 3 && p.ln_colsum && (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0) dma_row16(p.ln_colsum + n0, sXw + 768);
+      if (wave == 3 && has_csum && al16(p.ln_colsum)) dma_row16(p.ln_colsum + n0, sXw + 768);
     }
     // round 4: the output row map of the tile's 256 rows the same way (wave 4). Read per lane from global memory at the top of the
     // epilogue (orow_l below) it put a dependent memory round trip in front of pass 0 of every windowed q|k|v tile.
-    if (BM == 256 && p.row_map && m0 + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0 && wave == 4) dma_row16(p.row_map + m0, sXw + 1024);
+    if (BM == 256 && has_map && (MFULL || m0 + BM <= p.M) && al16(p.row_map) && wave == 4) dma_row16(p.row_map + m0, sXw + 1024);
     if (nk > 1) {
       stage_w_q(buf0 ^ 1, BK, Q0{});
       stage_w_q(buf0 ^ 1, BK, Q1{});
     }
     HAFF_TRACE(1);
+    HAFF_TRACE3(1);
     if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = (kt & 1) ^ buf0;
@@ -618,6 +675,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #define PP_READ(x) x
 #endif
       // ---- load slot A: W lo, W hi, A lo; requests for the A quarters of K-tile kt+1 ----
+      if (kt == nk - 1) HAFF_TRACE3(2);
       PP_READ(read_w(cur, pwl, Q0{}));
       PP_READ(read_a(cur, Q0{}));
       PP_READ(read_w(cur, pwh, Q1{}));
@@ -626,18 +684,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         PP_DMA(stage_a_q(cur ^ 1, a_k0, Q1{}));
       }
       close_load();
+      if (kt == nk - 1) HAFF_TRACE3(3);
       // ---- multiply slot A: quadrants (A lo, W lo), (A lo, W hi) ----
       __builtin_amdgcn_s_setprio(1);
       quad(pwl, I0{}, I0{});
       quad(pwh, I2{}, I0{});
       __builtin_amdgcn_s_setprio(0);
       slot_barrier();
+      if (kt == nk - 1) HAFF_TRACE3(4);
       // ---- load slot B: A hi; requests for the W quarters of K-tile kt+2; the wait for K-tile kt+1 ----
       if (kt + 2 == nk && pf_next) {   // from here on the staging coordinates are the next tile's
         tile_origin(tile_next, m0, n0);
         stage_coords(m0, n0);
       }
       PP_READ(read_a(cur, Q1{}));
+      if (kt == nk - 1) HAFF_TRACE3(5);
       if (w_next) {
         PP_DMA(stage_w_q(cur, w_k0, Q0{}));
         PP_DMA(stage_w_q(cur, w_k0, Q1{}));
@@ -645,7 +706,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      if (kt == nk - 1) HAFF_TRACE3(6);
       close_load();
+      if (kt == nk - 1) HAFF_TRACE3(7);
       // ---- multiply slot B: quadrants (A hi, W hi), (A hi, W lo) ----
       __builtin_amdgcn_s_setprio(1);
       quad(pwh, I2{}, IH{});
@@ -737,6 +800,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   if constexpr (!PP) __builtin_amdgcn_s_barrier();
   HAFF_TRACE(2);
   HAFF_TRACE2(0);
+  HAFF_TRACE3(9);
   // the buffer the last K-tile was read from takes the LDS-staged epilogue's images (ragged tiles); the other one holds the
   // next tile's first K-tile, which the ring loop has requested AND waited for already
   const int ebuf = ((nk - 1) & 1) ^ buf0;
@@ -760,17 +824,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   const int n_wave_out = SWIGLU ? (n_wave_in >> 1) : n_wave_in;
   const int m_wave = m0e + wm * WROWS;
   const bool c_vec = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((p.ldc & 7) == 0);
-  const bool r_vec = p.resid && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) && ((p.ldr & 7) == 0);
-  const bool fast = c_vec && (!p.resid || r_vec) && (n_wave_out + WCOLS <= n_total_out);
+  const bool r_vec = has_res && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) && ((p.ldr & 7) == 0);
+  const bool fast = SPEC || (c_vec && (!has_res || r_vec) && (n_wave_out + WCOLS <= n_total_out));
   const bool nt_out = p.nt_out != 0;
 
   float bias_r[TN][4];
-  if (!p.bias) {
+  if (!has_bias) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int r = 0; r < 4; ++r) bias_r[ni][r] = 0.f;
-  } else if (PP && n0e + BN <= p.N && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+  } else if (PP && (SPEC || n0e + BN <= p.N) && al16(p.bias)) {
     const float* sBias = reinterpret_cast<const float*>(smem + 2 * STAGE_ELEMS) + wn * WNC;   // staged at the top of the tile
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) load4(sBias + ni * 16 + fh * 4, bias_r[ni]);
@@ -786,24 +850,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         bias_r[ni][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
       }
   }
+  HAFF_TRACE3(28);
   // folded norm: this wave's {mean, rstd} rows and column sums go through LDS (free stage memory past the staging
   // images) so the per-pass code reads them back instead of holding 2*TM + 4*TN more registers
   static_assert((WM * WN * 16 * RS + WM * WN * (2 * WROWS + WNC)) * 4 <= STAGE_ELEMS * 2, "epilogue LDS fits one stage");
   float* sStat = reinterpret_cast<float*>(smem + ebuf * STAGE_ELEMS) + WM * WN * 16 * RS + wave * (2 * WROWS + WNC);   // behind the staging images
   float* sCsum = sStat + 2 * WROWS;
   // (8-wave tile, interior tile: both came in by DMA at the top of the tile's K loop — see there)
-  const bool ln_pref = PP && BM == 256 && p.ln_stats && m0e + BM <= p.M && n0e + BN <= p.N && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0 &&
-                       (!p.ln_colsum || (reinterpret_cast<uintptr_t>(p.ln_colsum) & 15) == 0);
+  const bool ln_pref = PP && BM == 256 && has_ln && (MFULL || m0e + BM <= p.M) && (SPEC || n0e + BN <= p.N) && al16(p.ln_stats) &&
+                       (!has_csum || al16(p.ln_colsum));
   if (ln_pref) {
     float* sLn = reinterpret_cast<float*>(smem + 2 * STAGE_ELEMS) + 256;
     sStat = sLn + 2 * wm * WROWS;
-    if (p.ln_colsum) sCsum = sLn + 512 + wn * WNC;
+    if (has_csum) sCsum = sLn + 512 + wn * WNC;
     else {   // RMSNorm: no mean term — zeros from the wave's own scratch
 #pragma unroll
       for (int h = 0; h < WNC / 64; ++h) sCsum[h * 64 + lane] = 0.f;
       __builtin_amdgcn_wave_barrier();
     }
-  } else if (p.ln_stats) {
+  } else if (has_ln) {
 #pragma unroll
     for (int h = 0; h < (WROWS + 63) / 64; ++h) {
       const int m = min(m_wave + h * 64 + lane, p.M - 1);
@@ -813,19 +878,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
     for (int h = 0; h < WNC / 64; ++h) {
       const int n = n_wave_in + h * 64 + lane;
-      sCsum[h * 64 + lane] = (p.ln_colsum && n < p.N) ? p.ln_colsum[n] : 0.f;
+      sCsum[h * 64 + lane] = (has_csum && n < p.N) ? p.ln_colsum[n] : 0.f;
     }
     __builtin_amdgcn_wave_barrier();
   }
+  HAFF_TRACE3(29);
   // output row of wave-row (lane) and (lane + 64): -1 = dropped. Distributed to the read-back lanes by ds_bpermute.
   int orow_l[(WROWS + 63) / 64];
-  const bool map_staged = PP && BM == 256 && p.row_map && m0e + BM <= p.M && (reinterpret_cast<uintptr_t>(p.row_map) & 15) == 0;   // (the DMA above)
+  const bool map_staged = PP && BM == 256 && has_map && (MFULL || m0e + BM <= p.M) && al16(p.row_map);   // (the DMA above)
 #pragma unroll
   for (int h = 0; h < (WROWS + 63) / 64; ++h) {
     const int m = m_wave + h * 64 + lane;
     if (map_staged) orow_l[h] = reinterpret_cast<const int*>(smem + 2 * STAGE_ELEMS)[1024 + wm * WROWS + h * 64 + lane];
-    else orow_l[h] = (m < p.M && h * 64 + lane < WROWS) ? (p.row_map ? p.row_map[m] : m) : -1;
+    else orow_l[h] = ((MFULL || m < p.M) && h * 64 + lane < WROWS) ? (has_map ? p.row_map[m] : m) : -1;
   }
+  HAFF_TRACE3(30);
 #ifndef HAFF_EPI_LDS   // -DHAFF_EPI_LDS: every tile through the LDS-staged epilogue below (A/B runs)
   // ---- register epilogue (interior tiles, 16-B aligned rows) ----
   // The swapped MFMA orientation leaves 4 consecutive output columns of ONE row in each lane (chunk c = 16-column
@@ -872,7 +939,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
       }
     };
     if constexpr (RES) fetch_r(0);
+    // head-major scatter (see GemmArgs::hm_d): the lane's 8 columns of chunk pair j lie inside ONE head (hm_d % 8 == 0); their
+    // element offset is fixed for the tile, the row part (row_map[m] * hm_d) changes per pass
+    long hm_col[NCH / 2 > 0 ? NCH / 2 : 1];
+    if constexpr (!ALL && !RES && !SWIGLU && !OUT_F32) {
+      if (has_hm) {
+#pragma unroll
+        for (int j = 0; j < NCH / 2; ++j) {
+          const int col = n_wave_out + 32 * j + coff;
+          const int part = (col >= p.hm_hd) + (col >= 2 * p.hm_hd);
+          const int rem = col - part * p.hm_hd;
+          const int h = (int)(((float)rem + 0.5f) * (1.0f / (float)p.hm_d));   // exact: rem < 2^16, hm_d >= 8
+          hm_col[j] = (long)part * p.hm_part + (long)h * p.hm_head + (rem - h * p.hm_d);
+        }
+      }
+    }
     HAFF_TRACE2(1);
+    HAFF_TRACE3(10);
     // ALL: the lane's output address is affine in the pass index — one 64-bit base per tile and a scalar stride per pass
     // instead of a 64-bit multiply-add chain per store (the epilogue is instruction-bound: two waves per SIMD, ~60 VALU
     // per pass before this)
@@ -881,16 +964,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     const long c_pass = 16L * p.ldc * (OUT_F32 ? 4 : 2);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-      if (p.ln_stats) {   // rstd * (acc - mean * colsum) in place; bias / activation follow as usual
+      // folded norm: x = rstd * (acc - mean * colsum) + bias as TWO explicit FMAs (acc - mean * colsum here, * rstd + bias where the
+      // bias is added), so that every instance of this kernel rounds alike whatever hipcc's contraction pass would pick; without a
+      // norm rstd_m = 1 and fma(acc, 1, bias) is the plain sum
+      float rstd_m = 1.0f;
+      if (has_ln) {
         const float2 st = *reinterpret_cast<const float2*>(sStat + 2 * (mi * 16 + fr));
+        rstd_m = st.y;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
           float cs[4];
           load4(sCsum + ni * 16 + fh * 4, cs);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[ni][mi][r] = (acc[ni][mi][r] - st.x * cs[r]) * st.y;
+          for (int r = 0; r < 4; ++r) acc[ni][mi][r] = __builtin_fmaf(-st.x, cs[r], acc[ni][mi][r]);
         }
       }
+      if (mi == 0) HAFF_TRACE3(21);
+      if (mi == 4) HAFF_TRACE3(25);
       float val[NCH][4];
       if constexpr (!SWIGLU) {
         auto act_side = [&](auto tag) {   // the activation is resolved ONCE per pass (wave-uniform switch)
@@ -898,16 +988,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
           for (int ni = 0; ni < TN; ++ni) {
             if constexpr (ACT == HAFF_ACT_GELU) {
-              const haff_f2 a = gelu_pair(haff_f2{acc[ni][mi][0] + bias_r[ni][0], acc[ni][mi][1] + bias_r[ni][1]});
-              const haff_f2 b = gelu_pair(haff_f2{acc[ni][mi][2] + bias_r[ni][2], acc[ni][mi][3] + bias_r[ni][3]});
+              const haff_f2 a = gelu_pair(haff_f2{__builtin_fmaf(acc[ni][mi][0], rstd_m, bias_r[ni][0]), __builtin_fmaf(acc[ni][mi][1], rstd_m, bias_r[ni][1])});
+              const haff_f2 b = gelu_pair(haff_f2{__builtin_fmaf(acc[ni][mi][2], rstd_m, bias_r[ni][2]), __builtin_fmaf(acc[ni][mi][3], rstd_m, bias_r[ni][3])});
               val[ni][0] = a[0]; val[ni][1] = a[1]; val[ni][2] = b[0]; val[ni][3] = b[1];
             } else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) val[ni][r] = gemm_act<ACT>(acc[ni][mi][r] + bias_r[ni][r]);
+              for (int r = 0; r < 4; ++r) val[ni][r] = gemm_act<ACT>(__builtin_fmaf(acc[ni][mi][r], rstd_m, bias_r[ni][r]));
             }
           }
         };
-        switch (p.act) {
+        switch (act) {
           case HAFF_ACT_GELU: act_side(std::integral_constant<int, HAFF_ACT_GELU>{}); break;
           case HAFF_ACT_QUICK_GELU: act_side(std::integral_constant<int, HAFF_ACT_QUICK_GELU>{}); break;
           case HAFF_ACT_RELU: act_side(std::integral_constant<int, HAFF_ACT_RELU>{}); break;
@@ -919,17 +1009,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         for (int nj = 0; nj < TN / 2; ++nj)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float g = acc[2 * nj][mi][r] + bias_r[2 * nj][r];
-            const float u = acc[2 * nj + 1][mi][r] + bias_r[2 * nj + 1][r];
+            const float g = __builtin_fmaf(acc[2 * nj][mi][r], rstd_m, bias_r[2 * nj][r]);
+            const float u = __builtin_fmaf(acc[2 * nj + 1][mi][r], rstd_m, bias_r[2 * nj + 1][r]);
             val[nj][r] = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u;
           }
       }
+      if (mi == 0) HAFF_TRACE3(22);
+      if (mi == 4) HAFF_TRACE3(26);
       const int orow = out_row(mi);
       float st1 = 0.f, st2 = 0.f;   // row statistics of the final values (RES && ALL && p.stat_out)
       // RoPE + KV-cache append (see GemmArgs::rope_cs): rotate the lane's (c, c + 64) pairs, pick the destination row
       bf16_t* rope_dst = nullptr;
       if constexpr (!RES && !SWIGLU && !OUT_F32) {
-        if (p.rope_cs) {   // wave-uniform
+        if (has_rope) {   // wave-uniform
           const int role = n0e / p.rope_hd;                               // 0 q, 1 k, 2 v: uniform over a 256-column tile
           const int col0 = n0e - role * p.rope_hd + (wn >> 1) * 128 + (wn & 1) * 32 + coff;   // lane's first column, j = 0
           const int m = (ALL || orow >= 0) ? orow : 0;
@@ -960,7 +1052,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         for (int c = 0; c < NCH; ++c) {
           if (ALL || orow >= 0) {
             const long o = n_wave_out + 16 * c + 4 * fh;
-            if (p.resid) {
+            if (has_res) {
               float rr[4];
               load4(reinterpret_cast<const float*>(p.resid) + (long)orow * p.ldr + o, rr);
 #pragma unroll
@@ -999,7 +1091,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
             }
             q = haff_u32x4{pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]), pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7])};
             if constexpr (ALL) {
-              if (p.stat_out) {   // (wave-uniform) the lane's 8 columns of this row; the row's other columns sit in 3 more lanes
+              if (has_stat) {   // (wave-uniform) the lane's 8 columns of this row; the row's other columns sit in 3 more lanes
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   st1 += v8[e];
@@ -1023,6 +1115,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
             if constexpr (!RES && !SWIGLU) {
               if (rope_dst) dst = rope_dst + 64 * j;   // logical columns: block pair j = 1 is the rotate-half partner half
             }
+            if constexpr (!ALL && !RES && !SWIGLU) {
+              if (has_hm) dst = reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.hm_d + hm_col[j];
+            }
             // plain stores: a lane writes HALF a 128-B line here and the other half with its next store; the L2 merges
             // them, a non-temporal store would send each half to memory on its own (measured -2...-8 %)
             *reinterpret_cast<haff_u32x4*>(dst) = q;
@@ -1030,8 +1125,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #endif
         }
       }
+      if (mi == 0) HAFF_TRACE3(23);
+      if (mi == 4) HAFF_TRACE3(27);
       if constexpr (RES && ALL) {
-        if (p.stat_out) {   // the four lanes of a row (same fr, fh = 0..3) -> one {sum, sum of squares} per (row, wave)
+        if (has_stat) {   // the four lanes of a row (same fr, fh = 0..3) -> one {sum, sum of squares} per (row, wave)
           st1 = quad_row_sum(st1);
           st2 = quad_row_sum(st2);
           if (fh == 0)
@@ -1039,10 +1136,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         }
       }
       HAFF_TRACE2(2 + mi);
+      HAFF_TRACE3(11 + mi);
     }
     };   // reg_epilogue
-    const bool all_rows = !p.row_map && m_wave + WROWS <= p.M;
-    if (!OUT_F32 && p.resid) {
+    const bool all_rows = !has_map && (MFULL || m_wave + WROWS <= p.M);
+    if (!OUT_F32 && has_res) {
       if (all_rows) reg_epilogue(std::true_type{}, std::true_type{});
       else reg_epilogue(std::false_type{}, std::true_type{});
     } else {
@@ -1070,7 +1168,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         rres[st] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)orow * p.ldr + n_out);
     }
   };
-  const bool pre_r = PREFETCH_R && fast && p.resid;
+  const bool pre_r = PREFETCH_R && fast && has_res;
   if (pre_r) fetch_resid(0);
 
 #ifdef HAFF_EXP_NOEPI   // timing experiment: the accumulators are kept alive, nothing is written
@@ -1082,14 +1180,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     float* row = sEp + fr * RS + fh * 4;
-    if (p.ln_stats) {   // rstd * (acc - mean * colsum) in place; bias / activation follow as usual
+    float rstd_m = 1.0f;   // (see the register epilogue: the same two FMAs)
+    if (has_ln) {
       const float2 st = *reinterpret_cast<const float2*>(sStat + 2 * (mi * 16 + fr));
+      rstd_m = st.y;
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         float cs[4];
         load4(sCsum + ni * 16 + fh * 4, cs);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = (acc[ni][mi][r] - st.x * cs[r]) * st.y;
+        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = __builtin_fmaf(-st.x, cs[r], acc[ni][mi][r]);
       }
     }
     if (!SWIGLU) {
@@ -1101,19 +1201,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
           float v[4];
 #ifndef HAFF_GEMM_GELU_SCALAR
           if constexpr (ACT == HAFF_ACT_GELU) {
-            const haff_f2 a = gelu_pair(haff_f2{acc[ni][mi][0] + bias_r[ni][0], acc[ni][mi][1] + bias_r[ni][1]});
-            const haff_f2 b = gelu_pair(haff_f2{acc[ni][mi][2] + bias_r[ni][2], acc[ni][mi][3] + bias_r[ni][3]});
+            const haff_f2 a = gelu_pair(haff_f2{__builtin_fmaf(acc[ni][mi][0], rstd_m, bias_r[ni][0]), __builtin_fmaf(acc[ni][mi][1], rstd_m, bias_r[ni][1])});
+            const haff_f2 b = gelu_pair(haff_f2{__builtin_fmaf(acc[ni][mi][2], rstd_m, bias_r[ni][2]), __builtin_fmaf(acc[ni][mi][3], rstd_m, bias_r[ni][3])});
             v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
           } else
 #endif
           {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gemm_act<ACT>(acc[ni][mi][r] + bias_r[ni][r]);
+            for (int r = 0; r < 4; ++r) v[r] = gemm_act<ACT>(__builtin_fmaf(acc[ni][mi][r], rstd_m, bias_r[ni][r]));
           }
           store4(row + ni * 16, v);
         }
       };
-      switch (p.act) {
+      switch (act) {
         case HAFF_ACT_GELU: write_side(std::integral_constant<int, HAFF_ACT_GELU>{}); break;
         case HAFF_ACT_QUICK_GELU: write_side(std::integral_constant<int, HAFF_ACT_QUICK_GELU>{}); break;
         case HAFF_ACT_RELU: write_side(std::integral_constant<int, HAFF_ACT_RELU>{}); break;
@@ -1126,8 +1226,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float g = acc[2 * nj][mi][r] + bias_r[2 * nj][r];
-          const float u = acc[2 * nj + 1][mi][r] + bias_r[2 * nj + 1][r];
+          const float g = __builtin_fmaf(acc[2 * nj][mi][r], rstd_m, bias_r[2 * nj][r]);
+          const float u = __builtin_fmaf(acc[2 * nj + 1][mi][r], rstd_m, bias_r[2 * nj + 1][r]);
           v[r] = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u;
         }
         store4(row + nj * 16, v);
@@ -1205,6 +1305,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
 #endif
   if (!has_next) break;
   HAFF_TRACE2(10);
+  HAFF_TRACE3(19);
   if constexpr (PP) {
     __builtin_amdgcn_s_barrier();   // every wave is past its epilogue: its staging buffer takes K-tile 1
     if (!pf_next) {                 // single-K-tile products: the next tile's only K-tile is requested and awaited here
@@ -1216,6 +1317,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     }
   }
   HAFF_TRACE2(11);
+  HAFF_TRACE3(20);
+  HAFF_TRACE3_FLUSH();
   tile = tile_next;
   buf0 = ebuf ^ 1;
   }   // tile loop
@@ -1573,6 +1676,15 @@ static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
 
 }  // namespace
 
+static bool haff_gemm_spec_enabled() {
+#ifdef HAFF_TUNING   // HAFF_GEMM_NO_SPEC=1: every launch through the generic instance (A/B)
+  static const bool off = [] { const char* e = getenv("HAFF_GEMM_NO_SPEC"); return e && atoi(e) != 0; }();
+  return !off;
+#else
+  return true;
+#endif
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -1596,6 +1708,39 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
     pd.deep_k = (long)tiles * nbatch <= deep_max && ((p.K + BK - 1) / BK) >= 3;
   }
   const GemmArgs& pl = pd;
+  if constexpr (BM == 256 && BN == 256 && WM * WN == 8) {
+    // a specialised instance (see the GF_* flags) when the launch meets its host-side contract and its feature set has one
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool ok = nbatch == 1 && p.nb_inner == 0 && !p.out_f32 && (p.N % 256) == 0 && a16(p.C) && (p.ldc & 7) == 0 && a16(p.bias) &&
+                    a16(p.resid) && (!p.resid || (p.ldr & 7) == 0) && a16(p.ln_stats) && a16(p.ln_colsum) && a16(p.row_map) &&
+                    (!p.ln_colsum || p.ln_stats);
+    if (ok && haff_gemm_spec_enabled()) {
+      const unsigned f = (p.bias ? GF_BIAS : 0u) | (p.ln_stats ? GF_LN : 0u) | (p.ln_colsum ? GF_CSUM : 0u) | (p.resid ? GF_RES : 0u) |
+                         (p.stat_out ? GF_STAT : 0u) | (p.row_map ? GF_MAP : 0u) | (p.hm_d ? GF_HM : 0u) | (p.rope_cs ? GF_ROPE : 0u) |
+                         ((unsigned)p.act << GF_ACT_SHIFT);
+      const bool mfull = (p.M % 256) == 0;
+#define HAFF_SPEC(FL, SW)                                                                                                   \
+  if (f == ((FL) & ~(GF_SPEC | GF_RAGM)) && (p.swiglu != 0) == (SW) && (mfull || ((FL) & GF_RAGM))) {                       \
+    hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, false, SW, (FL) | GF_SPEC>), grid, block, 0, s, pl);               \
+    return haff_check_launch();                                                                                             \
+  }
+      constexpr unsigned GELU_ = (unsigned)HAFF_ACT_GELU << GF_ACT_SHIFT, QGELU_ = (unsigned)HAFF_ACT_QUICK_GELU << GF_ACT_SHIFT;
+      // the ViT-H blocks (131072 rows per 32 frames: always whole tiles): q|k|v global / windowed head-major, lin1, proj and lin2
+      HAFF_SPEC(GF_BIAS | GF_LN | GF_CSUM, false)
+      HAFF_SPEC(GF_BIAS | GF_LN | GF_CSUM | GF_MAP | GF_HM, false)
+      HAFF_SPEC(GF_BIAS | GF_LN | GF_CSUM | GELU_, false)
+      HAFF_SPEC(GF_BIAS | GF_RES | GF_STAT, false)
+      // Llama prefill (64 x 291 rows: ragged last M-tile): q|k|v with RoPE, o_proj / down_proj, gate|up; CLIP and everything plain
+      HAFF_SPEC(GF_ROPE | GF_RAGM, false)
+      HAFF_SPEC(GF_RES | GF_RAGM, false)
+      HAFF_SPEC(GF_RAGM, true)
+      HAFF_SPEC(GF_RAGM, false)
+      HAFF_SPEC(GF_BIAS | GF_RAGM, false)
+      HAFF_SPEC(GF_BIAS | GF_RES | GF_RAGM, false)
+      HAFF_SPEC(GF_BIAS | QGELU_ | GF_RAGM, false)
+#undef HAFF_SPEC
+    }
+  }
   if (p.swiglu) {
     if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, pl);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, pl);
@@ -1862,6 +2007,37 @@ extern "C" int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ld
   if (!ln_stats) return HAFF_ERR_BAD_ARG;
   return gemm_bf16_impl(A, lda, nullptr, 0, W, ldw, C, ldc, bias, resid, ldr, row_map, M, N, K, act, out_f32, swiglu, 0,
                         stream, ln_stats, ln_colsum);
+}
+
+// Product (optionally with a folded norm, as haff_gemm_bf16_ln) whose output is scattered HEAD-MAJOR: the windowed q|k|v
+// projection of a ViT-H block (image_encoder.py:223-224 qkv Linear + :263-288 window_partition + :238-239 the reshape into heads)
+// writes q, k and v of every (window, head) as ONE contiguous [tokens][d] block, so that the window attention kernel's K / V
+// staging reads whole 128-B lines (round 4 measured the token-major layout's 160-B pieces at a 7680-B stride as what paces it).
+//   product column n = part * (heads * d) + h * d + c, product row m  ->  C[part * part_stride + h * head_stride + row_map[m] * d + c]
+// (bf16 elements). With row_map[m] = window * heads * n_tok + token, head_stride = n_tok * d and part_stride = (windows + 1) *
+// heads * n_tok * d, C is [part][window][head][token][d] with one spare window for the pad token. row_map entries < 0 drop the row.
+// bias f32 [N]; ln_stats / ln_colsum as haff_gemm_bf16_ln or both null. Whole 256 x 256 tiles only (M % 256 == 0, N % 256 == 0,
+// K % 64 == 0), N == parts * heads * d with parts <= 3, d % 8 == 0: otherwise HAFF_ERR_UNSUPPORTED (-2) and the caller keeps the
+// token-major layout.
+extern "C" int haff_gemm_bf16_heads(const void* A, long lda, const void* W, long ldw, void* C, const float* bias, const int* row_map,
+                                    const float* ln_stats, const float* ln_colsum, int M, int N, int K, int d, int heads,
+                                    long part_stride, long head_stride, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || d <= 0 || heads <= 0 || !row_map || !C) return HAFF_ERR_BAD_ARG;
+  if ((K & 7) || (lda & 7) || (ldw & 7) || (part_stride & 7) || (head_stride & 7)) return HAFF_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(C) & 15))
+    return HAFF_ERR_BAD_ARG;
+  const long hd = (long)heads * d;
+  if ((d & 7) || d > 4096 || (M % 256) || (N % 256) || (K % BK) || N % hd != 0 || N / hd > 3 || hd >= (1L << 16)) return HAFF_ERR_UNSUPPORTED;
+  if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return HAFF_ERR_UNSUPPORTED;
+  GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C, (long)d,
+             bias, nullptr, 0, row_map, nullptr, 8, ln_stats, ln_colsum, M, N, K, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  p.hm_d = d; p.hm_hd = (int)hd; p.hm_part = part_stride; p.hm_head = head_stride;
+  const int tn = N / 256;   // raster depth: the rule of gemm_bf16_impl
+  if (tn <= 5) p.group_m = 1;
+  else if (K >= 5120 && tn <= 8) p.group_m = 2;
+  else if (tn <= 16) p.group_m = 4;
+  p.nt_out = (long)M * N * 2 >= (64L << 20);
+  return launch_gemm<256, 256, 2, 4>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Batched C_z = A_z . W_z^T (no epilogue): z = zo * nb_inner + zi, operand offsets zo * s?o + zi * s?i (elements).

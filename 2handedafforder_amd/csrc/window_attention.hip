@@ -125,8 +125,9 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
   // caller passes; checked on the host). Pad / tail slots re-read chunk 0 of a K row: they only have to be finite
   // (the matching Q columns are zero).
   unsigned slot_off[NDMA];
-  unsigned slot_pad[NDMA];   // [31:28] token row in window, [27:24] token column, [23:0] byte offset inside the pad row
+  unsigned slot_pad[NDMA];   // [31:28] token row in window, [27:24] token column, [23] V slot, [7:0] byte offset of the chunk inside the pad token's K / V row
   const long v_minus_k = (p.v - p.k);   // elements; same for every (window, head) because strides match
+  const unsigned vmk_bytes = (unsigned)(v_minus_k * 2);   // (< 4 GiB: checked on the host)
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
     const int sl = tid + i * C::NTHREADS;
@@ -142,7 +143,8 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
       const int sv = sl - C::KSLOTS;
       const int row = sv / C::CPR, c = sv - row * C::CPR;
       off = v_minus_k + (long)row * p.v_st + c * 8;
-      pad = ((unsigned)(row / S) << 28) | ((unsigned)(row % S) << 24) | (unsigned)(v_minus_k * 2 + c * 16);
+      pad = ((unsigned)(row / S) << 28) | ((unsigned)(row % S) << 24) | (1u << 23) | (unsigned)(c * 16);   // (+ v_minus_k at issue time: round 5's
+      //                                                  head-major planes put V hundreds of MB behind K, past any packed field)
     }
     slot_off[i] = (unsigned)(off * 2);
     slot_pad[i] = pad;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
       if (i < i0 || i >= i1) continue;
       const unsigned m0v = nx_lds0 + i * C::NTHREADS * 16;
       const bool is_pad = (int)(slot_pad[i] >> 28) >= nx_pad_h0 || (int)((slot_pad[i] >> 24) & 15u) >= nx_pad_w0;
-      const unsigned off = is_pad ? nx_pad_base + (slot_pad[i] & 0xffffffu) : slot_off[i];
+      const unsigned off = is_pad ? nx_pad_base + (slot_pad[i] & 0xffu) + ((slot_pad[i] >> 23) & 1u) * vmk_bytes : slot_off[i];
       if ((i + 1) * C::NTHREADS <= C::PAD_SLOTS || (i * C::NTHREADS + wave * 64) < C::PAD_SLOTS)   // wave-uniform
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(nx_kb), "s"(m0v)
                      : "memory");

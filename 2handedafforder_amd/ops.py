@@ -233,6 +233,32 @@ def linear(x, w, bias=None, act=ACT_NONE, resid=None, row_map=None, out=None, ou
     return out
 
 
+def linear_heads_supported(M, N, K, d, heads, dtype):
+    """Shapes haff_gemm_bf16_heads serves: whole 256 x 256 tiles of the 8-wave kernel, N = parts * heads * d."""
+    return (dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and d % 8 == 0 and N % (heads * d) == 0
+            and N // (heads * d) <= 3 and heads * d < (1 << 16) and M * K * 2 < (1 << 32) and N * K * 2 < (1 << 32))
+
+
+def linear_heads(x, w, bias, row_map, out, d, heads, part_stride, head_stride, ln_stats=None, ln_colsum=None):
+    """x @ w.T (+ folded norm) scattered HEAD-MAJOR into `out` (haff_gemm_bf16_heads): product column part * heads * d + h * d + c of
+    row m goes to out.flat[part * part_stride + h * head_stride + row_map[m] * d + c]."""
+    lib = load_library()
+    _req(x, "x")
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and out.is_contiguous()
+    assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and row_map.dtype == torch.int32 and row_map.numel() == M
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == N)
+    if ln_stats is not None:
+        assert ln_stats.dtype == torch.float32 and ln_stats.shape == (M, 2) and ln_stats.is_contiguous()
+    parts = N // (heads * d)
+    assert out.numel() >= (parts - 1) * part_stride + heads * head_stride   # (the row map's range is the caller's contract)
+    rc = lib.haff_gemm_bf16_heads(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), _p(bias), row_map.data_ptr(),
+                                  _p(ln_stats), _p(ln_colsum), M, N, K, d, heads, part_stride, head_stride, _stream())
+    check(rc, "haff_gemm_bf16_heads")
+    return out
+
+
 _LINEAR = linear   # the function itself: linear()'s own two-launch form must not go through a wrapper installed on ops.linear (bench.py's meter)
 
 

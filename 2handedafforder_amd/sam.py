@@ -71,6 +71,10 @@ class SamEncoderHip:
         self._maps = {}
         self.fold_norms = fold        # (see above; False = the LayerNorm kernels, needs no other change)
         self.compact_windows = True   # windowed blocks skip the padded window rows (bf16, ViT-H window geometry)
+        # ... and their q|k|v product scatters HEAD-MAJOR ([q|k|v][window][head][token][80]: haff_gemm_bf16_heads), so that an
+        # item's K and V are one contiguous 31 KB block each for the window kernel's staging DMA (round 5; token-major rows are
+        # 160-B pieces at a 7680-B stride). False: the token-major [window token][3 * C] buffer of rounds 1-4.
+        self.head_major_windows = True
         self.fused_global = True      # global blocks: rel-pos inside the attention kernel (bf16, ViT-H geometry); False = tables
         self.producer_stats = True    # folded norms: row statistics from the producing product's epilogue (batches whose proj /
         #                               lin2 run on the 8-wave tile anyway: >= 2 frames; "force": any); False = haff_row_stats
@@ -122,6 +126,37 @@ class SamEncoderHip:
             self._maps[key] = inv
         return self._maps[key]
 
+    def _head_major_window_map(self, B):
+        """image token row -> window * heads * n_tok + token-in-window (int32 [B*g*g]): the row part of the head-major q|k|v
+        scatter (ops.linear_heads), in units of one head's token row."""
+        key = ("hm", B)
+        if key not in self._maps:
+            inv = self._compact_window_map(B).long()
+            ntok = self.cfg.window * self.cfg.window
+            self._maps[key] = ((inv // ntok) * (self.cfg.heads * ntok) + inv % ntok).to(torch.int32)
+        return self._maps[key]
+
+    def _windowed_qkv(self, x, blk, B, st, folded):
+        """q, k, v views [windows, heads, tokens, d] of one windowed block's projection of the REAL tokens + the pad-token row index
+        the window kernel substitutes for padded window positions. Head-major planes when the shapes allow, else token-major."""
+        s = self.cfg
+        C, H, hd = s.embed_dim, s.heads, self.hd
+        _, nw2 = self._window_maps(B)
+        nb, ntok = B * nw2, s.window * s.window
+        w, bias = (blk["wqkv_f"], blk["bqkv_f"]) if folded else (blk["wqkv"], blk["bqkv"])
+        kw = dict(ln_stats=st, ln_colsum=blk["sqkv"]) if folded else {}
+        if self.head_major_windows and ops.linear_heads_supported(x.shape[0], 3 * C, C, hd, H, x.dtype):
+            part = (nb + 1) * H * ntok * hd
+            planes = torch.empty((3, nb + 1, H, ntok, hd), dtype=x.dtype, device=x.device)
+            ops.linear_heads(x, w, bias, self._head_major_window_map(B), planes, hd, H, part, ntok * hd, **kw)
+            planes[:, nb, :, 0, :].copy_(blk["bqkv"].view(3, H, hd))   # the pad token: qkv of a zero row = the bias
+            return planes[0, :nb], planes[1, :nb], planes[2, :nb], nb * H * ntok
+        qkv = torch.empty((nb * ntok + 1, 3 * C), dtype=x.dtype, device=x.device)
+        ops.linear(x, w, bias=bias, row_map=self._compact_window_map(B), out=qkv[:-1], **kw)
+        qkv[-1].copy_(blk["bqkv"])
+        q5 = qkv[:-1].view(nb, ntok, 3, H, hd)
+        return q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 1].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3), nb * ntok
+
     def patch_rows_from_nchw(self, images):
         s = self.cfg
         return ops.patchify_nchw(images, s.patch, s.grid, s.grid, 3 * s.patch * s.patch, self.dtype)
@@ -161,20 +196,12 @@ class SamEncoderHip:
                 _, nw2 = self._window_maps(B)
                 inv = self._compact_window_map(B)
                 nb, ntok, S = B * nw2, s.window * s.window, s.window
-                qkv = torch.empty((nb * ntok + 1, 3 * C), dtype=self.dtype, device=x.device)
                 if self.fold_norms:
-                    ops.linear(x, blk["wqkv_f"], bias=blk["bqkv_f"], row_map=inv, out=qkv[:-1],
-                               ln_stats=st if st is not None else ops.row_stats(x, 1e-6), ln_colsum=blk["sqkv"])
+                    q, k, v, pad = self._windowed_qkv(x, blk, B, st if st is not None else ops.row_stats(x, 1e-6), True)
                 else:
-                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6)
-                    ops.linear(xn, blk["wqkv"], bias=blk["bqkv"], row_map=inv, out=qkv[:-1])
-                qkv[-1].copy_(blk["bqkv"])
-                q5 = qkv[:-1].view(nb, ntok, 3, H, hd)
-                q = q5[:, :, 0].permute(0, 2, 1, 3)
-                k = q5[:, :, 1].permute(0, 2, 1, 3)
-                v = q5[:, :, 2].permute(0, 2, 1, 3)
-                a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=nb * ntok)
-                del qkv
+                    q, k, v, pad = self._windowed_qkv(ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6), blk, B, None, False)
+                a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=pad)
+                del q, k, v
                 if carry:
                     _, st = ops.linear_rowstats(a.view(nb * ntok, C), blk["wproj"], blk["bproj"], x, 1e-6, out=x, a_map=inv)
                 else:
@@ -245,14 +272,10 @@ class SamEncoderHip:
                 _, nw2 = self._window_maps(B)
                 inv = self._compact_window_map(B)
                 nb, ntok, S = B * nw2, s.window * s.window, s.window
-                qkv = torch.empty((nb * ntok + 1, 3 * C), dtype=bf, device=x.device)
                 xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, out_dtype=bf)
-                ops.linear(xn, blk["wqkv"], bias=blk["bqkv"], row_map=inv, out=qkv[:-1])
-                qkv[-1].copy_(blk["bqkv"])
-                q5 = qkv[:-1].view(nb, ntok, 3, H, hd)
-                a = ops.window_attention(q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 1].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3),
-                                         scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=nb * ntok)
-                del qkv
+                q, k, v, pad = self._windowed_qkv(xn, blk, B, None, False)
+                a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=pad)
+                del q, k, v
                 ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, a_map=inv, out=x)
             else:
                 if blk["global"]:

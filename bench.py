@@ -105,11 +105,25 @@ class GemmMeter:
             meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K, "qkv_rope", (M, N, K)))
             return q
         ops.rowstats_gemm, ops.qkv_rope = timed_rs, timed_qr
+        # round 5: the windowed q|k|v products scatter head-major (haff_gemm_bf16_heads): same tile kernel, same bookkeeping
+        self._orig_lh = ops.linear_heads
+
+        def timed_lh(x, w, bias, row_map, out, d, heads, part_stride, head_stride, ln_stats=None, ln_colsum=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = meter._orig_lh(x, w, bias, row_map, out, d, heads, part_stride, head_stride, ln_stats=ln_stats, ln_colsum=ln_colsum)
+            e1.record()
+            M, K, N = x.shape[0], x.shape[1], w.shape[0]
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K,
+                                  "ln_fold" if ln_stats is not None else "plain", (M, N, K)))
+            return r
+        ops.linear_heads = timed_lh
         return self
 
     def __exit__(self, *exc):
         ops.linear = self._orig
         ops.rowstats_gemm, ops.qkv_rope = self._orig_rs, self._orig_qr
+        ops.linear_heads = self._orig_lh
 
     def summary(self):
         """(launches, ms, flop, algorithmic bytes) of the MFMA tile kernel launches."""
@@ -857,6 +871,11 @@ def main(argv=None):
     ap.add_argument("--no-fold-norms", action="store_true", help="SAM blocks: LayerNorm kernels instead of the norm carried into the qkv / lin1 products (A/B)")
     ap.add_argument("--tables-global", action="store_true",
                     help="SAM global blocks: rel-pos as fp32 tables + the plain attention kernel instead of the fused kernel (A/B)")
+    ap.add_argument("--token-major-windows", action="store_true",
+                    help="SAM windowed blocks: the token-major q|k|v buffer of rounds 1-4 instead of head-major planes (A/B)")
+    ap.add_argument("--sam-beside-decode", default="auto", choices=["auto", "on", "off"],
+                    help="where the SAM encoder is enqueued on its stream: on = behind the prefill (beside the HBM-bound decode steps), "
+                         "off = first (beside CLIP + prefill), auto = by batch size (lisa.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: skip the one real end-to-end CPU frame (~31 GB host RAM, ~1 min)")
     ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
@@ -924,6 +943,10 @@ def main(argv=None):
         model.sam_encoder.producer_stats = False
     if args.no_fused_qkv_rope:
         model.llm.fused_qkv_rope = False
+    if args.token_major_windows:
+        model.sam_encoder.head_major_windows = False
+    if args.sam_beside_decode != "auto":
+        model.sam_beside_decode = args.sam_beside_decode == "on"
     del sd
     torch.cuda.empty_cache()
     B, S = args.batch, cfg.sam.img_size

@@ -69,6 +69,18 @@ int haff_gemm_bf16_gather(const void* A, long lda, const int* a_map, long a_rows
 int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                       const void* resid, long ldr, const int* row_map, const float* ln_stats, const float* ln_colsum,
                       int M, int N, int K, int act, int out_f32, int swiglu, void* stream);
+/* Product (optionally with a folded norm: ln_stats / ln_colsum as above, or both null) whose bf16 output is scattered HEAD-MAJOR:
+ * the windowed q|k|v projection of a ViT-H block (image_encoder.py:223-224 the qkv Linear, :263-288 window_partition, :238-239 the
+ * reshape into heads) writes q, k, v of every (window, head) as ONE contiguous [tokens][d] block, so the window attention's K / V
+ * staging reads whole 128-B lines. Product column n = part * (heads * d) + h * d + c of product row m is stored at
+ *   C[part * part_stride + h * head_stride + row_map[m] * d + c]      (bf16 elements; row_map[m] < 0 drops the row)
+ * i.e. with row_map[m] = window * heads * n_tok + token, head_stride = n_tok * d, part_stride = (windows + 1) * heads * n_tok * d,
+ * C is [part][window][head][token][d] with one spare window whose token 0 holds the pad token (the caller writes it).
+ * Whole 256 x 256 tiles only (M % 256 == 0, N % 256 == 0, K % 64 == 0), N == parts * heads * d with parts <= 3, d % 8 == 0;
+ * otherwise HAFF_ERR_UNSUPPORTED (-2): the caller keeps the token-major layout (haff_gemm_bf16_ln / haff_gemm_bf16 with a row map). */
+int haff_gemm_bf16_heads(const void* A, long lda, const void* W, long ldw, void* C, const float* bias, const int* row_map,
+                         const float* ln_stats, const float* ln_colsum, int M, int N, int K, int d, int heads, long part_stride,
+                         long head_stride, void* stream);
 /* Llama prefill q|k|v projection with rotate-half RoPE and the KV-cache append in the epilogue (transformers
  * LlamaAttention.forward via llava_llama.py:93-102) — replaces haff_gemm_bf16 + haff_rope_cache on prefill-sized batches.
  * A bf16 [B*T][K]; Wp bf16 [3*H*d][K]: the fused q|k|v weights with the rows of every 256-row tile permuted — natural tile row

@@ -269,6 +269,11 @@ def test_sam_vith_width_windowed_blocks(dev):
         taps_c, taps_p, taps_ref = {}, {}, {}
         enc.compact_windows = True
         out_c = enc(images.to(dev), taps_c).float().cpu()
+        assert enc.head_major_windows   # the default: q|k|v of the windowed blocks scattered head-major (haff_gemm_bf16_heads)
+        enc.head_major_windows = False
+        out_tm = enc(images.to(dev)).float().cpu()
+        enc.head_major_windows = True
+        assert torch.equal(out_c, out_tm), "head-major q|k|v planes must be a pure re-layout of the token-major buffer"
         enc.compact_windows = False
         out_p = enc(images.to(dev), taps_p).float().cpu()
         ref = O.sam_image_encoder(sd, V + ".image_encoder", images, cfg.sam, taps_ref)

@@ -921,6 +921,39 @@ def test_norms(dev, C, dtype):
     assert (got[m < 0] == 0).all()
 
 
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("M,K,H,d", [(512, 128, 16, 80), (1024, 1280, 16, 80), (256, 64, 4, 64)])
+def test_linear_heads_scatter(dev, M, K, H, d, fold):
+    """haff_gemm_bf16_heads: the product's columns part * H * d + h * d + c of row m land at planes[part][w][h][t][c] with
+    row_map[m] = w * H * n_tok + t — bit-identical to the token-major product (same kernel, other store addresses), dropped rows
+    (-1) and unaddressed slots untouched."""
+    ops = _ops()
+    ntok = 196
+    nwin = (M + ntok - 1) // ntok + 1
+    N = 3 * H * d
+    x = _rand((M, K), dev, torch.bfloat16, 70)
+    w = _rand((N, K), dev, torch.bfloat16, 71, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 72)
+    g = torch.Generator().manual_seed(73)
+    slots = torch.randperm(nwin * ntok, generator=g)[:M]
+    keep = torch.rand((M,), generator=g) > 0.1
+    rmap = torch.where(keep, (slots // ntok) * (H * ntok) + slots % ntok, torch.full((M,), -1)).to(torch.int32).to(dev)
+    kw = {}
+    if fold:
+        kw = dict(ln_stats=torch.stack([_rand((M,), dev, torch.float32, 74), _rand((M,), dev, torch.float32, 75).abs() + 0.5], 1).contiguous(),
+                  ln_colsum=_rand((N,), dev, torch.float32, 76))
+    assert ops.linear_heads_supported(M, N, K, d, H, torch.bfloat16)
+    planes = torch.full((3, nwin + 1, H, ntok, d), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.linear_heads(x, w, bias, rmap, planes, d, H, (nwin + 1) * H * ntok * d, ntok * d, **kw)
+    ref = ops.linear(x, w, bias=bias, tile_cfg=0 if fold else 2, **kw).view(M, 3, H, d)
+    exp = torch.full_like(planes, 7.0)
+    mk = keep.to(dev)
+    wi, ti = (slots // ntok).to(dev)[mk], (slots % ntok).to(dev)[mk]
+    for part in range(3):
+        exp[part, wi, :, ti] = ref[mk, part]
+    assert torch.equal(planes, exp)
+
+
 @pytest.mark.parametrize("C,R", [(1280, 77), (1280, 8203), (4096, 5), (4096, 600), (5120, 3)])
 def test_norms_f32_rows_to_bf16(dev, C, R):
     """dtype 2 of haff_layernorm / haff_rmsnorm: an fp32 residual stream normalised in fp32 and rounded to bf16 ONCE — bit-equal

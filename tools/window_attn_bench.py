@@ -45,7 +45,23 @@ def main():
         rh, rw = ops.relpos_tables(q, th, tw, S)
         ops.attention(q, k, v, scale, relh=rh, relw=rw, S=S, out=out)
 
+    # round 5: the same items with q, k, v as HEAD-MAJOR planes [3][window][head][token][d] (what haff_gemm_bf16_heads writes): an
+    # item's K and V are one contiguous 31 KB block each instead of 196 pieces of 160 B at a 7680-B stride
+    planes = torch.empty((3, n_win + 1, H, N, d), dtype=torch.bfloat16, device=dev)
+    for i in range(3):
+        planes[i, :n_win] = q5[:, :, i].permute(0, 2, 1, 3)
+    out_hm = torch.empty_like(out)
+
+    def fused_hm():
+        ops.window_attention(planes[0, :n_win], planes[1, :n_win], planes[2, :n_win], scale, th, tw, S, out=out_hm)
+
+    c = t_us(fused_hm)
+    fused()
+    torch.cuda.synchronize()
+    same = torch.equal(out, out_hm)
     a, b = t_us(fused), t_us(generic)
+    print(f"windows {n_win} heads {H}: head-major planes {c:8.1f} us ({(qkv.numel() * 2 + out.numel() * 2) / c / 1e6:6.2f} TB/s algorithmic), "
+          f"bit-identical to token-major: {same}", flush=True)
     byts = qkv.numel() * 2 + out.numel() * 2
     fl = 4.0 * N * N * d * H * n_win
     print(f"windows {n_win} heads {H}: fused {a:8.1f} us ({byts / a / 1e6:6.2f} TB/s algorithmic, {fl / a / 1e6:6.0f} TF/s) | "
