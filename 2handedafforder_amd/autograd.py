@@ -30,6 +30,8 @@ def scale_dev(a, alpha, per_row=False):
     a torch multiply would first round the 0-dim upstream gradient to a's dtype (bf16)."""
     lib = load_library()
     a = a.contiguous()
+    if a.numel() == 0:   # empty in, empty out (the torch multiply this replaced accepted it; the kernel entry refuses cols = 0)
+        return a.clone()
     alpha = alpha.detach().to(torch.float32).contiguous()
     rows, cols = (a.shape[0], a.numel() // a.shape[0]) if per_row else (1, a.numel())
     assert alpha.numel() == (rows if per_row else 1) and alpha.device == a.device
@@ -123,6 +125,8 @@ def colsum(x2d):
     lib = load_library()
     x2d = x2d.contiguous()
     R, C = x2d.shape
+    if R == 0 or C == 0:   # no rows: the sums are zero (the kernel entries refuse empty inputs)
+        return torch.zeros((C,), dtype=torch.float32, device=x2d.device)
     if not ORDERED_REDUCTIONS:
         out = torch.zeros((C,), dtype=torch.float32, device=x2d.device)
         check(lib.haff_colsum(x2d.data_ptr(), out.data_ptr(), R, C, _dt(x2d), _s()), "haff_colsum")
@@ -682,15 +686,24 @@ class MaskLossFn(Function):
         x, t = x.contiguous(), t.contiguous()
         n, hw = x.shape
         stats = torch.zeros((n, 4), dtype=torch.float32, device=x.device)
+        if n == 0 or hw == 0:
+            ctx.save_for_backward(x, t, stats)
+            ctx.wgts = []
+            return torch.zeros((n, 2), dtype=torch.float32, device=x.device)
         if ORDERED_REDUCTIONS:
             import ctypes
-            partials = torch.empty((n, 256, 4), dtype=torch.float32, device=x.device)
+            # Layout (one convention, stated once — ADVICE r4): the kernel entry writes partials [n_samples][*n_parts][4] for ITS
+            # launch. Here every sample is its own launch (n_samples = 1: the per-sample weight is a host scalar), writing the first
+            # n_parts rows of its own SLOTS-row slab partials[i]; the reduce walks sample i's parts at group stride SLOTS * 4.
+            SLOTS = 256
+            partials = torch.empty((n, SLOTS, 4), dtype=torch.float32, device=x.device)
             n_parts = ctypes.c_int(0)
             for i in range(n):  # per-sample weight is a host scalar (taxonomy one-hot sums)
                 check(lib.haff_mask_loss_stats_partials(x[i].data_ptr(), t[i].data_ptr(), partials[i].data_ptr(), 1, hw, float(wgts[i]),
                                                         ctypes.byref(n_parts), _s()), "haff_mask_loss_stats_partials")
+                assert 0 < n_parts.value <= SLOTS, n_parts.value
             # stats[i][k] = sum over the parts of sample i, in index order (one launch for all samples)
-            _reduce_partials(partials, stats, 4 * n, n_parts.value, 4, 4, 256 * 4, False)
+            _reduce_partials(partials, stats, 4 * n, n_parts.value, 4, 4, SLOTS * 4, False)
         else:
             for i in range(n):
                 check(lib.haff_mask_loss_stats(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), 1, hw, float(wgts[i]), _s()),
@@ -711,6 +724,8 @@ class MaskLossFn(Function):
         n, hw = x.shape
         coef = g.to(torch.float32).contiguous()   # [n, 2] upstream gradients of {bce, dice}: read by the kernel, not by the host
         dx = torch.empty_like(x)
+        if n == 0 or hw == 0:
+            return dx, None, None
         for i in range(n):
             check(lib.haff_mask_loss_grad_dev(x[i].data_ptr(), t[i].data_ptr(), stats[i].data_ptr(), dx[i].data_ptr(), 1, hw,
                                               ctx.wgts[i], coef[i].data_ptr(), _s()), "haff_mask_loss_grad_dev")

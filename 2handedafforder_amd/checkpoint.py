@@ -64,21 +64,30 @@ def sentencepiece_vocab_size(path):
     fn = os.path.join(path, "tokenizer.model")
     if not os.path.exists(fn):
         return None
-    import sentencepiece as spm
+    try:
+        import sentencepiece as spm
+    except ImportError as e:   # name the dependency: the file is there, the package that reads it is not
+        raise ImportError(f"{fn} is a sentencepiece model: reading the base vocabulary size needs the `sentencepiece` package "
+                          "(pip install sentencepiece), or put an added_tokens.json beside it") from e
     sp = spm.SentencePieceProcessor()
     sp.Load(fn)
     return int(sp.GetPieceSize())
 
 
-def resolve_added_tokens(path, rows):
+def resolve_added_tokens(path, rows, layout_asserted=False):
     """Ids of [SEG] / <im_start> / <im_end> for a checkpoint directory whose embedding has `rows` rows (LisaMI355.from_pretrained
-    documents the order of authority); ValueError when they cannot be told."""
+    documents the order of authority); ValueError when they cannot be told. Without tokenizer files, "the last three rows" is
+    taken only where something SAYS the three rows are there: rows == config.json's vocab_size + 3, or rows == vocab_size in a
+    directory this repo wrote (config.json carries haff_vocab_includes_added_tokens: merge_lora.py) or whose caller passed an
+    explicit seg_token_idx (layout_asserted) — a plain base-Llama directory without tokenizer files is refused."""
     ids = added_token_ids(path)
     if ids is None:
         base = sentencepiece_vocab_size(path)
         with open(os.path.join(path, "config.json")) as f:
-            n_cfg = int(json.load(f).get("vocab_size", rows))
-        if (base is not None and rows == base + 3) or (base is None and rows in (n_cfg, n_cfg + 3)):
+            cj = json.load(f)
+        n_cfg = int(cj.get("vocab_size", rows))
+        counted = bool(cj.get("haff_vocab_includes_added_tokens", False)) or layout_asserted
+        if (base is not None and rows == base + 3) or (base is None and (rows == n_cfg + 3 or (rows == n_cfg and counted))):
             ids = {"[SEG]": rows - 3, "<im_start>": rows - 2, "<im_end>": rows - 1}
         else:
             raise ValueError(f"{path}: embed_tokens has {rows} rows, config.json says vocab_size {n_cfg}, the tokenizer's base "

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
   constexpr bool PP = (WM * WN == 8);   // the 8-wave tile runs the persistent ping-pong ring loop
   constexpr bool SPEC = (FLAGS & GF_SPEC) != 0;
   constexpr bool MFULL = SPEC && !(FLAGS & GF_RAGM);   // every M-tile is whole
-  static_assert(!SPEC || (PP && BM == 256 && !OUT_F32), "specialised epilogues exist for the bf16 256 x 256 tile");
+  static_assert(!SPEC || (PP && !OUT_F32 && (BM == 256 || !(FLAGS & (GF_LN | GF_MAP)))),
+                "specialised epilogues exist for the bf16 8-wave tiles (the 192-row form without the norm fold / row map, whose staging is 256 rows wide)");
   // feature tests: compile-time constants in a specialised instance, the argument block's pointers otherwise
   const bool has_bias = SPEC ? (FLAGS & GF_BIAS) != 0 : p.bias != nullptr;
   const bool has_ln = SPEC ? (FLAGS & GF_LN) != 0 : p.ln_stats != nullptr;
@@ -1739,6 +1740,26 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
       HAFF_SPEC(GF_BIAS | GF_RES | GF_RAGM, false)
       HAFF_SPEC(GF_BIAS | QGELU_ | GF_RAGM, false)
 #undef HAFF_SPEC
+    }
+  }
+  if constexpr (BM == 192 && BN == 256 && WM * WN == 8) {   // the fine-tune step's 2808-row products (forward, dX): plain / residual / SwiGLU
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool ok = nbatch == 1 && p.nb_inner == 0 && !p.out_f32 && (p.N % 256) == 0 && a16(p.C) && (p.ldc & 7) == 0 && a16(p.bias) &&
+                    a16(p.resid) && (!p.resid || (p.ldr & 7) == 0) && !p.ln_stats && !p.ln_colsum && !p.row_map && !p.stat_out && !p.hm_d &&
+                    !p.rope_cs && p.act == 0;
+    if (ok && haff_gemm_spec_enabled()) {
+      const unsigned f = (p.bias ? GF_BIAS : 0u) | (p.resid ? GF_RES : 0u);
+#define HAFF_SPEC192(FL, SW)                                                                                               \
+  if (f == ((FL) & ~(GF_SPEC | GF_RAGM)) && (p.swiglu != 0) == (SW)) {                                                       \
+    hipLaunchKernelGGL((gemm_bf16_kernel<192, 256, 2, 4, false, SW, (FL) | GF_SPEC | GF_RAGM>), grid, block, 0, s, pl);     \
+    return haff_check_launch();                                                                                             \
+  }
+      HAFF_SPEC192(0u, false)
+      HAFF_SPEC192(GF_RES, false)
+      HAFF_SPEC192(0u, true)
+      HAFF_SPEC192(GF_BIAS, false)
+      HAFF_SPEC192(GF_BIAS | GF_RES, false)
+#undef HAFF_SPEC192
     }
   }
   if (p.swiglu) {

@@ -351,6 +351,10 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
       // groups of 7 key tiles, k-step outer inside a group: 7 independent accumulators between two uses of the
       // same one, 7 K fragments in flight
       constexpr int KG = (S + 1) / 2;
+      // the zero-padded last k-step (d = 80: columns 64..95) would read 32 bytes PAST an unpadded row for fh >= 2 — the next key's
+      // first chunks, or V behind the last K row: finite only if the neighbour is (Inf / NaN x a zero Q column = NaN in ANOTHER
+      // key's score). Those lanes re-read the row's own last chunk instead (the global kernel's k_lane2 does the same).
+      const int koff_last = min(fh * 16 + (C::NKD - 1) * 64, D * 2 - 16);
 #pragma unroll
       for (int g0 = 0; g0 < S; g0 += KG) {
 #pragma unroll
@@ -358,7 +362,7 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
 #pragma unroll
           for (int kt = g0; kt < g0 + KG && kt < S; ++kt) {
             // A operand row = key (kh = kt, kw = fr)
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * S + qcol) * C::KSTR + fh * 16 + kd * 64);
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * S + qcol) * C::KSTR + (kd == C::NKD - 1 ? koff_last : fh * 16 + kd * 64));
             sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qs[kd], sacc[kt], 0, 0, 0);
           }
         }

@@ -328,8 +328,10 @@ class LisaMI355:
         # Where the encoder is enqueued. Throughput batches: first, so its GEMMs run beside the CLIP tower and the prefill.
         # A few frames (latency): behind the prefill, so it runs beside the HBM-bound decode steps, which leave the matrix
         # cores idle, instead of time-slicing them with the prefill (and the host enqueues it while the prefill runs).
+        # (round 5, bench.py --sam-beside-decode on / off at 8 and 16 frames: behind the prefill is +0.4 ... +1.8 % for 7B and 13B there
+        # too; at 64 frames the encoder is 60 % of the step and has to start first)
         late = self.overlap_streams and self.sam_beside_decode is not False and \
-            (self.sam_beside_decode is True or input_ids.shape[0] <= 4)
+            (self.sam_beside_decode is True or input_ids.shape[0] <= 16)
         if not late:
             launch_sam()
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask,
@@ -427,7 +429,7 @@ class LisaMI355:
         # without the added rows, a vocabulary padded to a multiple of 64 — is refused instead of silently reading ordinary or
         # padding rows as [SEG]. An explicit seg_token_idx is kept as given.
         rows = sd["model.embed_tokens.weight"].shape[0]
-        ids = checkpoint.resolve_added_tokens(pretrained_model_name_or_path, rows)
+        ids = checkpoint.resolve_added_tokens(pretrained_model_name_or_path, rows, layout_asserted=seg_token_idx is not None)
         cfg.llm.vocab = rows
         cfg.im_start_idx, cfg.im_end_idx = int(ids["<im_start>"]), int(ids["<im_end>"])
         if seg_token_idx is None:

@@ -692,14 +692,27 @@ def cpu_train_baseline(cfg, n_ids, mask_hw, threads):
         t = time.perf_counter(); O.sam_block(sd, V + ".image_encoder.blocks.7", x, s.heads, 0); t_glob = time.perf_counter() - t
     n_glob = len(cfg.sam.global_idx)
     extra_sam = (cfg.sam.depth - n_glob - 1) * t_win + (n_glob - 1) * t_glob
-    t_full = (f1 + b1) + (cfg.llm.layers - 1) * per_llm + extra_sam
+    # the frozen CLIP tower too: the reduced model ran 2 of its layers (forward only), the full one runs select_layer's count
+    c2 = copy.deepcopy(cfg.clip)
+    c2.layers, c2.select_layer = 2, 2
+    c1 = copy.deepcopy(c2)
+    c1.select_layer = 1
+    sdc = hw.make_state_dict(copy.deepcopy(cfg), 97, {k: v for k, v in hw.clip_shapes(c2).items()})
+    ic = torch.randn((1, 3, cfg.clip.image, cfg.clip.image), generator=g)
+    with torch.no_grad():
+        t = time.perf_counter(); O.clip_vision_features(sdc, "model.vision_tower.vision_tower", ic, c2); t_c2 = time.perf_counter() - t
+        t = time.perf_counter(); O.clip_vision_features(sdc, "model.vision_tower.vision_tower", ic, c1); t_c1 = time.perf_counter() - t
+    t_clip_layer = max(t_c2 - t_c1, 0.0)
+    n_clip = cfg.clip.layers + 1 + cfg.clip.select_layer if cfg.clip.select_layer < 0 else cfg.clip.select_layer
+    extra_clip = max(n_clip - 2, 0) * t_clip_layer
+    t_full = (f1 + b1) + (cfg.llm.layers - 1) * per_llm + extra_sam + extra_clip
     return {"value": 1.0 / t_full, "unit": "samples/s", "cores": threads, "kind": "port", "extrapolated": True,
             "sample": ("CPU oracle (oracle/lisa_oracle.py under torch autograd, fp32) — ONE sample, %d-id conversation, %dx%d masks, full "
                        "width, reduced depth: measured forward + backward with 1 and 2 Llama layers (2 ViT-H blocks, 2 CLIP layers), "
-                       "full depth = that + (layers - 1) x the difference + the remaining frozen ViT-H blocks forward" %
+                       "full depth = that + (layers - 1) x the difference + the remaining frozen ViT-H blocks and CLIP layers forward" %
                        (n_ids, mask_hw[0], mask_hw[1])),
             "measured_s": {"fwd_1_layer": f1, "bwd_1_layer": b1, "fwd_2_layers": f2, "bwd_2_layers": b2, "vit_h_window_block_fwd": t_win,
-                           "vit_h_global_block_fwd": t_glob},
+                           "vit_h_global_block_fwd": t_glob, "clip_layer_fwd": t_clip_layer},
             "seconds_per_sample_full_depth_extrapolated": t_full, "loss_of_the_reduced_model": loss}
 
 
@@ -757,9 +770,16 @@ def train_main(args):
     host_enqueue_ms = 1e3 * (time.time() - t_host)
     torch.cuda.synchronize()
     if rank == 0:
+        # per-launch event timing needs ONE HIP stream: with the frozen SAM encoder on its side stream the main stream's products
+        # were timed while they waited for CUs the encoder's persistent tiles held (round 4's by_shape listed the CLIP products at
+        # M = 2056 at 52 ... 211 TFLOP/s for that reason: single-stream they run at what the inference line shows)
+        overlap_prev, model.overlap_sam = model.overlap_sam, False
+        step()
+        torch.cuda.synchronize()
         with GemmMeter() as meter:
             step()
         torch.cuda.synchronize()
+        model.overlap_sam = overlap_prev
         n_launch, gemm_ms, gemm_fl, gemm_bytes = meter.summary()
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         n_train = sum(p.numel() for _, p in named)

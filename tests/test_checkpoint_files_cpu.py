@@ -163,7 +163,14 @@ def test_added_token_ids_come_from_the_tokenizer_files(tmp_path):
     (d / "config.json").write_text(json.dumps({"vocab_size": 32000, "hidden_size": 4096}))
     # no tokenizer files: the synthetic directories of this repo
     assert checkpoint.resolve_added_tokens(str(d), 32003) == {"[SEG]": 32000, "<im_start>": 32001, "<im_end>": 32002}
-    assert checkpoint.resolve_added_tokens(str(d), 32000)["[SEG]"] == 31997      # vocab_size already counts them
+    # rows == vocab_size: only where something says the three rows are counted in it — this repo's marker in config.json
+    # (merge_lora.py) or a caller that passed seg_token_idx; a plain base-Llama directory is refused
+    with pytest.raises(ValueError, match="cannot tell"):
+        checkpoint.resolve_added_tokens(str(d), 32000)
+    assert checkpoint.resolve_added_tokens(str(d), 32000, layout_asserted=True)["[SEG]"] == 31997
+    (d / "config.json").write_text(json.dumps({"vocab_size": 32000, "hidden_size": 4096, "haff_vocab_includes_added_tokens": True}))
+    assert checkpoint.resolve_added_tokens(str(d), 32000)["[SEG]"] == 31997
+    (d / "config.json").write_text(json.dumps({"vocab_size": 32000, "hidden_size": 4096}))
     with pytest.raises(ValueError):
         checkpoint.resolve_added_tokens(str(d), 32064)
     # a sentencepiece model: base + 3 or nothing

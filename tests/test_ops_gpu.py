@@ -205,6 +205,48 @@ def test_gemm_bf16_192_row_tile(dev, M, N, K):
     _close(ops.linear(x, w, bias=bias, a_map=a_map), x.float()[a_map.long()] @ w.float().T + bias, 1.2e-2, "192-row tile gather")
 
 
+@pytest.mark.parametrize("M,N,K", [(2808, 4096, 4096), (1500, 1280, 1280), (401, 512, 128)])
+def test_gemm_bf16_192_row_tile_row_maps(dev, M, N, K):
+    """the 192 x 256 tile is picked by the launcher for any launch without a folded norm, i.e. also with an output row
+    map (the non-DMA map path: both DMA stagings are 256 rows wide and compiled out for this tile), the half-filled second
+    orow slot of its 96-row wave tile, dropped rows (-1) and a ragged last M-tile (M % 192 != 0), with and without a residual,
+    with the activations, and with the A-side gather. Each against the 128 x 128 tile (bit for bit: same k order) and fp32.
+    (RoPE and the row statistics have entry points of their own that launch the 256-row tile only.)"""
+    ops = _ops()
+    x = _rand((M, K), dev, torch.bfloat16, 81)
+    w = _rand((N, K), dev, torch.bfloat16, 82, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 83)
+    g = torch.Generator().manual_seed(84)
+    rows_out = M + 37
+    perm = torch.randperm(rows_out, generator=g)[:M]
+    drop = torch.rand((M,), generator=g) < 0.07
+    rmap = torch.where(drop, torch.full((M,), -1), perm).to(torch.int32).to(dev)
+    resid = _rand((rows_out, N), dev, torch.bfloat16, 85)
+    y = x.float() @ w.float().T + bias
+    keep = (~drop).to(dev)
+    for act in (0, 1, 3):
+        for use_res in (False, True):
+            outs = []
+            for cfg_id in (3, 1):
+                out = torch.full((rows_out, N), 5.0, dtype=torch.bfloat16, device=dev)
+                ops.linear(x, w, bias=bias, act=act, resid=resid if use_res else None, row_map=rmap, out=out, tile_cfg=cfg_id)
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), f"192-row tile with a row map differs from the 128 x 128 tile (act {act}, resid {use_res})"
+            exp = torch.full((rows_out, N), 5.0, device=dev)
+            exp[rmap[keep].long()] = ACT_REF[act](y)[keep] + (resid.float()[rmap[keep].long()] if use_res else 0.0)
+            _close(outs[0], exp, 1.2e-2, f"192-row tile, row map, act {act}, resid {use_res}")
+    out32 = torch.full((rows_out, N), 5.0, dtype=torch.float32, device=dev)
+    ops.linear(x, w, bias=bias, row_map=rmap, out=out32, tile_cfg=3)
+    exp = torch.full((rows_out, N), 5.0, device=dev)
+    exp[rmap[keep].long()] = y[keep]
+    _close(out32, exp, 2e-3, "192-row tile, row map, f32 out")
+    a_map = torch.randint(0, M, (M,), device=dev).to(torch.int32)
+    got = ops.linear(x, w, bias=bias, a_map=a_map, row_map=rmap, out=torch.full((rows_out, N), 5.0, dtype=torch.bfloat16, device=dev))
+    exp = torch.full((rows_out, N), 5.0, device=dev)
+    exp[rmap[keep].long()] = (x.float()[a_map.long()] @ w.float().T + bias)[keep]
+    _close(got, exp, 1.2e-2, "gather + row map (auto tile)")
+
+
 @pytest.mark.parametrize("M", [1, 3, 8, 16, 17, 31, 32, 33, 50, 64])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 11008), (5120, 13824), (1003, 256), (320, 11008), (64, 128), (998, 384)])
 def test_gemm_skinny(dev, M, N, K):

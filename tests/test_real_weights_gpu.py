@@ -143,6 +143,12 @@ def test_from_pretrained_on_files_written_by_transformers_matches_the_oracle(dev
     c["haff_geometry"] = {"name": cfg.name, "sam": {k: getattr(cfg.sam, k) for k in ("img_size", "patch", "embed_dim", "depth", "heads", "window", "global_idx")},
                           "clip": {k: getattr(cfg.clip, k) for k in ("image", "patch", "hidden", "layers", "heads", "mlp")}}
     json.dump(c, open(d / "config.json", "w"))       # (vocab_size stays what transformers wrote: 323, no modulo-3 hint)
+    # without tokenizer files nothing says that the 323 rows include the three added tokens: refused ...
+    with pytest.raises(ValueError, match="cannot tell"):
+        lisa.LisaMI355.from_pretrained(str(d), vision_tower=os.path.join(gold, "hf_clip_tiny"), torch_dtype=torch.float32, device=dev)
+    # ... the reference's merge script saves the tokenizer beside the weights (merge_lora_weights_and_save_hf_model.py:155):
+    # added_tokens.json, as HF's tokenizer.save_pretrained writes it, is the authority
+    json.dump({"[SEG]": cfg.seg_token_idx, "<im_start>": cfg.im_start_idx, "<im_end>": cfg.im_end_idx}, open(d / "added_tokens.json", "w"))
     model = lisa.LisaMI355.from_pretrained(str(d), vision_tower=os.path.join(gold, "hf_clip_tiny"), torch_dtype=torch.float32, device=dev)
     assert model.cfg.llm.vocab == cfg.llm.vocab and model.cfg.seg_token_idx == cfg.seg_token_idx
     rng = np.random.default_rng(3)
