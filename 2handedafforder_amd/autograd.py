@@ -513,7 +513,15 @@ class LoraQKVRopeFn(Function):
         dev = x.device
         x = x.contiguous()
         qkv = ops.linear(x, wqkv)
-        xd = x if keep is None else _mul(x, keep)
+        # keep: None, ONE mask for both adapters (rounds 3-4), or a pair (keep_q, keep_v) — peft gives each adapted Linear its own
+        # lora_dropout module (train_ds.py:218-230), i.e. q_proj's and v_proj's adapters see independently dropped inputs
+        two = isinstance(keep, (tuple, list))
+        if two:
+            keep_q, keep_v = keep
+            xd, xdv = _mul(x, keep_q), _mul(x, keep_v)
+        else:
+            xd = x if keep is None else _mul(x, keep)
+            xdv = None
         if r == 8:   # the default rank: no padding, one launch each
             a2, b2 = torch.cat([aq, av], 0), torch.stack([bq, bv], 0)
         else:
@@ -525,19 +533,28 @@ class LoraQKVRopeFn(Function):
             b2[1, :, :r] = bv
         Mp = (M + 15) // 16 * 16
         tT = (torch.empty if Mp == M else torch.zeros)((16, Mp), dtype=x.dtype, device=dev)   # pad columns stay finite (zero)
-        ops.linear(a2, xd, out=tT[:, :M])
+        if two:   # the q adapter's rank rows from x * keep_q, the v adapter's from x * keep_v
+            ops.linear(a2[0:8], xd, out=tT[0:8, :M])
+            ops.linear(a2[8:16], xdv, out=tT[8:16, :M])
+        else:
+            ops.linear(a2, xd, out=tT[:, :M])
         q, k, v = (torch.empty((M, H), dtype=x.dtype, device=dev) for _ in range(3))
         check(lib.haff_lora_qkv_rope_fwd(qkv.data_ptr(), qkv.stride(0), tT.data_ptr(), Mp, b2[0].data_ptr(), b2[1].data_ptr(), 8,
                                          cos_sin.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), H, M, H, d, int(T),
                                          float(scale_), _s()), "haff_lora_qkv_rope_fwd")
-        ctx.save_for_backward(xd, wqkv_t, a2, b2, tT, cos_sin, keep if keep is not None else torch.empty(0, device=dev))
+        none = torch.empty(0, device=dev)
+        if two:
+            ctx.save_for_backward(xd, wqkv_t, a2, b2, tT, cos_sin, keep_q, xdv, keep_v)
+        else:
+            ctx.save_for_backward(xd, wqkv_t, a2, b2, tT, cos_sin, keep if keep is not None else none, none, none)
         ctx.cfg = (int(T), heads, float(scale_), r)
         return q, k, v
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
         lib = load_library()
-        xd, wqkv_t, a2, b2, tT, cos_sin, keep = ctx.saved_tensors
+        xd, wqkv_t, a2, b2, tT, cos_sin, keep, xdv, keep_v = ctx.saved_tensors
+        two = xdv.numel() > 0
         T, heads, scale_, r = ctx.cfg
         M, K = xd.shape
         H = b2.shape[1]
@@ -565,12 +582,21 @@ class LoraQKVRopeFn(Function):
 
         dbq = tn(tT[0:8], 8, dqkv[:, :H], H, torch.empty((H, r), dtype=dt_, device=dev), True, r)
         dbv = tn(tT[8:16], 8, dqkv[:, 2 * H:], H, torch.empty((H, r), dtype=dt_, device=dev), True, r)
-        da2 = tn(dtT, 16, xd, K, torch.empty((16, K), dtype=dt_, device=dev), False, 16)
+        if two:   # each adapter's dA against ITS dropped input
+            da2 = torch.empty((16, K), dtype=dt_, device=dev)
+            tn(dtT[0:8], 8, xd, K, da2[0:8], False, 8)
+            tn(dtT[8:16], 8, xdv, K, da2[8:16], False, 8)
+        else:
+            da2 = tn(dtT, 16, xd, K, torch.empty((16, K), dtype=dt_, device=dev), False, 16)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear(dqkv, wqkv_t)
-            check(lib.haff_lora_dx(dtT.data_ptr(), Mp, a2.data_ptr(), K, keep.data_ptr() if keep.numel() else 0, K, dx.data_ptr(),
-                                   dx.stride(0), 1, M, K, scale_, _s()), "haff_lora_dx")
+            if two:   # dx += s * (keep_q o (dt_q . Aq) + keep_v o (dt_v . Av)) in one pass
+                check(lib.haff_lora_dx2(dtT.data_ptr(), Mp, a2.data_ptr(), K, keep.data_ptr(), keep_v.data_ptr(), K, dx.data_ptr(),
+                                        dx.stride(0), 1, M, K, scale_, _s()), "haff_lora_dx2")
+            else:
+                check(lib.haff_lora_dx(dtT.data_ptr(), Mp, a2.data_ptr(), K, keep.data_ptr() if keep.numel() else 0, K, dx.data_ptr(),
+                                       dx.stride(0), 1, M, K, scale_, _s()), "haff_lora_dx")
         return dx, None, None, da2[0:r], dbq, da2[8:8 + r], dbv, None, None, None, None, None
 
 

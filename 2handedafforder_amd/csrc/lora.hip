@@ -148,6 +148,7 @@ struct LoraDxArgs {
   const bf16_t* keep; long ldk;
   bf16_t* dx; long ldx;
   long M; int K; int accumulate; float scale;
+  const bf16_t* keep_v;   // two masks (haff_lora_dx2): `keep` gates the q adapter's ranks (rows 0-7 of A2), keep_v the v adapter's (8-15)
 };
 __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxArgs p) {   // column operands permuted as in the forward kernel
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -173,21 +174,37 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxArgs p) {   // colum
     const bf16x8 tt = load_t_frag(p.dtT, p.ldt, rc, fh);
     bf16_t* dst = p.dx + rc * p.ldx + c0 + 8 * fh;
     const bf16_t* kpr = p.keep ? p.keep + rc * p.ldk + c0 + 8 * fh : nullptr;
+    const bf16_t* kvr = p.keep_v ? p.keep_v + rc * p.ldk + c0 + 8 * fh : nullptr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float old[8], kp[8];
+      float old[8], kp[8], kv[8];
       if (p.accumulate) load8(dst + 32 * g, old);
       if (kpr) load8(kpr + 32 * g, kp);
+      if (kvr) load8(kvr + 32 * g, kv);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       f32x4 d[2];
-      d[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g][0], tt, z, 0, 0, 0);
-      d[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g][1], tt, z, 0, 0, 0);
       float v[8];
+      if (kvr) {   // (wave-uniform) two masks: the q adapter's ranks sit in the fh = 0 lanes of the A fragment, the v adapter's in fh = 1
+        const bf16x8 zf = zero_frag();
+        f32x4 dv[2];
+        d[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh == 0 ? af[g][0] : zf, tt, z, 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh == 0 ? af[g][1] : zf, tt, z, 0, 0, 0);
+        dv[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh == 1 ? af[g][0] : zf, tt, z, 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh == 1 ? af[g][1] : zf, tt, z, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = p.scale * d[e >> 2][e & 3];
-        if (kpr) v[e] *= kp[e];
-        if (p.accumulate) v[e] += old[e];
+        for (int e = 0; e < 8; ++e) {
+          v[e] = p.scale * (d[e >> 2][e & 3] * kp[e] + dv[e >> 2][e & 3] * kv[e]);
+          if (p.accumulate) v[e] += old[e];
+        }
+      } else {
+        d[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g][0], tt, z, 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g][1], tt, z, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = p.scale * d[e >> 2][e & 3];
+          if (kpr) v[e] *= kp[e];
+          if (p.accumulate) v[e] += old[e];
+        }
       }
       if (valid) store8(dst + 32 * g, v);
     }
@@ -312,13 +329,14 @@ extern "C" int haff_lora_qkv_rope_bwd(const void* dq, const void* dk, const void
   return check_launch();
 }
 
-extern "C" int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda, const void* keep, long ldk, void* dx, long ldx,
-                            int accumulate, long M, int K, float scale, void* stream) {
-  if (M <= 0 || K <= 0 || !dtT || !A2 || !dx) return HAFF_ERR_BAD_ARG;
+static int lora_dx_launch(const void* dtT, long ldt, const void* A2, long lda, const void* keep, const void* keep_v, long ldk, void* dx,
+                          long ldx, int accumulate, long M, int K, float scale, void* stream) {
+  if (M <= 0 || K <= 0 || !dtT || !A2 || !dx || (keep_v && !keep)) return HAFF_ERR_BAD_ARG;
   if (K % 128) return HAFF_ERR_UNSUPPORTED;
   if (ldt < M || lda < K || ldx < K || (ldx & 7) || (keep && (ldk < K || (ldk & 7)))) return HAFF_ERR_BAD_ARG;
-  if (!al16(dx) || (keep && !al16(keep))) return HAFF_ERR_BAD_ARG;
-  LoraDxArgs p{(const bf16_t*)dtT, ldt, (const bf16_t*)A2, lda, (const bf16_t*)keep, ldk, (bf16_t*)dx, ldx, M, K, accumulate, scale};
+  if (!al16(dx) || (keep && !al16(keep)) || (keep_v && !al16(keep_v))) return HAFF_ERR_BAD_ARG;
+  LoraDxArgs p{(const bf16_t*)dtT, ldt, (const bf16_t*)A2, lda, (const bf16_t*)keep, ldk, (bf16_t*)dx, ldx, M, K, accumulate, scale,
+               (const bf16_t*)keep_v};
   const long n_rt = (M + 15) / 16;
   long gy = (n_rt + 3) / 4;
   const int gx = K / 128;
@@ -326,6 +344,19 @@ extern "C" int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda,
   if (gy > cap) gy = cap;
   hipLaunchKernelGGL(lora_dx_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, HS(stream), p);
   return check_launch();
+}
+
+extern "C" int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda, const void* keep, long ldk, void* dx, long ldx,
+                            int accumulate, long M, int K, float scale, void* stream) {
+  return lora_dx_launch(dtT, ldt, A2, lda, keep, nullptr, ldk, dx, ldx, accumulate, M, K, scale, stream);
+}
+
+// haff_lora_dx with TWO dropout masks (peft: one lora_dropout module per adapted Linear, 2Haff/train_ds.py:218-230):
+//   dx (+)= scale * ( keep_q o (dt[0:8]^T . A2[0:8]) + keep_v o (dt[8:16]^T . A2[8:16]) ),   both masks bf16 [M][ldk] of values.
+extern "C" int haff_lora_dx2(const void* dtT, long ldt, const void* A2, long lda, const void* keep_q, const void* keep_v, long ldk,
+                             void* dx, long ldx, int accumulate, long M, int K, float scale, void* stream) {
+  if (!keep_q || !keep_v) return HAFF_ERR_BAD_ARG;
+  return lora_dx_launch(dtT, ldt, A2, lda, keep_q, keep_v, ldk, dx, ldx, accumulate, M, K, scale, stream);
 }
 
 // rows per block of haff_lora_tn (multiple of 64): ~16 row blocks

@@ -72,6 +72,8 @@ _PROTOS = {
                                c_long, c_long, c_int, c_int, c_int, c_float, c_void_p],
     "haff_lora_qkv_rope_bwd": [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p],
     "haff_lora_dx": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_long, c_int, c_float, c_void_p],
+    "haff_lora_dx2": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_long, c_int, c_float,
+                      c_void_p],
     "haff_lora_tn_workspace_elems": [c_long, c_int, c_int],
     "haff_lora_tn": [c_void_p, c_long, c_int, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_int,
                      c_int, c_float, c_void_p],

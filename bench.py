@@ -736,6 +736,7 @@ def train_main(args):
     sd = hw.make_state_dict_device(cfg, 1234, device, torch.bfloat16)
     model = LisaTrainable(cfg, sd, dtype=torch.bfloat16, device=device)
     model.overlap_sam = not args.single_stream   # --single-stream: the frozen SAM encoder in front of the Llama forward instead of beside it
+    model.independent_lora_dropout = not args.shared_lora_dropout
     del sd
     torch.cuda.empty_cache()
     b = args.batch if args.batch != 64 else 8
@@ -916,6 +917,8 @@ def main(argv=None):
                     help="--mode train: the Llama self-attention with probabilities in HBM (batched products + softmax kernels) instead of the flash pair (A/B)")
     ap.add_argument("--separate-lora", action="store_true",
                     help="--mode train: the q / v adapters as separate product / scale / add / RoPE nodes instead of the fused node of csrc/lora.hip (A/B)")
+    ap.add_argument("--shared-lora-dropout", action="store_true",
+                    help="--mode train: ONE dropout mask per layer for the q and the v adapter (rounds 3-4) instead of peft's two (A/B)")
     ap.add_argument("--train-ids", type=int, default=96)
     ap.add_argument("--train-mask", type=int, default=1024)
     ap.add_argument("--stub-step-ms", type=float, default=None,

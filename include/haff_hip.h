@@ -183,6 +183,10 @@ int haff_lora_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, long 
                            long ld_out, long M, int H, int d, int T, void* stream);
 int haff_lora_dx(const void* dtT, long ldt, const void* A2, long lda, const void* keep, long ldk, void* dx, long ldx,
                  int accumulate, long M, int K, float scale, void* stream);
+/* the same with TWO dropout masks — peft gives each adapted Linear its own lora_dropout (train_ds.py:218-230):
+ * dx (+)= scale * (keep_q o (dt[0:8]^T . A2[0:8]) + keep_v o (dt[8:16]^T . A2[8:16])). */
+int haff_lora_dx2(const void* dtT, long ldt, const void* A2, long lda, const void* keep_q, const void* keep_v, long ldk, void* dx,
+                  long ldx, int accumulate, long M, int K, float scale, void* stream);
 int haff_lora_tn_workspace_elems(long M, int R, int N);
 int haff_lora_tn(const void* sT, long lds, int R, const void* big, long ldb, long M, int N, float* workspace,
                  long workspace_elems, void* out, long ldo, int out_f32, int transposed, int j_valid, float scale, void* stream);

@@ -237,12 +237,14 @@ def test_flash_attention_fn(dev, B, H, Nq, Nk, causal):
 
 
 @pytest.mark.parametrize("B,T,heads,K,r,drop", [(2, 37, 2, 256, 8, False), (3, 50, 3, 384, 8, True), (1, 129, 2, 256, 4, True),
-                                                (2, 16, 1, 128, 1, False), (1, 40, 40, 5120, 8, True)])   # the last: 13B widths
+                                                (2, 16, 1, 128, 1, False), (1, 40, 40, 5120, 8, True),   # the last: 13B widths
+                                                (3, 50, 3, 384, 8, "two"), (1, 129, 2, 256, 4, "two"), (2, 291, 32, 4096, 8, "two")])
 def test_lora_qkv_rope_fn(dev, B, T, heads, K, r, drop):
     """The adapted q|k|v projection + RoPE as one node (csrc/lora.hip: haff_lora_qkv_rope_fwd / _bwd, haff_lora_dx, haff_lora_tn
     and the role-swapped weight-streaming products) against (1) fp32 torch autograd of the definition (peft LoRA on q_proj /
-    v_proj with a shared dropout mask, rotate-half RoPE) and (2) the chain of separate nodes it replaces; row counts that
-    are not multiples of 16 or 8, ranks below 8 (zero-padded adapters), with and without the dropout mask; repeatable to the bit."""
+    v_proj, rotate-half RoPE) and (2) the chain of separate nodes it replaces; row counts that are not multiples of 16 or 8,
+    ranks below 8 (zero-padded adapters), without a dropout mask, with ONE mask for both adapters and with peft's TWO independent
+    masks ("two": each adapted Linear has its own lora_dropout, train_ds.py:218-230); repeatable to the bit."""
     A = _ag()
     dtype, d = torch.bfloat16, 128
     H, M = heads * d, B * T
@@ -252,10 +254,15 @@ def test_lora_qkv_rope_fn(dev, B, T, heads, K, r, drop):
     wt = A.transpose(w)[0]
     aq, av = (_leaf(_rand((r, K), dev, dtype, s_, K ** -0.5)) for s_ in (52, 53))
     bq, bv = (_leaf(_rand((H, r), dev, dtype, s_, 0.3)) for s_ in (54, 55))
-    keep = None
+    keep = keep_v = None
     if drop:
         g = torch.Generator(device="cpu").manual_seed(56)
         keep = ((torch.rand((M, K), generator=g) >= 0.25).float() / 0.75).to(dtype).to(dev)
+        keep_v = keep
+        if drop == "two":   # peft's semantics: the q and the v adapter drop their inputs independently (train_ds.py:218-230)
+            keep_v = ((torch.rand((M, K), generator=g) >= 0.25).float() / 0.75).to(dtype).to(dev)
+            keep = (keep, keep_v)
+    keep_q = keep[0] if isinstance(keep, tuple) else keep
     inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
     ang = torch.arange(T + 3, dtype=torch.float32)[:, None] * inv[None, :]
     cs = torch.cat([ang.cos(), ang.sin()], 1).contiguous().to(dev)
@@ -273,11 +280,12 @@ def test_lora_qkv_rope_fn(dev, B, T, heads, K, r, drop):
         return torch.cat([t1 * co - t2 * si, t2 * co + t1 * si], -1).reshape(M, H)
 
     xr, aqr, avr, bqr, bvr = (_leaf(t.detach().float()) for t in (x, aq, av, bq, bv))
-    xd = xr if keep is None else xr * keep.float()
+    xd = xr if keep is None else xr * keep_q.float()
+    xdv = xr if keep is None else xr * keep_v.float()
     qkv = xr @ w.float().t()
     qr = rope(qkv[:, :H] + scale * (xd @ aqr.t()) @ bqr.t())
     kr = rope(qkv[:, H:2 * H])
-    vr = qkv[:, 2 * H:] + scale * (xd @ avr.t()) @ bvr.t()
+    vr = qkv[:, 2 * H:] + scale * (xdv @ avr.t()) @ bvr.t()
     torch.autograd.backward([qr, kr, vr], [gq.float(), gk.float(), gv.float()])
     for got, ref, what in ((q, qr, "q"), (k, kr, "k"), (v, vr, "v"), (x.grad, xr.grad, "dx"), (aq.grad, aqr.grad, "dAq"),
                            (av.grad, avr.grad, "dAv"), (bq.grad, bqr.grad, "dBq"), (bv.grad, bvr.grad, "dBv")):
@@ -297,10 +305,11 @@ def test_lora_qkv_rope_fn(dev, B, T, heads, K, r, drop):
         return torch.cat([a_, torch.zeros((8 - a_.shape[0] % 8, a_.shape[1]), dtype=a_.dtype, device=a_.device)], 0)
 
     qkvs = A.linear(xs, w, None, None, wt)
-    hl = xs if keep is None else xs * keep
+    hl = xs if keep is None else xs * keep_q
+    hv = xs if keep is None else xs * keep_v
     qs = A.rope(A.add(qkvs[:, :H], A.scale(A.linear(A.linear(hl, pada(aqs)), padk(bqs)), scale)), cs, T, heads, d)
     ks = A.rope(qkvs[:, H:2 * H], cs, T, heads, d)
-    vs = A.add(qkvs[:, 2 * H:], A.scale(A.linear(A.linear(hl, pada(avs)), padk(bvs)), scale))
+    vs = A.add(qkvs[:, 2 * H:], A.scale(A.linear(A.linear(hv, pada(avs)), padk(bvs)), scale))
     torch.autograd.backward([qs, ks, vs], [gq, gk, gv])
     for got, ref, what in ((q, qs, "q"), (k, ks, "k"), (v, vs, "v"), (x.grad, xs.grad, "dx"), (aq.grad, aqs.grad, "dAq"),
                            (av.grad, avs.grad, "dAv"), (bq.grad, bqs.grad, "dBq"), (bv.grad, bvs.grad, "dBv")):

@@ -34,6 +34,34 @@ def test_model_forward_loss_and_grads_match_oracle(dev, mode):
     check_forward_backward(dev, cfg, mode, make_batch(cfg), min_tensors=150)
 
 
+def grad_class(key):
+    """Tensor class of a trainable parameter (the reference's trainable set: train_ds.py:192-244)."""
+    if "lora_A" in key:
+        return "lora_A"
+    if "lora_B" in key:
+        return "lora_B"
+    if "embed_tokens" in key:
+        return "embed_tokens"
+    if "lm_head" in key:
+        return "lm_head"
+    if "text_hidden_fcs" in key:
+        return "text_hidden_fcs"
+    for part in ("output_upscaling", "output_hypernetworks", "taxonomy_embed", "iou_prediction", "_token", "transformer"):
+        if part in key:
+            return "decoder." + part.strip("_")
+    return "other"
+
+
+# worst per-tensor relative L2 error of a bf16 gradient against the fp32 oracle's, per class. Measured on MI355X in round 5 (tiny
+# geometry / 7B width at reduced depth): lora_A 1.5e-2 / 1.5e-2, lora_B 1.1e-2 / 1.5e-2, embed_tokens 1.0e-2 / 8.3e-3, lm_head
+# 5.5e-3 / 4.5e-3, text_hidden_fcs 9.3e-2 / 9.5e-2, decoder upscaling 1.5e-2 / 1.5e-2, hypernetworks 1.3e-1 / 4.0e-2, transformer
+# 1.6e-1 / 1.3e-1, tokens 1.2e-1 / 1.4e-1, taxonomy head 1.7e-1 / 1.9e-1 (the fp32 mode: <= 1.3e-5 everywhere). The language-model
+# side — what LoRA fine-tuning moves — gets 2x its measurement; the mask decoders' small gradients (differences of bf16-rounded
+# activations of 256-wide layers) keep the old 0.25.
+BF16_CLASS_TOL = {"lora_A": 3e-2, "lora_B": 3e-2, "embed_tokens": 2e-2, "lm_head": 1.2e-2, "text_hidden_fcs": 0.2,
+                  "decoder.output_upscaling": 3e-2}
+
+
 def check_forward_backward(dev, cfg, mode, batch, min_tensors):
     """All 6 losses and every trainable gradient of LisaTrainable (HIP forward + backward) vs the oracle under autograd."""
     import haff  # noqa: F401
@@ -66,10 +94,11 @@ def check_forward_backward(dev, cfg, mode, batch, min_tensors):
         a, b = float(out[k]), float(ref[k])
         print(f"{mode} {k}: hip {a:.6f} oracle {b:.6f}")
         assert abs(a - b) <= ltol * max(1.0, abs(b)), k
-    gtol = 2e-3 if mode == "f32" else 0.25  # bf16: per-tensor relative L2; plus a global cosine check below
+    gtol = 2e-3 if mode == "f32" else 0.25  # bf16: per-tensor relative L2; plus per-class bounds and a global cosine check below
     flat_g, flat_r = [], []
     worst = ("", 0.0)
     n_checked = 0
+    by_class = {}
     for k, p in model.named_parameters():
         r = (lora[k] if "lora_" in k else osd[k]).grad
         if r is None:
@@ -88,11 +117,17 @@ def check_forward_backward(dev, cfg, mode, batch, min_tensors):
             rel = ((p.grad.float().cpu() - r).norm() / (r.norm() + 1e-12)).item()
         if rel > worst[1]:
             worst = (k, rel)
+        cls = grad_class(k)
+        by_class[cls] = max(by_class.get(cls, 0.0), rel)
         n_checked += 1
         flat_g.append(p.grad.float().cpu().reshape(-1))
         flat_r.append(r.reshape(-1))
         assert scale == 0 or rel <= gtol, f"{k}: grad rel err {rel:.3g} (scale {scale:.3g})"
     print(f"{mode}: {n_checked} gradient tensors checked, worst {worst}")
+    print(f"{mode}: worst relative error per tensor class: " + ", ".join(f"{c} {v:.3e}" for c, v in sorted(by_class.items())))
+    if mode == "bf16":   # per class, ~2x what MI355X measures on these two geometries instead of one global 0.25
+        for c, v in by_class.items():
+            assert v <= BF16_CLASS_TOL.get(c, gtol), f"bf16 gradient class {c}: worst relative L2 {v:.3e} > {BF16_CLASS_TOL.get(c, gtol)}"
     assert n_checked > min_tensors
     cos = torch.nn.functional.cosine_similarity(torch.cat(flat_g).double(), torch.cat(flat_r).double(), dim=0).item()
     print(f"{mode}: global gradient cosine {cos:.6f}")
