@@ -353,6 +353,41 @@ class RMSNormFn(Function):
 rmsnorm = RMSNormFn.apply
 
 
+class ResidRMSNormFn(Function):
+    """x -> (x, rmsnorm(x)) for a pre-norm residual block (transformers' LlamaDecoderLayer: h = norm(x); x_new = x + f(h)): the
+    stream is handed on beside its normalised copy, so that backward sees BOTH gradients of x — the one that arrives along the
+    residual branch and the norm's — and adds them inside the norm adjoint kernel (haff_norm_bwd_add): one pass instead of the
+    adjoint + autograd's separate accumulation add (340 such adds per fine-tune step in round 4's profile)."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return x.view_as(x), ops.rmsnorm(x, w, eps)
+
+    @staticmethod
+    def backward(ctx, g_x, g_h):
+        lib = load_library()
+        x, w = ctx.saved_tensors
+        if g_h is None:
+            return g_x, None, None
+        g_h = g_h.contiguous()
+        dx = torch.empty_like(x)
+        if g_x is None:
+            check(lib.haff_norm_bwd(x.data_ptr(), g_h.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, x.shape[0], x.shape[1], float(ctx.eps), 1,
+                                    _dt(x), _s()), "haff_norm_bwd")
+        else:
+            g_x = g_x.contiguous()
+            check(lib.haff_norm_bwd_add(x.data_ptr(), g_h.data_ptr(), w.data_ptr(), g_x.data_ptr(), dx.data_ptr(), 0, x.shape[0], x.shape[1],
+                                        float(ctx.eps), 1, _dt(x), _s()), "haff_norm_bwd_add")
+        return dx, None, None
+
+
+resid_rmsnorm = ResidRMSNormFn.apply
+FUSED_RESID_NORM = True   # False: rmsnorm + autograd's own gradient add (A/B, tests)
+
+
 class RopeFn(Function):
     """x [rows, H*d] (rows = B*T, position = row % T) -> rotated copy."""
 

@@ -146,7 +146,7 @@ __global__ void swiglu_bwd_vec_kernel(const bf16_t* gu, const bf16_t* dy, bf16_t
 // RMSNorm  : xhat = x*rstd ;            dx = rstd*(g - xhat*mean(g*xhat))
 template <typename T, bool RMS>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* x, const T* dy, const float* w, T* dx, float* dyx,
-                                                      int rows, int C, float eps) {
+                                                      int rows, int C, float eps, const T* add) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* x, const T* dy, 
     const float xh = (elem<T>::ld(xr + c) - mean) * rstd;
     const float d = elem<T>::ld(dr + c);
     const float g = d * w[c];
-    elem<T>::st(dx + (long)row * C + c, rstd * (g - (RMS ? 0.f : a) - xh * b));
+    // add: the gradient that reaches the SAME tensor along the residual branch (haff_norm_bwd_add): summed here in fp32
+    elem<T>::st(dx + (long)row * C + c, rstd * (g - (RMS ? 0.f : a) - xh * b) + (add ? elem<T>::ld(add + (long)row * C + c) : 0.f));
     if (dyx) dyx[(long)row * C + c] = d * xh;
   }
 }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* x, const T* dy, 
 // against 15 us of traffic at the HBM rate: 2.6 % of the fine-tune step)
 template <bool RMS, int NV>
 __global__ __launch_bounds__(256) void norm_bwd_vec_kernel(const bf16_t* x, const bf16_t* dy, const float* w, bf16_t* dx, float* dyx,
-                                                          int rows, float eps) {
+                                                          int rows, float eps, const bf16_t* add) {
   constexpr int C = 512 * NV;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -249,6 +250,12 @@ __global__ __launch_bounds__(256) void norm_bwd_vec_kernel(const bf16_t* x, cons
       const float xh = (v[e] - mean) * rstd;
       o[e] = rstd * (d[e] * wv[e] - (RMS ? 0.f : a) - xh * b);
       d[e] *= xh;
+    }
+    if (add) {   // (wave-uniform) the residual branch's gradient of the same tensor
+      float ad[8];
+      load8(add + (long)row * C + (i * 64 + lane) * 8, ad);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += ad[e];
     }
     store8(dx + (long)row * C + (i * 64 + lane) * 8, o);
     if (dyx) store8(dyx + (long)row * C + (i * 64 + lane) * 8, d);
@@ -724,27 +731,42 @@ extern "C" int haff_mul(const void* a, const void* b, void* out, long n, int dty
   return haff_check_launch();
 }
 // rms != 0: RMSNorm adjoint (dx only). dyx (f32 [rows][C], may be null) receives dy*xhat for the weight gradient.
-extern "C" int haff_norm_bwd(const void* x, const void* dy, const float* w, void* dx, float* dyx, int rows, int C, float eps,
-                             int rms, int dtype, void* stream) {
+static int norm_bwd_launch(const void* x, const void* dy, const float* w, const void* add, void* dx, float* dyx, int rows, int C,
+                           float eps, int rms, int dtype, void* stream) {
   if (rows <= 0 || C <= 0) return HAFF_ERR_BAD_ARG;
   dim3 g((rows + 3) / 4), b(256);
   const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
-                    reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dyx)) & 15) == 0;
+                    reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dyx) | reinterpret_cast<uintptr_t>(add)) & 15) == 0;
   if (dtype == 0 && al && (C == 4096 || C == 5120)) {   // Llama 7B / 13B rows: one pass, the row in registers
-#define HAFF_NBV(R_, NV_) hipLaunchKernelGGL((norm_bwd_vec_kernel<R_, NV_>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, eps)
+#define HAFF_NBV(R_, NV_) hipLaunchKernelGGL((norm_bwd_vec_kernel<R_, NV_>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, eps, (const bf16_t*)add)
     if (C == 4096) { if (rms) HAFF_NBV(true, 8); else HAFF_NBV(false, 8); }
     else { if (rms) HAFF_NBV(true, 10); else HAFF_NBV(false, 10); }
 #undef HAFF_NBV
     return haff_check_launch();
   }
   if (dtype == 0) {
-    if (rms) hipLaunchKernelGGL((norm_bwd_kernel<bf16_t, true>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, C, eps);
-    else hipLaunchKernelGGL((norm_bwd_kernel<bf16_t, false>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, C, eps);
+    if (rms) hipLaunchKernelGGL((norm_bwd_kernel<bf16_t, true>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, C, eps, (const bf16_t*)add);
+    else hipLaunchKernelGGL((norm_bwd_kernel<bf16_t, false>), g, b, 0, HS(stream), (const bf16_t*)x, (const bf16_t*)dy, w, (bf16_t*)dx, dyx, rows, C, eps, (const bf16_t*)add);
   } else {
-    if (rms) hipLaunchKernelGGL((norm_bwd_kernel<float, true>), g, b, 0, HS(stream), (const float*)x, (const float*)dy, w, (float*)dx, dyx, rows, C, eps);
-    else hipLaunchKernelGGL((norm_bwd_kernel<float, false>), g, b, 0, HS(stream), (const float*)x, (const float*)dy, w, (float*)dx, dyx, rows, C, eps);
+    if (rms) hipLaunchKernelGGL((norm_bwd_kernel<float, true>), g, b, 0, HS(stream), (const float*)x, (const float*)dy, w, (float*)dx, dyx, rows, C, eps, (const float*)add);
+    else hipLaunchKernelGGL((norm_bwd_kernel<float, false>), g, b, 0, HS(stream), (const float*)x, (const float*)dy, w, (float*)dx, dyx, rows, C, eps, (const float*)add);
   }
   return haff_check_launch();
+}
+
+extern "C" int haff_norm_bwd(const void* x, const void* dy, const float* w, void* dx, float* dyx, int rows, int C, float eps,
+                             int rms, int dtype, void* stream) {
+  return norm_bwd_launch(x, dy, w, nullptr, dx, dyx, rows, C, eps, rms, dtype, stream);
+}
+
+// haff_norm_bwd with the gradient of the residual branch folded in: the tensor x of a pre-norm block feeds the norm AND the
+// residual add (x_new = x + f(norm(x)): transformers' LlamaDecoderLayer, image_encoder.py:186-193), so its gradient is
+// dx = norm adjoint(dy) + add, add = the gradient that arrives along the residual branch (same shape / dtype as x; dx may alias
+// it). One pass instead of the adjoint + autograd's separate accumulation add.
+extern "C" int haff_norm_bwd_add(const void* x, const void* dy, const float* w, const void* add, void* dx, float* dyx, int rows, int C,
+                                 float eps, int rms, int dtype, void* stream) {
+  if (!add) return HAFF_ERR_BAD_ARG;
+  return norm_bwd_launch(x, dy, w, add, dx, dyx, rows, C, eps, rms, dtype, stream);
 }
 extern "C" int haff_colsum(const void* x, float* out, long R, int C, int dtype, void* stream) {
   if (R <= 0 || C <= 0) return HAFF_ERR_BAD_ARG;

@@ -124,6 +124,7 @@ _PROTOS = {
     "haff_scatter_add_rows_sorted": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "haff_mul": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "haff_norm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
+    "haff_norm_bwd_add": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_colsum": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "haff_softmax_fwd": [c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p],
     "haff_softmax_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int, c_void_p],

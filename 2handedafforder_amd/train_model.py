@@ -109,7 +109,11 @@ class LisaTrainable:
         P = self.params
         for i, L in enumerate(llm.layers):
             wt = self.wt[i]
-            h = A.rmsnorm(x, L["n1"], l.rms_eps)
+            # (x, norm(x)) as one node: the adjoint adds the residual branch's gradient of x inside the norm kernel
+            if A.FUSED_RESID_NORM:
+                x, h = A.resid_rmsnorm(x, L["n1"], l.rms_eps)
+            else:
+                h = A.rmsnorm(x, L["n1"], l.rms_eps)
             pre = f"model.layers.{i}.self_attn."
             drop = self.lora_dropout if self.training else 0.0
             if A.FUSED_LORA_QKV and A.lora_qkv_rope_supported(h, L["wqkv"], P[pre + "q_proj.lora_A"], nh):
@@ -139,7 +143,10 @@ class LisaTrainable:
                 k = A.rope(k, cs, T, nh, hd)
             a = A.attention(q.view(B, T, H), k.view(B, T, H), v.view(B, T, H), nh, hd ** -0.5, True)
             x = A.linear(a.view(B * T, H), L["wo"], None, x, wt["wo"])
-            h = A.rmsnorm(x, L["n2"], l.rms_eps)
+            if A.FUSED_RESID_NORM:
+                x, h = A.resid_rmsnorm(x, L["n2"], l.rms_eps)
+            else:
+                h = A.rmsnorm(x, L["n2"], l.rms_eps)
             gu = A.linear(h, L["wgu"], None, None, wt["wgu"])
             x = A.linear(A.swiglu(gu), L["wd"], None, x, wt["wd"])
         return A.rmsnorm(x, llm.norm, l.rms_eps)

@@ -351,6 +351,10 @@ int haff_mul(const void* a, const void* b, void* out, long n, int dtype, void* s
 /* LayerNorm (rms=0) / RMSNorm (rms=1) adjoint: dx; dyx (f32 [rows][C], may be null) = dy*xhat for the weight grad */
 int haff_norm_bwd(const void* x, const void* dy, const float* w, void* dx, float* dyx, int rows, int C, float eps, int rms,
                   int dtype, void* stream);
+/* the same with the residual branch's gradient folded in: x of a pre-norm block feeds the norm AND the residual add (transformers'
+ * LlamaDecoderLayer; image_encoder.py:186-193), so dx = norm adjoint(dy) + add (add: same shape / dtype as x; dx may alias it). */
+int haff_norm_bwd_add(const void* x, const void* dy, const float* w, const void* add, void* dx, float* dyx, int rows, int C,
+                      float eps, int rms, int dtype, void* stream);
 /* out[c] += sum_r x[r][c] (bias / norm-weight gradients); out f32, zeroed by the caller */
 int haff_colsum(const void* x, float* out, long R, int C, int dtype, void* stream);
 /* row softmax of scale*s (+ causal mask, row r = query r % Nq, key j visible iff j <= q + q_pos0) and its adjoint

@@ -164,6 +164,48 @@ def test_norm_adjoints_llama_width(dev, C):
     assert (a.grad.float() - ar.grad).abs().mean().item() <= 4e-3 * ar.grad.abs().mean().item() + 1e-6   # bf16 rounding of dx only
 
 
+@pytest.mark.parametrize("C,dtype", [(4096, torch.bfloat16), (5120, torch.bfloat16), (256, torch.bfloat16), (192, torch.float32)])
+def test_resid_rmsnorm_fn(dev, C, dtype):
+    """(x, rmsnorm(x)) as one node (ResidRMSNormFn: haff_norm_bwd_add): a pre-norm residual block y = x + f(norm(x)) built on it has
+    the gradients of the plain rmsnorm node + autograd's own accumulation add (bit for bit where the bf16 sum rounds once either
+    way is not guaranteed: the fused form adds in fp32 and rounds ONCE, so it is held to the fp32 reference and must be at least
+    as close as the two-node form), with only one branch used, and for both row kernels (Llama widths / generic)."""
+    A = _ag()
+    R = 37
+    x = _rand((R, C), dev, dtype, 31, 2.0) + 0.5
+    w = _rand((C,), dev, torch.float32, 32) + 1.0
+    m = _rand((C, C), dev, dtype, 33, C ** -0.5)
+    gy = _rand((R, C), dev, dtype, 34)
+
+    def block(x_, fused):
+        if fused:
+            xs, h = A.resid_rmsnorm(x_, w, 1e-5)
+        else:
+            xs, h = x_, A.rmsnorm(x_, w, 1e-5)
+        return A.linear(h, m, None, xs)          # y = x + norm(x) @ m.T (the residual enters LinearFn's epilogue)
+    a, b = _leaf(x), _leaf(x)
+    ya, yb = block(a, True), block(b, False)
+    assert torch.equal(ya, yb)
+    ya.backward(gy)
+    yb.backward(gy)
+    xr = _leaf(x.float())
+    (xr + (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w) @ m.float().t()).backward(gy.float())
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-5
+    _close(a.grad, xr.grad, tol, "fused residual + rmsnorm dx")
+    e_f = (a.grad.float() - xr.grad).abs().mean().item()
+    e_s = (b.grad.float() - xr.grad).abs().mean().item()
+    assert e_f <= 1.05 * e_s + 1e-7, (e_f, e_s)
+    # one branch only: the stream output unused / the norm output unused
+    c = _leaf(x)
+    A.resid_rmsnorm(c, w, 1e-5)[1].backward(gy)
+    d = _leaf(x)
+    A.rmsnorm(d, w, 1e-5).backward(gy)
+    assert torch.equal(c.grad, d.grad)
+    e = _leaf(x)
+    A.resid_rmsnorm(e, w, 1e-5)[0].backward(gy)
+    assert torch.equal(e.grad, gy)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,H,Nq,Nk,d,causal", [(2, 4, 37, 37, 32, True), (2, 8, 6, 200, 16, False), (1, 8, 130, 6, 16, False),
                                                 (2, 2, 50, 50, 128, True)])
