@@ -177,3 +177,49 @@ def test_host_helpers_match_reference():
     conv.append_message(conv.roles[0], "<im_start><image><im_end>\nWhere would you hold the mug?")
     conv.append_message(conv.roles[1], "")
     assert conv.get_prompt() == g["conv_llava_v1_prompt"]
+
+
+def test_bf16_points_per_stack_and_memo():
+    """Test infrastructure of round 5 (bench.parity_full_frame's attribution): lisa_evaluate(points=, memo=) switches the
+    bf16-points mode per stack and re-uses stage results. points=None is the exact forward bit for bit (memo or not); all three
+    stacks == `with bf16_points():` bit for bit; a single stack's points change the result, by less than all three together do in
+    the stack that dominates; and a memo filled by one call serves the next without recomputing the shared stage."""
+    import numpy as np
+    import haff  # noqa: F401
+    from haff import config as hcfg, weights as hw
+    from oracle import lisa_oracle as O
+    cfg = hcfg.tiny()
+    sd = hw.round_to_bf16_(hw.make_state_dict(cfg, 3))
+    rng = np.random.default_rng(3)
+    S = cfg.sam.img_size
+    images = torch.from_numpy(rng.standard_normal((1, 3, S, S), dtype=np.float32))
+    clip = torch.from_numpy(rng.standard_normal((1, 3, 224, 224), dtype=np.float32))
+    ids = torch.tensor([[cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx, 11, 12, 13, 14]])
+    forced = torch.tensor([[7, cfg.seg_token_idx, 9, cfg.eos_token_id]])
+    kw = dict(max_new_tokens=4, forced_answer=forced, use_cache=True)
+    sz = [(S, S)]
+    with torch.no_grad():
+        exact = O.lisa_evaluate(sd, cfg, clip, images, ids, sz, sz, **kw)
+        memo = {}
+        again = O.lisa_evaluate(sd, cfg, clip, images, ids, sz, sz, memo=memo, points=(), **kw)
+        assert torch.equal(exact[1][0], again[1][0]) and torch.equal(exact[2][0], again[2][0]) and len(memo) == 2
+        with O.bf16_points():
+            allp = O.lisa_evaluate(sd, cfg, clip, images, ids, sz, sz, **kw)
+        allp2 = O.lisa_evaluate(sd, cfg, clip, images, ids, sz, sz, memo=memo, points=("sam", "clip", "llama"), **kw)
+        assert torch.equal(allp[1][0], allp2[1][0]) and torch.equal(allp[2][0], allp2[2][0])
+        calls = {"sam": 0}
+        real = O.sam_image_encoder
+
+        def counting(*a, **k):
+            calls["sam"] += 1
+            return real(*a, **k)
+        O.sam_image_encoder = counting
+        try:
+            sam_only = O.lisa_evaluate(sd, cfg, clip, images, ids, sz, sz, memo=memo, points=("sam",), **kw)
+            llama_only = O.lisa_evaluate(sd, cfg, clip, images, ids, sz, sz, memo=memo, points=("llama",), **kw)
+        finally:
+            O.sam_image_encoder = real
+        assert calls["sam"] == 0, "both image embeddings were in the memo already (exact and bf16-points)"
+    d = lambda a: (a[1][0] - exact[1][0]).abs().max().item()   # noqa: E731
+    assert 0 < d(sam_only) and 0 < d(llama_only) and d(allp) > 0
+    assert max(d(sam_only), d(llama_only)) <= 2.0 * d(allp) + 1e-6
