@@ -1361,17 +1361,23 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(GemmArgs p) {
   // folded RMSNorm from producer partials: thread (bl = tid >> 4, m = tid & 15) gathers partials b = bl, bl + 16, ...;
   // the loads go out before the weight stream and are only consumed after the K loop
   __shared__ float s_ssq[KW][16];
-  // thread t fetches partial workgroups b = t and t + 256 of each row (<= 4 rows, <= 512 partials: haff_gemm_bf16_rms checks);
+  // thread t fetches partial workgroups b = t and t + 256 of each row (<= 8 rows, <= 512 partials: haff_gemm_bf16_rms checks;
+  // round 5: 8 rows instead of 4, as 16-byte loads of four rows each — configs[4] decodes 8 frames per GPU);
   // the values stay untouched in registers until after the K loop, so the weight stream starts without waiting for them
   // (summing them here — a dependent L2 round trip before the first weight load — made the step slower than the norm kernels)
-  constexpr int SSQ_M = 4;
+  constexpr int SSQ_M = 8;
   float ssq_a[SSQ_M], ssq_b[SSQ_M];
   if (MT == 1 && p.ssq_in) {
+    const int b0 = threadIdx.x, b1 = threadIdx.x + 64 * KW;
 #pragma unroll
-    for (int mm = 0; mm < SSQ_M; ++mm) {
-      const int b0 = threadIdx.x, b1 = threadIdx.x + 64 * KW;
-      ssq_a[mm] = (mm < p.M && b0 < p.ssq_n) ? p.ssq_in[b0 * 16 + mm] : 0.f;
-      ssq_b[mm] = (mm < p.M && b1 < p.ssq_n) ? p.ssq_in[b1 * 16 + mm] : 0.f;
+    for (int h4 = 0; h4 < SSQ_M / 4; ++h4) {
+      float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+      if (4 * h4 < p.M) {   // (uniform) rows 4 h4 .. 4 h4 + 3 of a partial are 16 contiguous, 16-byte aligned bytes; rows >= M hold finite junk nobody reads
+        if (b0 < p.ssq_n) load4(p.ssq_in + b0 * 16 + 4 * h4, va);
+        if (b1 < p.ssq_n) load4(p.ssq_in + b1 * 16 + 4 * h4, vb);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ssq_a[4 * h4 + e] = va[e]; ssq_b[4 * h4 + e] = vb[e]; }
     }
   }
 
@@ -1922,7 +1928,7 @@ extern "C" int haff_gemm_bf16_ws(const void* A, long lda, const void* W, long ld
                         stream, nullptr, nullptr, workspace, workspace_bytes);
 }
 
-// Decode-sized product (M <= 16; with ssq_in M <= 4 and ssq_n <= 512; K % 128 == 0; weight-streaming kernel) that carries Llama's RMSNorm between products
+// Decode-sized product (M <= 16; with ssq_in M <= 8 and ssq_n <= 512; K % 128 == 0; weight-streaming kernel) that carries Llama's RMSNorm between products
 // without a norm kernel (LlamaDecoderLayer as reached from llava_llama.py:93-102: input_layernorm -> q/k/v,
 // post_attention_layernorm -> gate/up):
 //   ssq_in  != NULL: C = epi( rstd_m * (A . W^T) ), rstd_m = rsqrt(sum_{b < ssq_n} ssq_in[b][m] / K + eps), W = the weights with
@@ -1934,7 +1940,8 @@ extern "C" int haff_gemm_bf16_rms(const void* A, long lda, const void* W, long l
                                   const void* resid, long ldr, int M, int N, int K, int act, int out_f32, int swiglu,
                                   const float* ssq_in, int ssq_n, float eps, float* ssq_out, int* n_parts_out, void* stream) {
   if (M <= 0 || M > 16 || N <= 0 || K <= 0 || (K % 128) || (lda & 7) || (ldw & 7)) return HAFF_ERR_BAD_ARG;
-  if (ssq_in && (M > 4 || ssq_n > 512)) return HAFF_ERR_BAD_ARG;   // consumer side: <= 4 rows, <= 512 producer workgroups
+  if (ssq_in && (M > 8 || ssq_n > 512)) return HAFF_ERR_BAD_ARG;   // consumer side: <= 8 rows, <= 512 producer workgroups
+  if (ssq_in && (reinterpret_cast<uintptr_t>(ssq_in) & 15)) return HAFF_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return HAFF_ERR_BAD_ARG;
   if (swiglu && ((N & 31) || (ldc & 3) || resid)) return HAFF_ERR_BAD_ARG;
   if ((ssq_in && ssq_n <= 0) || (ssq_out && (out_f32 || swiglu))) return HAFF_ERR_BAD_ARG;

@@ -122,9 +122,10 @@ class LlamaHip:
             del wqkv, wgu
         self.norm = _f32(sd["model.norm.weight"], dev)
         self.lm_head = sd["lm_head.weight"].to(dev, dtype).contiguous()
-        # Decode steps of <= 4 rows carry RMSNorm between the products (ops.linear_rms): no norm kernels, the q/k/v and gate/up
+        # Decode steps of <= 8 rows (round 5; <= 4 before) carry RMSNorm between the products (ops.linear_rms): no norm kernels, the q/k/v and gate/up
         # weights get a second copy with the norm weight folded in (built on first use; +9 GB at 7B, +18 GB at 13B of 288)
         self.carry_rms = dtype == torch.bfloat16 and self.hd == 128 and l.hidden % 128 == 0 and l.ffn % 128 == 0
+        self.carry_rms_max_rows = 8   # the consumer side of haff_gemm_bf16_rms gathers the partials of <= 8 rows
         self._folded = None
         self._cs = None
         # Prefill-sized batches (>= 1024 rows: where the 8-wave tile runs anyway): RoPE and the KV-cache append ride in the q|k|v projection's epilogue
@@ -133,7 +134,7 @@ class LlamaHip:
         self._wqkv_rope = None
         # fp32 RESIDUAL STREAM (bf16 mode; round 5): the hidden-state stream lives in HBM as fp32 — o_proj /
         # down_proj add their fp32 accumulators to it and write fp32, RMSNorm reads it and rounds the NORMALISED row to bf16 once
-        # for the bf16 MFMA products. Off by default (it gives up the norm-carrying 5-launch decode layer at <= 4 rows).
+        # for the bf16 MFMA products. Off by default (it gives up the norm-carrying 5-launch decode layer at <= 8 rows).
         self.fp32_stream = False
 
     def _cos_sin(self, tmax):
@@ -206,7 +207,7 @@ class LlamaHip:
         nd = self.dtype if s32 else None
         if s32:
             x = x.float()
-        elif self.carry_rms and B <= 4:
+        elif self.carry_rms and B <= self.carry_rms_max_rows:
             return self._decode_rows_carry(x, cache, cs, nk)
         for li, L in enumerate(self.layers):
             h = ops.rmsnorm(x, L["n1"], l.rms_eps, out_dtype=nd)
@@ -228,7 +229,7 @@ class LlamaHip:
         return ops.rmsnorm(x, self.norm, l.rms_eps, out_dtype=nd).view(B, 1, H)
 
     def _decode_rows_carry(self, x, cache, cs, nk):
-        """decode_rows for <= 4 rows without norm kernels: o_proj / down_proj write, beside the residual stream, each
+        """decode_rows for <= 8 rows without norm kernels: o_proj / down_proj write, beside the residual stream, each
         workgroup's sum of squares of its slice of it; the next q/k/v or gate/up product (on norm-weight-folded weights and the
         RAW stream) turns the partials into 1/rms in its epilogue. 5 launches per layer instead of 7 (layer 0 takes its
         statistic from one pass over the embedding rows)."""

@@ -45,7 +45,7 @@ int haff_gemm_bf16_cfg(const void* A, long lda, const void* W, long ldw, void* C
 int haff_gemm_bf16_ws(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias,
                       const void* resid, long ldr, const int* row_map, int M, int N, int K, int act, int out_f32,
                       int swiglu, void* workspace, long workspace_bytes, void* stream);
-/* Decode-sized product (M <= 16; with ssq_in: M <= 4, ssq_n <= 512; K % 128 == 0) that carries Llama's RMSNorm between products without a norm kernel
+/* Decode-sized product (M <= 16; with ssq_in: M <= 8, ssq_n <= 512, ssq_in 16-B aligned; K % 128 == 0) that carries Llama's RMSNorm between products without a norm kernel
  * (transformers LlamaDecoderLayer as reached from 2Haff/model/llava/model/language_model/llava_llama.py:93-102:
  * input_layernorm -> q/k/v_proj, post_attention_layernorm -> gate/up_proj). ssq_in != NULL: row m of A . W^T is scaled by
  * rsqrt(sum_{b < ssq_n} ssq_in[b][m] / K + eps) before the epilogue — W must have the norm weight folded into its columns

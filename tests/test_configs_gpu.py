@@ -222,9 +222,9 @@ def test_full_width_llama_layer_matches_oracle(dev, width, mode):
         assert err2 <= 1.5e-2 and llm._wqkv_rope is not None
 
 
-@pytest.mark.parametrize("width", ["7b", "13b"])
-def test_decode_rows_carrying_rmsnorm_matches_oracle(dev, width):
-    """Decode steps of <= 4 rows run without norm kernels (LlamaHip._decode_rows_carry: o_proj / down_proj emit per-workgroup
+@pytest.mark.parametrize("width,B", [("7b", 3), ("13b", 3), ("13b", 8), ("7b", 6)])
+def test_decode_rows_carrying_rmsnorm_matches_oracle(dev, width, B):
+    """Decode steps of <= 8 rows (<= 4 until round 5; 8 = configs[4]'s frames per GPU) run without norm kernels (LlamaHip._decode_rows_carry: o_proj / down_proj emit per-workgroup
     sums of squares, the next product on norm-weight-folded weights applies 1/rms): after a 291-position prefill, two cached
     steps at full width equal the oracle's no-cache recompute within the bf16 tolerance of the plain path, agree with the
     plain path (norm kernels), and repeat bit for bit."""
@@ -241,7 +241,7 @@ def test_decode_rows_carrying_rmsnorm_matches_oracle(dev, width):
     for k in sd:   # norm weights away from 1 so that the fold matters
         if k.endswith("layernorm.weight") or k == "model.norm.weight":
             sd[k] = (1.0 + 0.5 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16).float()
-    B, T, Hd = 3, 291, cfg.llm.hidden
+    T, Hd = 291 if B <= 3 else 64, cfg.llm.hidden      # (the oracle's no-cache recompute of 8 x 293 positions at 13B width takes minutes)
     x = torch.randn((B, T + 2, Hd), generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).float()
     with torch.no_grad():
         ref = O.llama_forward(sd, x, cfg.llm)[:, T:]

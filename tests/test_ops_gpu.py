@@ -57,7 +57,7 @@ def test_gemm_bf16_epilogues(dev, M, N, K, act):
     _close(got32, ACT_REF[act](x.float() @ w.float().T + bias), 2e-3, "gemm_bf16 f32-out")
 
 
-@pytest.mark.parametrize("M", [1, 3, 4])
+@pytest.mark.parametrize("M", [1, 3, 4, 5, 8])
 @pytest.mark.parametrize("H,N2", [(4096, 12288), (512, 1000), (5120, 27648)])
 def test_linear_rms_carries_the_norm(dev, M, H, N2):
     """haff_gemm_bf16_rms: a residual product that also emits per-workgroup sums of squares of its bf16 output, and a product
