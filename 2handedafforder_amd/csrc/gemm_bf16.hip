@@ -1683,6 +1683,16 @@ static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
 
 }  // namespace
 
+// Workgroups a persistent 8-wave launch takes (one per CU: 256 fills the chip). A caller that wants CUs left over for
+// kernels of ANOTHER stream (HBM-bound decode steps beside the MFMA-bound encoder) lowers it for the launches it
+// enqueues meanwhile; multiples of 8 keep a workgroup's tiles on one XCD.
+static int g_persist_cap = 256;
+extern "C" int haff_gemm_persistent_cap(int cap) {
+  const int old = g_persist_cap;
+  if (cap >= 8 && cap <= 256 && (cap & 7) == 0) g_persist_cap = cap;
+  return old;
+}
+
 static bool haff_gemm_spec_enabled() {
 #ifdef HAFF_TUNING   // HAFF_GEMM_NO_SPEC=1: every launch through the generic instance (A/B)
   static const bool off = [] { const char* e = getenv("HAFF_GEMM_NO_SPEC"); return e && atoi(e) != 0; }();
@@ -1697,10 +1707,10 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   int gx = tiles;
   if (WM * WN == 8) {   // persistent 8-wave tile: one workgroup per CU
-    int cap = 256;
+    int cap = g_persist_cap;
 #ifdef HAFF_TUNING       // HAFF_GEMM_PERSIST: other cap, 0 = one tile per workgroup
-    static const int cap_env = [] { const char* e = getenv("HAFF_GEMM_PERSIST"); return e ? atoi(e) : 256; }();
-    cap = cap_env;
+    static const int cap_env = [] { const char* e = getenv("HAFF_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
+    if (cap_env >= 0) cap = cap_env;
 #endif
     if (cap > 0 && gx > cap) gx = cap;
   }

@@ -29,6 +29,7 @@ _PROTOS = {
                           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_bf16_heads": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_int, c_long, c_long, c_void_p],
+    "haff_gemm_persistent_cap": [c_int],
     "haff_row_stats": [c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_row_stats_finalize": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     "haff_gemm_bf16_qkv_rope": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,

@@ -12,12 +12,13 @@ Differences from the reference that do NOT change results:
   * frames / prompts are batched through the SAM encoder and decoders (reference: python loops, :157-168,494-532).
 Extension for synthetic benchmarking: `forced_answer` overrides the appended tokens (argmax still computed).
 """
+import contextlib
 import json
 import os
 
 import torch
 
-from . import ops
+from . import ops, overlap
 from .llava import ClipTowerHip, LlamaHip, _f32
 from .sam import SamEncoderHip, SamPromptDecoderHip
 
@@ -35,6 +36,13 @@ class LisaMI355:
         self.seg_token_idx = cfg.seg_token_idx
         self.sam_chunk = sam_chunk
         self._sam_stream = torch.cuda.Stream(device=self.device)
+        # How the encoder's stream shares the CUs with the decode steps (overlap.py): "auto" = the work-model plan per
+        # evaluate() call, None = every launch on all CUs, or an explicit list of workgroup caps per encoder chunk;
+        # sam_waits_for_prefill "auto" | True | False (late mode: the encoder starts behind the prefill on the GPU too).
+        self.sam_chunk_caps = "auto"
+        self.sam_waits_for_prefill = "auto"
+        self.expected_new_tokens = 8          # what the plan assumes a reply takes ("Sure, ... [SEG] ." templates) when max_new_tokens is larger
+        self._plan = (None, False, None)      # (caps, wait, chunk) of the evaluate() call in flight
         # The SAM encoder runs on its own HIP stream beside the language model and joins before the mask decoders
         # (+4-5 % frames/s); False serialises everything on the caller's stream (per-kernel measurements). Results are
         # bit-identical either way (tests/test_fullsize_gpu.py; the history of that check: DESIGN.md section 10a).
@@ -236,20 +244,45 @@ class LisaMI355:
         return out
 
     # ---- a10: SAM image encoder --------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def _chunk_cap(self, n, frames):
+        """Encoder chunk n of a `frames`-frame step: the persistent GEMM launches enqueued inside take `sam_chunk_caps[n]`
+        workgroups instead of one per CU (ops.gemm_persistent_cap), leaving CUs to the other stream's kernels. None: no cap;
+        "auto": overlap.plan, decided per evaluate() call."""
+        caps = self._plan[0]
+        cap = caps[min(n, len(caps) - 1)] if caps and self.overlap_streams else 256
+        if cap == 256:
+            yield
+            return
+        old = ops.gemm_persistent_cap(cap)
+        try:
+            yield
+        finally:
+            ops.gemm_persistent_cap(old)
+
+    def _chunk(self, frames):
+        """Frames per encoder launch sequence: `sam_chunk`, or the plan's choice for sam_chunk="auto"."""
+        c = self._plan[2] if self.sam_chunk == "auto" else self.sam_chunk
+        return int(c) if c else max(1, min(int(frames), 8))
+
     @torch.no_grad()
     def get_visual_embs(self, images):
         """LISA.py:157-168 without the per-image python loop; chunked to bound activation memory."""
         outs = []
-        for i in range(0, images.shape[0], self.sam_chunk):
-            outs.append(self.sam_encoder(images[i:i + self.sam_chunk].to(self.device)))
+        ch = self._chunk(images.shape[0])
+        for n, i in enumerate(range(0, images.shape[0], ch)):
+            with self._chunk_cap(n, images.shape[0]):
+                outs.append(self.sam_encoder(images[i:i + ch].to(self.device)))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
     @torch.no_grad()
     def get_visual_embs_u8(self, frames, mean, std):
         outs = []
-        for i in range(0, frames.shape[0], self.sam_chunk):
-            fr = frames[i:i + self.sam_chunk]
-            outs.append(self.sam_encoder.forward_rows(self.sam_encoder.patch_rows_from_u8(fr, mean, std), fr.shape[0]))
+        ch = self._chunk(frames.shape[0])
+        for n, i in enumerate(range(0, frames.shape[0], ch)):
+            fr = frames[i:i + ch]
+            with self._chunk_cap(n, frames.shape[0]):
+                outs.append(self.sam_encoder.forward_rows(self.sam_encoder.patch_rows_from_u8(fr, mean, std), fr.shape[0]))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
     @torch.no_grad()
@@ -258,12 +291,14 @@ class LisaMI355:
         resize + fused normalise/pad/patchify (cheap, HBM-bound), the patch rows are concatenated and the ViT runs batched."""
         ing, enc = self.frame_ingest(), self.sam_encoder
         outs = []
-        for i in range(0, len(frames), self.sam_chunk):
+        ch = self._chunk(len(frames))
+        for n, i in enumerate(range(0, len(frames), ch)):
             rows = []
-            for fr in frames[i:i + self.sam_chunk]:
+            for fr in frames[i:i + ch]:
                 u8, _ = ing.sam_frames(fr.to(self.device)[None], self.cfg.sam.img_size)
                 rows.append(enc.patch_rows_from_u8(u8, mean, std))
-            outs.append(enc.forward_rows(torch.cat(rows, 0) if len(rows) > 1 else rows[0], len(rows)))
+            with self._chunk_cap(n, len(frames)):
+                outs.append(enc.forward_rows(torch.cat(rows, 0) if len(rows) > 1 else rows[0], len(rows)))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
     # ---- a9: [SEG] gather + text_hidden_fcs ---------------------------------------------------------------
@@ -312,6 +347,10 @@ class LisaMI355:
 
         def launch_sam():
             side.wait_event(inputs_ready)
+            if late and wait:   # really BEHIND the prefill on the GPU too, not only in the host's enqueue order
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                side.wait_event(ev)
             with torch.cuda.stream(side):
                 if frames_u8 is not None:
                     from .preprocess import SAM_MEAN, SAM_STD
@@ -332,6 +371,19 @@ class LisaMI355:
         # too; at 64 frames the encoder is 60 % of the step and has to start first)
         late = self.overlap_streams and self.sam_beside_decode is not False and \
             (self.sam_beside_decode is True or input_ids.shape[0] <= 16)
+        # ... and which CUs its GEMM launches leave to the decode steps (overlap.py)
+        n_frames = input_ids.shape[0]
+        chunk = overlap.auto_chunk(n_frames, late) if self.sam_chunk == "auto" else self.sam_chunk
+        caps, wait = None, False
+        if self.overlap_streams:
+            if self.sam_chunk_caps == "auto":
+                caps, wait = overlap.plan(self.cfg, n_frames, chunk, input_ids.shape[1],
+                                          min(max_new_tokens, self.expected_new_tokens), late)
+            elif self.sam_chunk_caps:
+                caps, wait = list(self.sam_chunk_caps), late
+            if self.sam_waits_for_prefill != "auto":
+                wait = bool(self.sam_waits_for_prefill) and late
+        self._plan = (caps, wait, chunk)
         if not late:
             launch_sam()
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask,

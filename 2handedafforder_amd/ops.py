@@ -239,6 +239,12 @@ def linear_heads_supported(M, N, K, d, heads, dtype):
             and N // (heads * d) <= 3 and heads * d < (1 << 16) and M * K * 2 < (1 << 32) and N * K * 2 < (1 << 32))
 
 
+def gemm_persistent_cap(cap):
+    """Workgroups per launch of the persistent GEMM tile from now on (haff_gemm_persistent_cap; 256 = every CU). Returns the
+    previous setting. Scheduling only: outputs do not depend on it."""
+    return int(load_library().haff_gemm_persistent_cap(int(cap)))
+
+
 def linear_heads(x, w, bias, row_map, out, d, heads, part_stride, head_stride, ln_stats=None, ln_colsum=None):
     """x @ w.T (+ folded norm) scattered HEAD-MAJOR into `out` (haff_gemm_bf16_heads): product column part * heads * d + h * d + c of
     row m goes to out.flat[part * part_stride + h * head_stride + row_map[m] * d + c]."""

@@ -883,7 +883,12 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--text-tokens", type=int, default=32)
     ap.add_argument("--n-gen", type=int, default=8)
-    ap.add_argument("--sam-chunk", type=int, default=32)
+    ap.add_argument("--sam-chunk", default="auto",
+                    help="frames per pass of the SAM encoder: a number, or 'auto' = overlap.auto_chunk (64 frames: 16)")
+    ap.add_argument("--sam-caps", default="auto",
+                    help="workgroups per persistent GEMM launch for each encoder chunk (haff_gemm_persistent_cap), e.g. 256,256,224,224; "
+                         "'auto' = LisaMI355's rule, 'off' = one per CU everywhere (A/B)")
+    ap.add_argument("--sam-waits-for-prefill", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--fold-norms", action="store_true", help="(default since round 3 for the ViT-H geometry; kept for old command lines)")
@@ -953,11 +958,15 @@ def main(argv=None):
             sd[k] = sd[k].float()
     if args.fold_norms:
         cfg.sam.fold_norms = True
-    model = LisaMI355(cfg, sd, dtype=run_dtype, device=device, sam_chunk=args.sam_chunk,
+    model = LisaMI355(cfg, sd, dtype=run_dtype, device=device, sam_chunk="auto" if args.sam_chunk == "auto" else int(args.sam_chunk),
                       fp32_stream=False if args.fp32_stream == "off" else args.fp32_stream)
     if args.fold_norms:
         model.sam_encoder.fold_norms = True
     model.overlap_streams = not args.single_stream
+    if args.sam_waits_for_prefill != "auto":
+        model.sam_waits_for_prefill = args.sam_waits_for_prefill == "on"
+    model.sam_chunk_caps = {"auto": "auto", "off": None}.get(args.sam_caps) if args.sam_caps in ("auto", "off") else \
+        [int(c) for c in args.sam_caps.split(",")]
     if args.tables_global:
         model.sam_encoder.fused_global = False
     if args.no_fold_norms:
@@ -987,6 +996,7 @@ def main(argv=None):
     outs = []
     elapsed = hdist.timed_steps(lambda: outs.append(step()), args.steps, device)  # fence | K steps | fence | max over ranks
     out = outs[-1]
+    plan_timed = model._plan     # (workgroup caps per encoder chunk, encoder waits for the prefill, frames per chunk) of the timed steps
     ms_per_step = 1e3 * elapsed / args.steps
     fps = world * B * args.steps / elapsed
     n_ranks = rccl_ranks(device)   # one real all-reduce over the group the timing fence used: the rank count that actually ran
@@ -1072,7 +1082,11 @@ def main(argv=None):
                          "answer tokens with [SEG], KV-cached greedy decode, random-init weights; CLIP + SAM preprocessing of the "
                          "uint8 frames on the device inside the step" % (cfg.name, B, S, S, args.text_tokens, T_exp, args.n_gen),
                          B, {"hip_streams": 2 if model.overlap_streams else 1, "fp32_decoder_tail": bool(model.fp32_tail),
-                             "fp32_residual_stream": args.fp32_stream})
+                             "fp32_residual_stream": args.fp32_stream,
+                             # how the two streams shared the CUs in the timed steps (overlap.py): frames per encoder pass, workgroups per
+                             # persistent GEMM launch of each pass (null = one per CU everywhere)
+                             "sam_chunk": plan_timed[2], "sam_chunk_workgroup_caps": plan_timed[0],
+                             "sam_waits_for_prefill": plan_timed[1]})
         line["roofline"] = roofline
         line["rccl_ranks"] = n_ranks
         if f32_mode:

@@ -81,6 +81,13 @@ int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C,
 int haff_gemm_bf16_heads(const void* A, long lda, const void* W, long ldw, void* C, const float* bias, const int* row_map,
                          const float* ln_stats, const float* ln_colsum, int M, int N, int K, int d, int heads, long part_stride,
                          long head_stride, void* stream);
+/* How many workgroups a launch of the persistent 8-wave tile takes from now on (process-wide, read when a launch is enqueued;
+ * 256 = one per CU, the default). Scheduling, not arithmetic: results are bit-identical for every value. The caller lowers it for
+ * the launches of ONE stream so that kernels of another stream find free CUs while they run — LisaMI355.evaluate does for the
+ * later chunks of the SAM encoder (image_encoder.py:107-121), which run beside the HBM-bound decode steps (LISA.py:443-450) of
+ * the caller's stream. cap: a multiple of 8 in 8..256 (a workgroup's tiles stay on one XCD); anything else leaves the setting
+ * as it is. Returns the previous value. */
+int haff_gemm_persistent_cap(int cap);
 /* Llama prefill q|k|v projection with rotate-half RoPE and the KV-cache append in the epilogue (transformers
  * LlamaAttention.forward via llava_llama.py:93-102) — replaces haff_gemm_bf16 + haff_rope_cache on prefill-sized batches.
  * A bf16 [B*T][K]; Wp bf16 [3*H*d][K]: the fused q|k|v weights with the rows of every 256-row tile permuted — natural tile row

@@ -205,6 +205,32 @@ def test_gemm_bf16_192_row_tile(dev, M, N, K):
     _close(ops.linear(x, w, bias=bias, a_map=a_map), x.float()[a_map.long()] @ w.float().T + bias, 1.2e-2, "192-row tile gather")
 
 
+def test_gemm_persistent_cap_is_scheduling_only(dev):
+    """haff_gemm_persistent_cap: fewer workgroups per launch of the persistent tile (the CUs a caller leaves to another stream)
+    compute the same tiles — bit-identical outputs for every accepted value, on whole and ragged tile grids, with a fused epilogue;
+    values that are not a multiple of 8 in 8..256 are ignored; the call returns the previous setting."""
+    ops = _ops()
+    assert ops.gemm_persistent_cap(256) == 256
+    try:
+        for (M, N, K, tile) in ((16384, 1280, 1280, 0), (9000, 2560, 1280, 0), (2808, 4096, 4096, 3)):
+            x = _rand((M, K), dev, torch.bfloat16, 91)
+            w = _rand((N, K), dev, torch.bfloat16, 92, K ** -0.5)
+            bias = _rand((N,), dev, torch.float32, 93)
+            resid = _rand((M, N), dev, torch.bfloat16, 94)
+            ref = ops.linear(x, w, bias=bias, resid=resid, tile_cfg=tile)
+            for cap in (8, 96, 128, 160, 192, 216, 224, 248):
+                old = ops.gemm_persistent_cap(cap)
+                assert ops.gemm_persistent_cap(cap) == cap, (old, cap)
+                out = ops.linear(x, w, bias=bias, resid=resid, tile_cfg=tile)
+                assert torch.equal(out, ref), f"cap {cap} changed the product {M}x{N}x{K}"
+            ops.gemm_persistent_cap(224)
+            for bad in (0, 7, 100, 260, -8):
+                assert ops.gemm_persistent_cap(bad) == 224     # ignored: the setting stays
+            ops.gemm_persistent_cap(256)
+    finally:
+        ops.gemm_persistent_cap(256)
+
+
 @pytest.mark.parametrize("M,N,K", [(2808, 4096, 4096), (1500, 1280, 1280), (401, 512, 128)])
 def test_gemm_bf16_192_row_tile_row_maps(dev, M, N, K):
     """the 192 x 256 tile is picked by the launcher for any launch without a folded norm, i.e. also with an output row
