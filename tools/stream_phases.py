@@ -44,7 +44,7 @@ def wrap(obj, name, label):
 wrap(model, "encode_images", "clip+projector")
 wrap(model.llm, "forward", "prefill")
 wrap(model, "_decode_book_step", "decode step")
-wrap(model.sam_encoder, "forward_rows", "sam chunk")
+wrap(model, "get_visual_embs_u8", "sam encoder")
 wrap(model, "_decoder_tail", "decoder tail")
 
 
