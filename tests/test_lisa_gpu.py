@@ -243,6 +243,39 @@ def test_batch_invariance_and_determinism(dev):
     assert (t3[1] - t1[0]).abs().max().item() <= 2e-2
 
 
+def test_stream_schedules_do_not_change_results(dev):
+    """overlap.py / haff_gemm_persistent_cap: which CUs the encoder's GEMM launches take, how the frames are grouped into encoder
+    passes, whether the encoder's stream waits for the prefill, one stream or two — scheduling only: ids, masks and taxonomy
+    rows are bit for bit the same under every setting (here on a small geometry with 5 frames, so that the 'late' mode with a
+    real wait, several passes and a ragged last pass are all exercised; the full-size schedules, where the grouping of the
+    frames does not change the bits either: test_fullsize_gpu.py)."""
+    from haff.lisa import LisaMI355
+    cfg, sd, images, images_clip, ids, forced = _setup("mid", "bf16", B=5)
+    S = cfg.sam.img_size
+    model = LisaMI355(cfg, sd, dtype=torch.bfloat16, device=dev, sam_chunk=2)
+    args = (images_clip.to(dev), images.to(dev), ids.to(dev), [(S, S)] * 5, [(S, S)] * 5)
+
+    def run():
+        o, l, r, t = model.evaluate(*args, max_new_tokens=4, forced_answer=forced)
+        return [o] + l + r + t
+    refs = {}
+    for chunk, caps, wait, two in ((2, None, "auto", False), (2, None, "auto", True), (2, [256, 128, 64], True, True), (2, [8], True, True),
+                                   (5, None, "auto", False), (5, [224], False, True), (5, "auto", "auto", True),
+                                   (1, None, "auto", False), (1, [256, 256, 32, 32, 32], True, True),
+                                   (3, None, "auto", False), (3, [96, 160], "auto", True)):
+        model.sam_chunk, model.sam_chunk_caps, model.sam_waits_for_prefill, model.overlap_streams = chunk, caps, wait, two
+        got = run()
+        if chunk not in refs:     # (small passes take other kernels by row count: a reference per grouping, one stream, no caps)
+            assert not two and caps is None
+            refs[chunk] = got
+            continue
+        assert all(torch.equal(a, b) for a, b in zip(refs[chunk], got)), (chunk, caps, wait, two)
+        if two and caps not in (None, "auto"):
+            assert model._plan[0] == caps and model._plan[1] == (wait is True or wait == "auto")   # 5 frames: late mode
+    from haff import ops
+    assert ops.gemm_persistent_cap(256) == 256     # every evaluate() leaves the process-wide setting where it found it
+
+
 def test_sam_vith_width_windowed_blocks(dev):
     """ViT-H block geometry (dim 1280, 16 heads of 80, 14x14 windows on a 64x64 grid -> 5x5 windows with padding),
     depth cut to 3 (windowed, global, windowed): exercises the fused window-attention kernel, the pad-token
