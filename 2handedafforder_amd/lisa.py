@@ -42,7 +42,8 @@ class LisaMI355:
         self.sam_chunk_caps = "auto"
         self.sam_waits_for_prefill = "auto"
         self.expected_new_tokens = 8          # what the plan assumes a reply takes ("Sure, ... [SEG] ." templates) when max_new_tokens is larger
-        self._plan = (None, False, None)      # (caps, wait, chunk) of the evaluate() call in flight
+        self._plan = (None, False, None)      # (caps, wait, chunk) of the evaluate() call in flight (no caps outside one)
+        self.last_plan = (None, False, None)  # ... of the last evaluate() call (what bench.py reports)
         # The SAM encoder runs on its own HIP stream beside the language model and joins before the mask decoders
         # (+4-5 % frames/s); False serialises everything on the caller's stream (per-kernel measurements). Results are
         # bit-identical either way (tests/test_fullsize_gpu.py; the history of that check: DESIGN.md section 10a).
@@ -383,12 +384,13 @@ class LisaMI355:
                 caps, wait = list(self.sam_chunk_caps), late
             if self.sam_waits_for_prefill != "auto":
                 wait = bool(self.sam_waits_for_prefill) and late
-        self._plan = (caps, wait, chunk)
+        self._plan = self.last_plan = (caps, wait, chunk)
         if not late:
             launch_sam()
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask,
                                            after_prefill=launch_sam if late else None)
         emb = sam_out[0]
+        self._plan = (None, False, chunk)     # the encoder is enqueued: direct get_visual_embs* calls take no caps
         pred, frame_idx, counts = self.seg_embeddings(output_ids, hidden)
         cur.wait_stream(side)
         emb.record_stream(cur)

@@ -996,7 +996,7 @@ def main(argv=None):
     outs = []
     elapsed = hdist.timed_steps(lambda: outs.append(step()), args.steps, device)  # fence | K steps | fence | max over ranks
     out = outs[-1]
-    plan_timed = model._plan     # (workgroup caps per encoder chunk, encoder waits for the prefill, frames per chunk) of the timed steps
+    plan_timed = model.last_plan     # (workgroup caps per encoder chunk, encoder waits for the prefill, frames per chunk) of the timed steps
     ms_per_step = 1e3 * elapsed / args.steps
     fps = world * B * args.steps / elapsed
     n_ranks = rccl_ranks(device)   # one real all-reduce over the group the timing fence used: the rank count that actually ran

@@ -100,12 +100,12 @@ def test_full_size_7b_batch64_throughput_config(dev):
         return o, torch.stack(l + r), torch.stack(t)
     a = run(B)
     # the schedule bench.py times (overlap.py): encoder passes of 16 frames, the last two on 224 of the 256 CUs
-    assert model._plan == ([256, 256, 224, 224], False, 16), model._plan
+    assert model.last_plan == ([256, 256, 224, 224], False, 16), model.last_plan
     b = run(B)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), "batch-64 step is not deterministic"
     model.sam_chunk_caps = None          # every launch on all CUs: scheduling only, the bits must not move
     c = run(B)
-    assert model._plan[0] is None
+    assert model.last_plan[0] is None
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]), "the workgroup caps changed the result"
     model.sam_chunk = 32                 # ... nor with the frames grouped otherwise
     c = run(B)
@@ -143,12 +143,12 @@ def test_full_size_13b_batch8_config(dev):
     a = run()
     assert a[0].shape == (B, ids.shape[1] + 8) and a[1].shape == (2 * B, 1, S, S)
     assert bool(torch.isfinite(a[1]).all()) and bool(((a[2].sum(-1) - 1.0).abs() < 1e-3).all())
-    assert model._plan == ([128], True, 8), model._plan   # the encoder behind the prefill, on half the CUs beside the decode steps
+    assert model.last_plan == ([128], True, 8), model.last_plan   # the encoder behind the prefill, on half the CUs beside the decode steps
     b = run()
     assert all(torch.equal(x, y) for x, y in zip(a, b)), "13B step is not deterministic"
     model.sam_chunk_caps = None
     b = run()
-    assert model._plan[0] is None
+    assert model.last_plan[0] is None
     assert all(torch.equal(x, y) for x, y in zip(a, b)), "the workgroup cap changed the result (13B)"
     model.sam_chunk_caps = "auto"
     model.decode_graphs = False

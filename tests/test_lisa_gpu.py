@@ -271,7 +271,7 @@ def test_stream_schedules_do_not_change_results(dev):
             continue
         assert all(torch.equal(a, b) for a, b in zip(refs[chunk], got)), (chunk, caps, wait, two)
         if two and caps not in (None, "auto"):
-            assert model._plan[0] == caps and model._plan[1] == (wait is True or wait == "auto")   # 5 frames: late mode
+            assert model.last_plan[0] == caps and model.last_plan[1] == (wait is True or wait == "auto")   # 5 frames: late mode
     from haff import ops
     assert ops.gemm_persistent_cap(256) == 256     # every evaluate() leaves the process-wide setting where it found it
 

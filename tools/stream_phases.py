@@ -62,7 +62,7 @@ for rep in range(3):
     run()
     e1.record()
     torch.cuda.synchronize()
-    print("step %d: %.1f ms  (%d frames, plan: caps %s, encoder waits for the prefill %s, chunk %s)" % ((rep, e0.elapsed_time(e1), B) + model._plan))
+    print("step %d: %.1f ms  (%d frames, plan: caps %s, encoder waits for the prefill %s, chunk %s)" % ((rep, e0.elapsed_time(e1), B) + model.last_plan))
     dec = [m for m in marks if m[0] == "decode step"]
     for label, a, b in marks:
         if label == "decode step":
