@@ -165,7 +165,7 @@ class SamEncoderHip:
         s = self.cfg
         return ops.patchify_u8(frames, s.patch, s.grid, s.grid, 3 * s.patch * s.patch, mean, std, self.dtype)
 
-    def forward_rows(self, rows, B, taps=None):
+    def forward_rows(self, rows, B, taps=None, out=None):
         s = self.cfg
         C, g, H, hd = s.embed_dim, s.grid, s.heads, self.hd
         N = g * g
@@ -175,7 +175,7 @@ class SamEncoderHip:
                 self._pos32 = self.pos.float()
             x = ops.linear(rows, self.w_patch, bias=self.b_patch, out_dtype=torch.float32)
             x = ops.add_bcast(x, self._pos32, mod=N, out=x)
-            return self._forward_rows_fp32_stream(x, B, taps)
+            return self._forward_rows_fp32_stream(x, B, taps, out)
         x = ops.linear(rows, self.w_patch, bias=self.b_patch)
         x = ops.add_bcast(x, self.pos, mod=N, out=x)
         scale = hd ** -0.5
@@ -255,10 +255,11 @@ class SamEncoderHip:
         y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
         cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
         y = ops.linear(cols, self.w_neck2, out_dtype=torch.float32 if self.emb_f32 else None)
-        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6)
+        # (out: a [B, N, out_chans] slice of the caller's embedding buffer — several passes fill one tensor, no torch.cat)
+        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6, out=None if out is None else out.view(B * N, s.out_chans))
         return y.view(B, N, s.out_chans)
 
-    def _forward_rows_fp32_stream(self, x, B, taps=None):
+    def _forward_rows_fp32_stream(self, x, B, taps=None, out=None):
         """The blocks on an fp32 residual stream x [B*N, C] (see fp32_stream): LayerNorm kernels fp32 -> bf16, bf16 MFMA products,
         proj / lin2 with fp32 residual in and fp32 out (haff_gemm_bf16*'s out_f32 epilogue). image_encoder.py:177-193."""
         s = self.cfg
@@ -307,7 +308,8 @@ class SamEncoderHip:
         y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
         cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
         y = ops.linear(cols, self.w_neck2, out_dtype=torch.float32 if self.emb_f32 else None)
-        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6)
+        # (out: a [B, N, out_chans] slice of the caller's embedding buffer — several passes fill one tensor, no torch.cat)
+        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6, out=None if out is None else out.view(B * N, s.out_chans))
         return y.view(B, N, s.out_chans)
 
     def __call__(self, images, taps=None):
