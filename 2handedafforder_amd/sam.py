@@ -9,6 +9,8 @@ but batched over frames and prompts, channels-last everywhere, weights re-laid-o
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -438,9 +440,10 @@ class SamPromptDecoderHip:
         self.left = SamDecoderSideHip(sd, V + ".mask_decoder_left", cfg, dtype, device, True)
         self.right = SamDecoderSideHip(sd, V + ".mask_decoder_right", cfg, dtype, device, False)
         # a handful of prompts: the two decoders are two independent chains of ~70 latency-bound launches each; they run
-        # side by side on two HIP streams (inside the tail's hipGraph: two parallel branches). Many prompts fill the chip
-        # per launch and stay on one stream.
+        # side by side on two HIP streams (inside the tail's hipGraph: two parallel branches) — at every prompt count (round 5).
         self.pair_streams = True
+        self.pair_max_prompts = 1 << 30   # (rounds 1-4: 8 — "many prompts fill the chip"; but at 64 prompts the TOKEN-side products
+                                          # are still 8-workgroup latency chains of 33 us each: side by side +0.4 % of the 64-frame step)
         self._pair_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
     def decode(self, emb, frame_idx, text, taps=None):
@@ -449,7 +452,7 @@ class SamPromptDecoderHip:
         N, C = emb.shape[1], emb.shape[2]
         src = emb.index_select(0, frame_idx).reshape(P * N, C).to(self.dtype)
         src = ops.add_bcast(src, self.no_mask, mod=1).view(P, N, C)
-        if self.pair_streams and self._pair_stream is not None and P <= 8 and taps is None:
+        if self.pair_streams and self._pair_stream is not None and P <= self.pair_max_prompts and taps is None:
             cur, side = torch.cuda.current_stream(self.device), self._pair_stream
             capturing = torch.cuda.is_current_stream_capturing()
             side.wait_stream(cur)
