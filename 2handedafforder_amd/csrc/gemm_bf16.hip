@@ -33,6 +33,7 @@
 
 #include <cstdlib>
 #include "haff_common.h"
+#include <mutex>
 
 // Tuning hooks (ablation switches HAFF_EXP_*, phase traces HAFF_GEMM_TRACE / _TRACE2, A/B switches HAFF_EPI_LDS /
 // HAFF_GEMM_NO_NT / HAFF_GEMM_GELU_SCALAR, environment overrides of the raster) exist only in builds made with
@@ -1685,12 +1686,44 @@ static void launch_skinny(const GemmArgs& p, int N, int swiglu, hipStream_t s) {
 
 // Workgroups a persistent 8-wave launch takes (one per CU: 256 fills the chip). A caller that wants CUs left over for
 // kernels of ANOTHER stream (HBM-bound decode steps beside the MFMA-bound encoder) lowers it for the launches it
-// enqueues meanwhile; multiples of 8 keep a workgroup's tiles on one XCD.
-static int g_persist_cap = 256;
-extern "C" int haff_gemm_persistent_cap(int cap) {
-  const int old = g_persist_cap;
-  if (cap >= 8 && cap <= 256 && (cap & 7) == 0) g_persist_cap = cap;
-  return old;
+// enqueues on ITS stream; multiples of 8 keep a workgroup's tiles on one XCD. The setting belongs to a stream (round 6;
+// rounds 5's was one process-wide int: two models or two host threads in one process raced on it): a small table keyed by
+// hipStream_t behind a mutex, entries at 256 are dropped, so it holds only streams that are capped right now.
+namespace {
+struct StreamCapTable {
+  static constexpr int kSlots = 32;
+  std::mutex mu;
+  void* stream[kSlots];
+  int cap[kSlots];
+  int n = 0;
+  int get(void* s) {
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < n; ++i)
+      if (stream[i] == s) return cap[i];
+    return 256;
+  }
+  // returns the previous cap of the stream, -1 when the table is full
+  int set(void* s, int c) {
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < n; ++i)
+      if (stream[i] == s) {
+        const int old = cap[i];
+        if (c == 256) { stream[i] = stream[n - 1]; cap[i] = cap[n - 1]; --n; }
+        else cap[i] = c;
+        return old;
+      }
+    if (c == 256) return 256;
+    if (n == kSlots) return -1;
+    stream[n] = s; cap[n] = c; ++n;
+    return 256;
+  }
+};
+StreamCapTable g_stream_caps;
+}  // namespace
+extern "C" int haff_gemm_stream_cap(void* stream, int cap) {
+  if (!(cap >= 8 && cap <= 256 && (cap & 7) == 0)) return g_stream_caps.get(stream);   // not a valid cap: a query
+  const int old = g_stream_caps.set(stream, cap);
+  return old < 0 ? HAFF_ERR_UNSUPPORTED : old;
 }
 
 static bool haff_gemm_spec_enabled() {
@@ -1707,7 +1740,7 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   int gx = tiles;
   if (WM * WN == 8) {   // persistent 8-wave tile: one workgroup per CU
-    int cap = g_persist_cap;
+    int cap = g_stream_caps.get((void*)s);
 #ifdef HAFF_TUNING       // HAFF_GEMM_PERSIST: other cap, 0 = one tile per workgroup
     static const int cap_env = [] { const char* e = getenv("HAFF_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
     if (cap_env >= 0) cap = cap_env;

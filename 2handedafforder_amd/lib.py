@@ -29,7 +29,7 @@ _PROTOS = {
                           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_bf16_heads": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_int, c_long, c_long, c_void_p],
-    "haff_gemm_persistent_cap": [c_int],
+    "haff_gemm_stream_cap": [c_void_p, c_int],
     "haff_row_stats": [c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_row_stats_finalize": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     "haff_gemm_bf16_qkv_rope": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
@@ -163,6 +163,19 @@ def build_library(verbose=False):
     if res.returncode != 0:
         raise HaffLibraryError("hipcc build of libhaff_hip.so failed")
     return LIB_PATH
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the HIP sources the library is built from: what profiles/pmc_gemm_traffic.json is stamped with,
+    so bench.py never reports PMC traffic collected on another tree as this run's."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC_DIR)):
+        if name.endswith((".hip", ".h", ".inc")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(CSRC_DIR, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load_library():

@@ -248,18 +248,18 @@ class LisaMI355:
     @contextlib.contextmanager
     def _chunk_cap(self, n, frames):
         """Encoder chunk n of a `frames`-frame step: the persistent GEMM launches enqueued inside take `sam_chunk_caps[n]`
-        workgroups instead of one per CU (ops.gemm_persistent_cap), leaving CUs to the other stream's kernels. None: no cap;
+        workgroups instead of one per CU (ops.gemm_stream_cap on the stream they are enqueued on), leaving CUs to the other stream's kernels. None: no cap;
         "auto": overlap.plan, decided per evaluate() call."""
         caps = self._plan[0]
         cap = caps[min(n, len(caps) - 1)] if caps and self.overlap_streams else 256
         if cap == 256:
             yield
             return
-        old = ops.gemm_persistent_cap(cap)
+        old = ops.gemm_stream_cap(cap)
         try:
             yield
         finally:
-            ops.gemm_persistent_cap(old)
+            ops.gemm_stream_cap(old)
 
     def _chunk(self, frames):
         """Frames per encoder launch sequence: `sam_chunk`, or the plan's choice for sam_chunk="auto"."""

@@ -239,10 +239,15 @@ def linear_heads_supported(M, N, K, d, heads, dtype):
             and N // (heads * d) <= 3 and heads * d < (1 << 16) and M * K * 2 < (1 << 32) and N * K * 2 < (1 << 32))
 
 
-def gemm_persistent_cap(cap):
-    """Workgroups per launch of the persistent GEMM tile from now on (haff_gemm_persistent_cap; 256 = every CU). Returns the
-    previous setting. Scheduling only: outputs do not depend on it."""
-    return int(load_library().haff_gemm_persistent_cap(int(cap)))
+def gemm_stream_cap(cap, stream=None):
+    """Workgroups per launch of the persistent GEMM tile for launches enqueued on `stream` (a torch stream; default: the current
+    one) from now on (haff_gemm_stream_cap; 256 = every CU). Returns the stream's previous setting. Scheduling only: outputs do
+    not depend on it, launches on other streams are unaffected."""
+    s = _stream() if stream is None else stream.cuda_stream
+    rc = int(load_library().haff_gemm_stream_cap(s, int(cap)))
+    if rc < 0:
+        check(rc, "haff_gemm_stream_cap")
+    return rc
 
 
 def linear_heads(x, w, bias, row_map, out, d, heads, part_stride, head_stride, ln_stats=None, ln_colsum=None):

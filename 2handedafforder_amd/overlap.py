@@ -4,7 +4,7 @@ The SAM encoder (MFMA-bound, persistent GEMM tiles that fill every CU) runs on a
 decode on the caller's stream (LISA.py:432-534: the two halves only meet at the mask decoders). The decode steps are weight
 streams: launched beside a GEMM that owns all 256 CUs they wait for it, launched after it they leave the matrix cores idle.
 So for the part of the encoder that runs WHILE the decode steps run, its GEMM launches take `cap` < 256 workgroups
-(`haff_gemm_persistent_cap`) and the decode kernels run on the CUs left over; the cap balances the two so that they finish
+(`haff_gemm_stream_cap`) and the decode kernels run on the CUs left over; the cap balances the two so that they finish
 together. Results never depend on it (a launch computes the same tiles with fewer workgroups).
 
 The plan is static (the host enqueues the encoder before the decode steps exist) and comes from a small work model whose three

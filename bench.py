@@ -614,6 +614,103 @@ def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf1
     return {"parity": par, "cpu_frame": cpu}
 
 
+LINE_BUDGET_BYTES = 4096   # the driver keeps a bounded tail of stdout: round 5's 20.7 KB line was not parsed (BENCH_r05.json)
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(full):
+    """The ONE stdout line the driver parses: the contract's keys + roofline + cpu_baseline + the parity summary of the timed mode,
+    every nested diagnostic (by_shape, the per-geometry parity objects, extrapolations ...) left to bench_detail.json. Pure function
+    of the full line object (tests/test_bench_line_cpu.py holds it to LINE_BUDGET_BYTES)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: full[k] for k in keep if k in full}     # the contract's numbers at full precision
+    cfg = dict(full.get("config") or {})
+    if isinstance(cfg.get("workload"), str) and len(cfg["workload"]) > 400:
+        cfg["workload"] = cfg["workload"][:397] + "..."
+    out["config"] = cfg
+    rf = full.get("roofline")
+    if rf:
+        r_keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch_avg",
+                  "launches_per_step", "avg_launch_us", "gemm_share_of_step")
+        out["roofline"] = {k: _r(rf.get(k)) for k in r_keep if k in rf}
+        if isinstance(out["roofline"].get("kernel"), str):
+            out["roofline"]["kernel"] = out["roofline"]["kernel"][:120]
+        if rf.get("whole_path"):
+            out["roofline"]["whole_path_frac"] = _r(rf["whole_path"].get("frac"))
+        ws = rf.get("weight_streaming_gemm")
+        if ws and ws.get("achieved"):
+            out["roofline"]["weight_streaming_GBps"] = _r(ws["achieved"], 1)
+    else:
+        out["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb:
+        c_keep = ("value", "unit", "cores", "kind", "seconds_per_frame", "extrapolated")
+        out["cpu_baseline"] = {k: _r(cb.get(k), 6) for k in c_keep if k in cb}
+        smp = cb.get("sample") or ""
+        out["cpu_baseline"]["sample"] = smp if len(smp) <= 300 else smp[:297] + "..."
+    else:
+        out["cpu_baseline"] = None
+    par = full.get("parity")
+    if par:
+        p = {"timed_mode": par.get("timed_mode"), "reference": "oracle/lisa_oracle.py (CPU fp32 restatement of LISA.py:432-534)"}
+        ff = par.get("full_frame") or {}
+        tm = ff.get(par.get("timed_mode") or "bf16") or {}
+        if tm:
+            p.update({"geometry": "one full-depth frame of the timed config", "mask_iou_min": _r(tm.get("mask_iou_min"), 5),
+                      "mask_iou_left_right": [_r((tm.get(h) or {}).get("mask_iou"), 5) for h in ("left", "right")],
+                      "logit_max_rel_err": _r(tm.get("logit_max_rel_err"), 6), "token_ids_equal": tm.get("token_ids_equal")})
+        elif par.get("tiny"):
+            tm = par["tiny"].get(par.get("timed_mode") or "bf16") or {}
+            p.update({"geometry": "tiny (configs[0]); full-depth frame skipped", "mask_iou_min": _r(tm.get("mask_iou_vs_oracle"), 5),
+                      "logit_max_rel_err": _r(tm.get("mask_logit_max_err_rel"), 6), "token_ids_equal": tm.get("token_ids_equal")})
+        f32 = ff.get("fp32") or {}
+        if f32:
+            p["fp32_mask_iou_min"] = _r(f32.get("mask_iou_min"), 5)
+            p["fp32_logit_max_abs_err"] = _r(f32.get("logit_max_abs_err"), 8)
+        p["meets_iou_0.999"] = bool(p.get("mask_iou_min") is not None and p["mask_iou_min"] >= 0.999)
+        p["gate_failed"] = (par.get("gate") or {}).get("failed")
+        out["parity"] = p
+    for k in ("rccl_ranks", "frames_per_s_per_gpu", "samples_per_s_per_gpu", "latency_batch1_ms", "outputs_finite", "detail",
+              "host_enqueue_ms_per_step", "peak_hbm_gb"):
+        if k in full:
+            out[k] = _r(full[k])
+    d1 = full.get("decode_step_batch1")
+    if d1:
+        out["decode_step_batch1"] = {"ms": _r(d1.get("ms")), "achieved_TBps": _r(d1.get("achieved_TBps")), "peak_TBps": d1.get("peak_TBps")}
+    s = json.dumps(out)
+    if len(s) > LINE_BUDGET_BYTES:     # never let a long free-text field push the line over: shorten those, keep every number
+        for path in (("config", "workload"), ("cpu_baseline", "sample"), ("roofline", "kernel"), ("config", "parallelism")):
+            o = out.get(path[0])
+            if isinstance(o, dict) and isinstance(o.get(path[1]), str):
+                o[path[1]] = o[path[1]][:80]
+        s = json.dumps(out)
+    assert len(s) <= LINE_BUDGET_BYTES, len(s)
+    return out
+
+
+def emit(full):
+    """Everything measured goes to bench_detail.json (under gpurun_out/ so it travels back from a GPU box; beside this file
+    otherwise); stdout gets the compact line and NOTHING after it."""
+    dst = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail.json")
+            with open(path, "w") as fh:
+                json.dump(full, fh, indent=1)
+            dst = os.path.relpath(path, ROOT)
+            break
+        except OSError:
+            continue
+    full["detail"] = dst
+    sys.stderr.flush()
+    print(json.dumps(compact_line(full)), flush=True)
+
+
 def base_line(fps, world, steps, warmup, ms_per_step, workload, B, extra_cfg):
     cfg = {"workload": workload, "frames_per_step_per_gpu": B,
            "parallelism": "frame-sharded replicas x%d (no collective)" % world}
@@ -808,7 +905,7 @@ def train_main(args):
                 "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_train_baseline(cfg, args.train_ids, (args.train_mask, args.train_mask), min(len(os.sched_getaffinity(0)), 32))
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -833,7 +930,7 @@ def stub_main(args):
                          "stub (sleep %.0f ms per step)" % args.stub_step_ms, B, {"stub": True})
         line["cpu_baseline"] = None
         line["rccl_ranks"] = n_ranks
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -886,7 +983,7 @@ def main(argv=None):
     ap.add_argument("--sam-chunk", default="auto",
                     help="frames per pass of the SAM encoder: a number, or 'auto' = overlap.auto_chunk (64 frames: 16)")
     ap.add_argument("--sam-caps", default="auto",
-                    help="workgroups per persistent GEMM launch for each encoder chunk (haff_gemm_persistent_cap), e.g. 256,256,224,224; "
+                    help="workgroups per persistent GEMM launch for each encoder chunk (haff_gemm_stream_cap), e.g. 256,256,224,224; "
                          "'auto' = LisaMI355's rule, 'off' = one per CU everywhere (A/B)")
     ap.add_argument("--sam-waits-for-prefill", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--single-stream", action="store_true",
@@ -914,8 +1011,10 @@ def main(argv=None):
                          "(LisaMI355(fp32_stream=...): 2-3x closer to the reference at depth 32; DESIGN.md section 2)")
     ap.add_argument("--no-full-frame-parity", action="store_true",
                     help="parity: skip the one full-depth frame against the oracle on shared weights (~31 GB host RAM, ~1 min of CPU)")
-    ap.add_argument("--no-attribution", action="store_true",
-                    help="full-frame parity: skip the oracle's per-stack bf16-points passes (~35 s of CPU)")
+    ap.add_argument("--attribution", action="store_true",
+                    help="full-frame parity: add the oracle's per-stack bf16-points passes (~45 s of CPU; off by default since round 6: "
+                         "the default run is the driver's bench, tools/full_frame_parity.py is where attribution lives)")
+    ap.add_argument("--no-attribution", action="store_true", help="(default since round 6; kept for old command lines)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: BASELINE configs[2] (the headline metric); train: configs[3], one LoRA fine-tune step per step")
     ap.add_argument("--materialised-attention", action="store_true",
@@ -1037,9 +1136,13 @@ def main(argv=None):
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            if pmc.get("config") == cfg.name and pmc.get("batch") == B:
+            from haff import lib as hlib
+            if pmc.get("config") == cfg.name and pmc.get("batch") == B and pmc.get("library_source_sha16") == hlib.source_hash():
                 traffic = pmc["hbm_bytes_per_launch"]
                 traffic_src = "profiles/pmc_gemm_traffic.json (%s)" % pmc.get("collected", "")
+            else:   # collected on another tree / workload: not this run's traffic
+                traffic_src = "profiles/pmc_gemm_traffic.json does not match this tree (config %s, batch %s, csrc sha %s vs %s): null" % (
+                    pmc.get("config"), pmc.get("batch"), pmc.get("library_source_sha16"), hlib.source_hash())
         f32_mode = run_dtype == torch.float32
         if f32_mode:   # the parity mode: every product is gemm_f32_kernel (f32-input MFMA, 157.3 TFLOP/s dense)
             n_launch, gemm_ms, gemm_fl = f32_n, f32_ms, f32_fl
@@ -1134,7 +1237,7 @@ def main(argv=None):
             del model
             model = None
             torch.cuda.empty_cache()
-            full_parity = parity_full_frame(cfg, device, threads, args.text_tokens, args.n_gen, attribution=not args.no_attribution)
+            full_parity = parity_full_frame(cfg, device, threads, args.text_tokens, args.n_gen, attribution=args.attribution)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.text_tokens, args.n_gen, threads)
             if not args.no_cpu_full_frame:
@@ -1159,10 +1262,12 @@ def main(argv=None):
         if world == 1 and not args.no_parity:
             del model
             line["parity"] = parity_vs_oracle(device)
+            # which entry of the parity objects belongs to the number this line prints (the compact line quotes that one)
+            line["parity"]["timed_mode"] = "fp32" if f32_mode else ("bf16" if args.fp32_stream == "off" else "bf16_fp32_stream")
             if full_parity is not None:
                 line["parity"]["full_frame"] = full_parity.get("parity", full_parity)
                 line["parity"]["gate"]["failed"] += (full_parity.get("parity") or {}).get("gate", {}).get("failed", [])
-        print(json.dumps(line), flush=True)
+        emit(line)
         if (line.get("parity") or {}).get("gate", {}).get("failed"):
             print("parity gate failed: " + ", ".join(line["parity"]["gate"]["failed"]), file=sys.stderr)
             exit_code = 3

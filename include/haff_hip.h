@@ -7,8 +7,10 @@
  * maintainer binds with ctypes from the reference's own modules.
  *
  * Conventions
- *   - all pointers are caller-owned DEVICE pointers (HBM) unless marked "host"; no internal allocation, no global
- *     state, re-entrant; `stream` is a hipStream_t passed as void* (0 = null stream); kernels are only enqueued.
+ *   - all pointers are caller-owned DEVICE pointers (HBM) unless marked "host"; no internal allocation; re-entrant;
+ *     `stream` is a hipStream_t passed as void* (0 = null stream); kernels are only enqueued. No process-wide setting:
+ *     the one piece of state the library keeps is haff_gemm_stream_cap's table, keyed by stream and guarded by a mutex
+ *     (scheduling only, results never depend on it) — host threads that enqueue on different streams do not interact.
  *   - return value: 0 ok, -1 bad argument, -2 unsupported shape, -3 launch error. No exceptions cross the ABI.
  *   - dtype codes: 0 = bf16 (raw 16-bit payload), 1 = f32. bf16 = throughput mode (bf16 MFMA, fp32 accumulate,
  *     fp32 softmax/norm statistics); f32 = parity mode (every op in fp32, for the 1e-3 mask-logit criterion).
@@ -81,13 +83,15 @@ int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C,
 int haff_gemm_bf16_heads(const void* A, long lda, const void* W, long ldw, void* C, const float* bias, const int* row_map,
                          const float* ln_stats, const float* ln_colsum, int M, int N, int K, int d, int heads, long part_stride,
                          long head_stride, void* stream);
-/* How many workgroups a launch of the persistent 8-wave tile takes from now on (process-wide, read when a launch is enqueued;
- * 256 = one per CU, the default). Scheduling, not arithmetic: results are bit-identical for every value. The caller lowers it for
- * the launches of ONE stream so that kernels of another stream find free CUs while they run — LisaMI355.evaluate does for the
- * later chunks of the SAM encoder (image_encoder.py:107-121), which run beside the HBM-bound decode steps (LISA.py:443-450) of
- * the caller's stream. cap: a multiple of 8 in 8..256 (a workgroup's tiles stay on one XCD); anything else leaves the setting
- * as it is. Returns the previous value. */
-int haff_gemm_persistent_cap(int cap);
+/* How many workgroups the persistent 8-wave tile launches enqueued ON `stream` take from now on (256 = one per CU, the default;
+ * read when a launch is enqueued or captured). Scheduling, not arithmetic: results are bit-identical for every value. The caller
+ * lowers it for the launches of ONE stream so that kernels of another stream find free CUs while they run — LisaMI355.evaluate does
+ * for the later passes of the SAM encoder (image_encoder.py:107-121) on its encoder stream, which run beside the HBM-bound decode
+ * steps (LISA.py:443-450) of the caller's stream. The setting is per stream (round 5's was process-wide: two models or two host
+ * threads raced on it): launches on other streams are unaffected. cap: a multiple of 8 in 8..256 (a workgroup's tiles stay on one
+ * XCD); any other value changes nothing (a query). Returns the stream's previous cap (256 when it had none), or
+ * HAFF_ERR_UNSUPPORTED (-2) when 32 streams are capped at once. Setting 256 releases the stream's entry. */
+int haff_gemm_stream_cap(void* stream, int cap);
 /* Llama prefill q|k|v projection with rotate-half RoPE and the KV-cache append in the epilogue (transformers
  * LlamaAttention.forward via llava_llama.py:93-102) — replaces haff_gemm_bf16 + haff_rope_cache on prefill-sized batches.
  * A bf16 [B*T][K]; Wp bf16 [3*H*d][K]: the fused q|k|v weights with the rows of every 256-row tile permuted — natural tile row

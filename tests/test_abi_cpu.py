@@ -34,6 +34,42 @@ def test_library_exports_every_declared_symbol():
     haff.load_library()
 
 
+def test_stream_caps_are_per_stream_and_thread_safe():
+    """haff_gemm_stream_cap keeps ONE table keyed by stream (no process-wide setting: include/haff_hip.h, conventions): a cap set for
+    one stream is invisible to another, 256 releases the entry, invalid values are queries, the 33rd simultaneously capped stream is
+    refused, and host threads hammering their own streams never see each other's values. Touches no GPU (nothing is launched)."""
+    import threading
+    lib = haff.load_library()
+    cap = lambda s, c: int(lib.haff_gemm_stream_cap(ctypes.c_void_p(s), c))   # noqa: E731
+    A, B = 0x1000, 0x2000
+    assert cap(A, 0) == 256 and cap(B, 0) == 256 and cap(0, 0) == 256
+    assert cap(A, 224) == 256 and cap(B, 128) == 256
+    assert cap(A, 0) == 224 and cap(B, 0) == 128 and cap(0, 0) == 256        # the null stream is a stream of its own
+    for bad in (7, 100, 260, -8):
+        assert cap(A, bad) == 224                                             # not a multiple of 8 in 8..256: a query
+    assert cap(A, 192) == 224 and cap(B, 0) == 128
+    assert cap(A, 256) == 192 and cap(A, 0) == 256 and cap(B, 0) == 128       # released
+    assert cap(B, 256) == 128
+    keys = [0x10000 + 64 * i for i in range(32)]
+    assert all(cap(k, 64) == 256 for k in keys)
+    assert cap(0x99999, 64) == -2                                             # table full: refused, nothing changed
+    assert all(cap(k, 256) == 64 for k in keys) and cap(0x99999, 0) == 256
+    bad = []
+
+    def worker(key, mine):
+        for _ in range(2000):
+            if cap(key, mine) not in (256, mine):
+                bad.append(key)
+            if cap(key, 0) != mine:
+                bad.append(key)
+            if cap(key, 256) != mine:
+                bad.append(key)
+    ts = [threading.Thread(target=worker, args=(0x5000 + 8 * i, 8 * (i + 1))) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -244,7 +244,7 @@ def test_batch_invariance_and_determinism(dev):
 
 
 def test_stream_schedules_do_not_change_results(dev):
-    """overlap.py / haff_gemm_persistent_cap: which CUs the encoder's GEMM launches take, how the frames are grouped into encoder
+    """overlap.py / haff_gemm_stream_cap: which CUs the encoder's GEMM launches take, how the frames are grouped into encoder
     passes, whether the encoder's stream waits for the prefill, one stream or two — scheduling only: ids, masks and taxonomy
     rows are bit for bit the same under every setting (here on a small geometry with 5 frames, so that the 'late' mode with a
     real wait, several passes and a ragged last pass are all exercised; the full-size schedules, where the grouping of the
@@ -273,7 +273,8 @@ def test_stream_schedules_do_not_change_results(dev):
         if two and caps not in (None, "auto"):
             assert model.last_plan[0] == caps and model.last_plan[1] == (wait is True or wait == "auto")   # 5 frames: late mode
     from haff import ops
-    assert ops.gemm_persistent_cap(256) == 256     # every evaluate() leaves the process-wide setting where it found it
+    # every evaluate() leaves both streams' settings where it found them
+    assert ops.gemm_stream_cap(0) == 256 and ops.gemm_stream_cap(0, stream=model._sam_stream) == 256
 
 
 def test_sam_vith_width_windowed_blocks(dev):

@@ -205,12 +205,14 @@ def test_gemm_bf16_192_row_tile(dev, M, N, K):
     _close(ops.linear(x, w, bias=bias, a_map=a_map), x.float()[a_map.long()] @ w.float().T + bias, 1.2e-2, "192-row tile gather")
 
 
-def test_gemm_persistent_cap_is_scheduling_only(dev):
-    """haff_gemm_persistent_cap: fewer workgroups per launch of the persistent tile (the CUs a caller leaves to another stream)
-    compute the same tiles — bit-identical outputs for every accepted value, on whole and ragged tile grids, with a fused epilogue;
-    values that are not a multiple of 8 in 8..256 are ignored; the call returns the previous setting."""
+def test_gemm_stream_cap_is_scheduling_only_and_per_stream(dev):
+    """haff_gemm_stream_cap: fewer workgroups per launch of the persistent tile ON ONE STREAM (the CUs a caller leaves to another
+    stream) compute the same tiles — bit-identical outputs for every accepted value, on whole and ragged tile grids, with a fused
+    epilogue; values that are not a multiple of 8 in 8..256 change nothing; the call returns the stream's previous setting; a cap
+    set on one stream is not seen by launches (or queries) on another."""
     ops = _ops()
-    assert ops.gemm_persistent_cap(256) == 256
+    other = torch.cuda.Stream(device=dev)
+    assert ops.gemm_stream_cap(256) == 256
     try:
         for (M, N, K, tile) in ((16384, 1280, 1280, 0), (9000, 2560, 1280, 0), (2808, 4096, 4096, 3)):
             x = _rand((M, K), dev, torch.bfloat16, 91)
@@ -219,16 +221,29 @@ def test_gemm_persistent_cap_is_scheduling_only(dev):
             resid = _rand((M, N), dev, torch.bfloat16, 94)
             ref = ops.linear(x, w, bias=bias, resid=resid, tile_cfg=tile)
             for cap in (8, 96, 128, 160, 192, 216, 224, 248):
-                old = ops.gemm_persistent_cap(cap)
-                assert ops.gemm_persistent_cap(cap) == cap, (old, cap)
+                old = ops.gemm_stream_cap(cap)
+                assert ops.gemm_stream_cap(cap) == cap, (old, cap)
+                assert ops.gemm_stream_cap(0, stream=other) == 256          # the other stream keeps its own (default) setting
                 out = ops.linear(x, w, bias=bias, resid=resid, tile_cfg=tile)
                 assert torch.equal(out, ref), f"cap {cap} changed the product {M}x{N}x{K}"
-            ops.gemm_persistent_cap(224)
+            ops.gemm_stream_cap(224)
             for bad in (0, 7, 100, 260, -8):
-                assert ops.gemm_persistent_cap(bad) == 224     # ignored: the setting stays
-            ops.gemm_persistent_cap(256)
+                assert ops.gemm_stream_cap(bad) == 224     # a query: the setting stays
+            # two capped streams at once: each keeps its own value, launches on both give the same bits
+            assert ops.gemm_stream_cap(64, stream=other) == 256
+            torch.cuda.current_stream().synchronize()
+            other.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(other):
+                assert ops.gemm_stream_cap(0) == 64
+                out2 = ops.linear(x, w, bias=bias, resid=resid, tile_cfg=tile)
+            assert ops.gemm_stream_cap(0) == 224
+            other.synchronize()
+            assert torch.equal(out2, ref)
+            assert ops.gemm_stream_cap(256, stream=other) == 64
+            ops.gemm_stream_cap(256)
     finally:
-        ops.gemm_persistent_cap(256)
+        ops.gemm_stream_cap(256)
+        ops.gemm_stream_cap(256, stream=other)
 
 
 @pytest.mark.parametrize("M,N,K", [(2808, 4096, 4096), (1500, 1280, 1280), (401, 512, 128)])

@@ -57,7 +57,11 @@ def main():
         write = 1024.0 * w[k][1] / w[k][0] if k in w else 0.0
         table[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write}
     g = table["gemm_bf16_kernel"]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import haff  # noqa: F401
+    from haff import lib as hlib
     res = {"config": config, "batch": batch, "kernel": "gemm_bf16_kernel",
+           "library_source_sha16": hlib.source_hash(),   # bench.py reports traffic: null when the tree's sources differ
            "launches_profiled": g["launches"],
            "hbm_bytes_per_launch": g["fetch_bytes_per_launch"] + g["write_bytes_per_launch"],
            "fetch_bytes_per_launch": g["fetch_bytes_per_launch"], "write_bytes_per_launch": g["write_bytes_per_launch"],

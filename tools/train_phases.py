@@ -43,11 +43,11 @@ def wrap(obj, name, label):
 
 def capped(fn):
     def inner(*a, **kw):
-        old = ops.gemm_persistent_cap(cap)
+        old = ops.gemm_stream_cap(cap)
         try:
             return fn(*a, **kw)
         finally:
-            ops.gemm_persistent_cap(old)
+            ops.gemm_stream_cap(old)
     return inner
 
 
