@@ -4,7 +4,7 @@ Mirrors `2Haff/utils/aff_dataset.py:48-346` (`AffDataset`) for records of the pu
 (`_load_from_huggingface`, :117-150): each record carries `narration` (or `text`), `image` (or `inpainted`), `taxonomy`
 and `masks = {aff_left: [contour, ...], aff_right: [...], original_size: (h, w)}` with OpenCV-style contours
 (lists of (x, y) points). `__getitem__` reproduces :198-280: a RANDOM record per call (the reference ignores `idx`),
-masks re-drawn from the contours, the question/answer templates of :29-46, one llava_v1 conversation, CLIP and SAM
+masks re-drawn from the contours, the question/answer templates of :29-46, one conversation of the default template (llava_v1 unless train_ds.py --conv_type says otherwise), CLIP and SAM
 preprocessing, and the 11/12-tuple that `collate_fn` (utils/dataset.py:30-169 = train_ds.collate_fn here) consumes.
 
 `AffValDataset` mirrors `AffDatasetVal` (:350-544): the benchmark folder walk (`<root>/<video>/<frame>/{inpainting.png,
@@ -186,7 +186,7 @@ class AffRecordsDataset(torch.utils.data.Dataset):
         image_t = preprocess.sam_preprocess(resized, cfg.sam.img_size)
         question = self.rng.choice(SHORT_QUESTION_LIST).format(class_name=text.lower())
         answer = self.rng.choice(ANSWER_LIST)
-        conv = hprompt.conv_llava_v1()
+        conv = hprompt.default_conversation()
         conv.append_message(conv.roles[0], question)
         conv.append_message(conv.roles[1], answer)
         out = (None, image_t, image_clip, [conv.get_prompt()], torch.from_numpy(left).unsqueeze(0),
@@ -254,7 +254,7 @@ class AffValDataset(torch.utils.data.Dataset):
         image_t = preprocess.sam_preprocess(resized, cfg.sam.img_size)
         question = self.rng.choice(SHORT_QUESTION_LIST).format(class_name=text.lower())
         answer = self.rng.choice(ANSWER_LIST)
-        conv = hprompt.conv_llava_v1()
+        conv = hprompt.default_conversation()
         conv.append_message(conv.roles[0], question)
         conv.append_message(conv.roles[1], answer)
         return (None, image_t, image_clip, [conv.get_prompt()], torch.from_numpy(left).unsqueeze(0),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interactive CLI — same flags, prompts and output files as the reference's 2Haff/chat.py (:66-269): reads a text
-prompt and an image path from stdin, wraps the prompt in the llava_v1 template, runs LisaMI355.evaluate() on the
+prompt and an image path from stdin, wraps the prompt in the --conv_type template (llava_v1 / llava_llama_2, :155), runs LisaMI355.evaluate() on the
 MI355X, prints the decoded text and writes <name>_mask_left<i>.jpg, <name>_mask_right<i>.jpg (mask*100) and the
 red/blue overlay <name>_masked_img_<i>.jpg. A taxonomy argmax of 1 blanks the left mask, 0 the right one (:233-247).
 """
@@ -42,7 +42,7 @@ def main(argv, input_fn=input, max_turns=None):
     turns = 0
     while max_turns is None or turns < max_turns:
         turns += 1
-        prompt = hprompt.build_chat_prompt(input_fn("Please input your prompt: "), args.use_mm_start_end)
+        prompt = hprompt.build_chat_prompt(input_fn("Please input your prompt: "), args.use_mm_start_end, args.conv_type)
         image_path = input_fn("Please input the image path: ")
         if not os.path.exists(image_path):
             print("File not found in {}".format(image_path))

@@ -163,7 +163,7 @@ class SyntheticAffDataset:
         taxonomy = [0.0] * 4
         taxonomy[tax_idx] = 1.0
         action = "action%d" % int(torch.randint(0, 50, (1,), generator=g))
-        conv = hprompt.conv_llava_v1()
+        conv = hprompt.default_conversation()
         conv.append_message(conv.roles[0], hprompt.DEFAULT_IMAGE_TOKEN + "\n" + QUESTION.format(action))
         conv.append_message(conv.roles[1], ANSWER)
         label = {"left": torch.zeros(h, w), "right": torch.zeros(h, w)}
@@ -171,8 +171,9 @@ class SyntheticAffDataset:
                 (S, S), [QUESTION.format(action)], [action], self.inference)
 
 
-def collate_fn(batch, tokenizer, model_max_length=575, use_mm_start_end=True):
-    """utils/dataset.py:30-169 for the llava_v1 template: pad with pad_token, mask the instruction spans with -100."""
+def collate_fn(batch, tokenizer, model_max_length=575, use_mm_start_end=True, conv_type="llava_v1"):
+    """utils/dataset.py:30-169: pad with pad_token, mask the instruction spans with -100; conv_type picks the template whose sep2
+    splits the rounds and the separator that ends a round's instruction (:97-101: " ASSISTANT: " or "[/INST] ")."""
     images, clips, convs, ml, mr, labels_l, resizes, tax, offs = [], [], [], [], [], [], [], [], [0]
     for (_, image, image_clip, conversations, m_left, m_right, taxonomy, label, resize, _q, _c, inference) in batch:
         images.append(image)
@@ -190,8 +191,8 @@ def collate_fn(batch, tokenizer, model_max_length=575, use_mm_start_end=True):
     input_ids = torch.nn.utils.rnn.pad_sequence(ids, batch_first=True, padding_value=tokenizer.pad_token_id)
     attention_masks = input_ids.ne(tokenizer.pad_token_id)
     targets = input_ids.clone()
-    conv = hprompt.conv_llava_v1()
-    sep = conv.sep + conv.roles[1] + ": "
+    conv = hprompt.get_conv(conv_type)
+    sep = hprompt.label_separator(conv_type, conv)
     for conversation, target in zip(convs, targets):
         cur = 1
         target[:cur] = -100
@@ -237,7 +238,7 @@ def validate(model, dataset, tokenizer, args, rank, world, device):
     iou_m, iocm_m = AverageMeter("IoU"), AverageMeter("IoCM")
     lo, hi = hdist.shard_bounds(len(dataset), rank, world)
     for idx in range(lo, hi):
-        batch = collate_fn([dataset[idx]], tokenizer, args.model_max_length)
+        batch = collate_fn([dataset[idx]], tokenizer, args.model_max_length, conv_type=args.conv_type)
         batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         out = model(**batch)
         t = int(out["pred_taxonomies"][0][0].argmax())
@@ -259,6 +260,7 @@ def validate(model, dataset, tokenizer, args, rank, world, device):
 # ---------------------------------------------------------------------------------------------------------------------
 def main(argv):
     args = parse_args(argv)
+    hprompt.set_default_conversation(args.conv_type)      # train_ds.py:188-190
     rank, world, local_rank = hdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("train_ds.py needs MI355X devices: the fine-tune path has no CPU fallback")
@@ -356,7 +358,8 @@ def main(argv):
         for step in range(args.steps_per_epoch):
             reducer.zero()
             for micro in range(args.grad_accumulation_steps):
-                batch = collate_fn([train_ds[sample_idx + j] for j in range(args.batch_size)], tokenizer, args.model_max_length)
+                batch = collate_fn([train_ds[sample_idx + j] for j in range(args.batch_size)], tokenizer, args.model_max_length,
+                                   conv_type=args.conv_type)
                 sample_idx += args.batch_size
                 batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 out = model(**batch)

@@ -230,10 +230,27 @@ def host_goldens():
     c.messages = []
     c.append_message(c.roles[0], "<im_start><image><im_end>\nWhere would you hold the mug?")
     c.append_message(c.roles[1], "")
+    # round 6: both templates the CLIs' --conv_type offers (chat.py:41-46,155; train_ds.py:115-120,188-190), in the three shapes
+    # the path builds: an open turn (chat / evaluate), one closed round and two closed rounds (training conversations, whose
+    # rounds utils/dataset.py:105 splits at sep2)
+    by_type = {}
+    for name in ("llava_v1", "llava_llama_2"):
+        shapes = {}
+        for tag, msgs in (("open_turn", [("<im_start><image><im_end>\nWhere would you hold the mug?", "")]),
+                          ("one_round", [("<image>\nWhere would you interact with the object to perform action open drawer? Please output segmentation mask.", "[SEG].")]),
+                          ("two_rounds", [("<image>\nfirst question", "first answer [SEG]."), ("second question", "It is [SEG].")])):
+            t = conv.conv_templates[name].copy()
+            t.messages = []
+            for q, a in msgs:
+                t.append_message(t.roles[0], q)
+                t.append_message(t.roles[1], a)
+            shapes[tag] = {"messages": [list(m) for m in msgs], "prompt": t.get_prompt()}
+        t = conv.conv_templates[name]
+        by_type[name] = {"roles": list(t.roles), "sep": t.sep, "sep2": t.sep2, "system": t.system, "shapes": shapes}
     import json
     with open(os.path.join(OUT, "host_helpers.json"), "w") as f:
         json.dump({"prompts": prompts, "ids": ids, "conv_llava_v1_prompt": c.get_prompt(),
-                   "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2}, f, indent=1)
+                   "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2, "conv_templates": by_type}, f, indent=1)
     print("host helpers ok:", c.get_prompt()[:80].replace("\n", "\\n"))
 
 

@@ -177,6 +177,88 @@ def test_host_helpers_match_reference():
     conv.append_message(conv.roles[0], "<im_start><image><im_end>\nWhere would you hold the mug?")
     conv.append_message(conv.roles[1], "")
     assert conv.get_prompt() == g["conv_llava_v1_prompt"]
+    # both templates --conv_type offers (round 6), in every shape the path builds, against conversation_lib.conv_templates itself
+    assert sorted(P.conv_templates) == sorted(g["conv_templates"]) == ["llava_llama_2", "llava_v1"]
+    for name, ref in g["conv_templates"].items():
+        t = P.get_conv(name)
+        assert [list(t.roles), t.sep, t.sep2, t.system] == [ref["roles"], ref["sep"], ref["sep2"], ref["system"]]
+        for tag, shape in ref["shapes"].items():
+            c = P.get_conv(name)
+            for q, a in shape["messages"]:
+                c.append_message(c.roles[0], q)
+                c.append_message(c.roles[1], a)
+            assert c.get_prompt() == shape["prompt"], (name, tag)
+            assert c.copy().get_prompt() == shape["prompt"]
+    assert P.build_chat_prompt("Where would you hold the mug?", True, "llava_llama_2") == \
+        g["conv_templates"]["llava_llama_2"]["shapes"]["open_turn"]["prompt"]
+    assert P.build_chat_prompt("Where would you hold the mug?", True) == g["conv_llava_v1_prompt"]
+    with pytest.raises(ValueError):
+        P.get_conv("mpt")
+
+
+def test_collate_label_mask_follows_conv_type():
+    """utils/dataset.py:95-128 under both --conv_type values: BOS and every round's instruction span (up to and including the
+    separator: " ASSISTANT: " for llava_v1, "[/INST] " for llava_llama_2, with the reference's -2 correction) are -100, the answer
+    tokens keep their ids, padding is -100 — checked against an independent character-level reconstruction with a 1-char-1-token
+    tokenizer (so spans can be located by string search)."""
+    import torch
+    from haff import prompt as P
+    from haff import train_ds as TD
+
+    class CharTok:
+        bos_token_id, pad_token_id = 1, 0
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [1] + [3 + ord(ch) for ch in text]
+            return r
+
+    def sample(conv, rounds):
+        for q, a in rounds:
+            conv.append_message(conv.roles[0], q)
+            conv.append_message(conv.roles[1], a)
+        z = torch.zeros(1, 8, 8)
+        return (None, torch.zeros(3, 8, 8), torch.zeros(3, 8, 8), [conv.get_prompt()], z, z, [1.0, 0, 0, 0], {"left": z[0], "right": z[0]},
+                (8, 8), None, None, False)
+    for name in ("llava_v1", "llava_llama_2"):
+        rounds_a = [("<image>\nwhere to hold the mug?", "Sure, [SEG]."), ("and the pan?", "It is [SEG].")]
+        rounds_b = [("<image>\nshort", "[SEG].")]
+        batch = [sample(P.get_conv(name), rounds_a), sample(P.get_conv(name), rounds_b)]
+        out = TD.collate_fn(batch, CharTok(), model_max_length=100000, use_mm_start_end=False, conv_type=name)
+        ids, labels = out["input_ids"], out["labels"]
+        sep = " ASSISTANT: " if name == "llava_v1" else "[/INST] "
+        for row, text in enumerate(out["conversation_list"]):
+            # token t of the row <-> character: BOS, then one id per character, "<image>" collapsed into the single -200
+            chars = [None]
+            i = 0
+            while i < len(text):
+                if text.startswith("<image>", i):
+                    chars.append("<image>")
+                    i += 7
+                else:
+                    chars.append(text[i])
+                    i += 1
+            n = len(chars)
+            assert int((ids[row] != 0).sum()) == n
+            want = torch.full((ids.shape[1],), -100, dtype=torch.long)
+            # answers: from the end of each separator to the end of the round (incl. sep2's characters); the reference's "- 2"
+            # on the instruction length (written for sentencepiece, where BOS and the separator's trailing space do not count)
+            # lets the mask stop two tokens early with a 1-char-1-token tokenizer: the last two separator characters stay labelled
+            pos, tok = 0, 1
+            for rou in text.split("</s>"):
+                if rou == "":
+                    break
+                k = rou.index(sep) + len(sep)
+                n_rou = len(rou.replace("<image>", "I"))
+                n_ins = len(rou[:k].replace("<image>", "I"))
+                # reference arithmetic: round_len = n_rou + 1 (BOS), instruction_len = n_ins + 1 - 2
+                want[tok + n_ins - 1:tok + n_rou + 1] = ids[row][tok + n_ins - 1:tok + n_rou + 1]
+                tok += n_rou + 1
+            want[tok:] = -100
+            assert torch.equal(labels[row], want), (name, row)
+            assert (labels[row][:1] == -100).all() and (labels[row][n:] == -100).all()
 
 
 def test_bf16_points_per_stack_and_memo():
