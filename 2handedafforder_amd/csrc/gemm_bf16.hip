@@ -100,6 +100,12 @@ struct GemmArgs {
   // order. The consumer product then needs no pass over the rows it normalises.
   float* stat_out;
   int stat_slots;
+  // fp32 RESIDUAL STREAM beside the bf16 one (round 6, haff_gemm_bf16_rowstats32; specialised 8-wave instance only): the residual
+  // is read from and the sum written back to res32[m][ld32] in fp32 (in place), and C receives the bf16 copy of the same values
+  // (the next product's MFMA operand); stat_out as above, from the fp32 values. The stream is rounded to bf16 ONCE per consumer
+  // instead of once per residual add (64 times through a ViT-H).
+  float* res32;
+  long ld32;
   // Llama prefill q|k|v projection with RoPE and the KV-cache append in the epilogue (haff_gemm_bf16_qkv_rope; 8-wave tile,
   // register epilogue, bf16, no residual). W's rows arrive PERMUTED inside every 256-row tile so that a lane holds column c
   // of a head in col-block t and its rotate-half partner c + 64 in col-block t + 2 (natural tile column wn*64 + t*16 + i is
@@ -275,6 +281,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 enum : unsigned {
   GF_SPEC = 1u, GF_BIAS = 2u, GF_LN = 4u, GF_CSUM = 8u, GF_RES = 16u, GF_STAT = 32u, GF_MAP = 64u, GF_HM = 128u, GF_ROPE = 256u,
   GF_RAGM = 512u,   // the row count need not be a multiple of BM: the M-side interior tests stay at run time (Llama's 64 x 291 rows)
+  GF_RES32 = 1024u, // with GF_RES: the residual stream is fp32 (GemmArgs::res32), C gets its bf16 copy
   GF_ACT_SHIFT = 16
 };
 
@@ -922,6 +929,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     auto reg_epilogue = [&](auto all_tag, auto res_tag) {
     constexpr bool ALL = decltype(all_tag)::value;
     constexpr bool RES = decltype(res_tag)::value && !OUT_F32;
+    constexpr bool R32 = RES && ALL && SPEC && (FLAGS & GF_RES32) != 0;   // fp32 residual stream in / out + bf16 copy
     constexpr int NCH = SWIGLU ? TN / 2 : TN;   // 4-column chunks per lane per pass
     const int coff = 16 * (fh & 1) + 4 * (fh & 2);   // first of this lane's 8 columns inside a chunk pair (bf16 output)
     auto out_row = [&](int mi) -> int {
@@ -930,7 +938,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     };
     // bf16 residual of pass mi + 1, requested before the stores of pass mi go out
     uint4 rnext[NCH / 2 > 0 ? NCH / 2 : 1];
+    haff_f32x4 rnext32[R32 ? NCH / 2 : 1][2];
+    // (R32) the lane's 8 fp32 stream columns of pass mi sit at x_lane + mi * x_pass + 128 * j bytes
+    char* x_lane = nullptr;
+    long x_pass = 0;
+    if constexpr (R32) {
+      x_lane = reinterpret_cast<char*>(p.res32) + ((long)(m_wave + fr) * p.ld32 + n_wave_out + coff) * 4;
+      x_pass = 16L * p.ld32 * 4;
+    }
     auto fetch_r = [&](int mi) {
+      if constexpr (R32) {
+#pragma unroll
+        for (int j = 0; j < NCH / 2; ++j) {
+          const haff_f32x4* src = reinterpret_cast<const haff_f32x4*>(x_lane + mi * x_pass + 128 * j);
+          rnext32[j][0] = src[0];
+          rnext32[j][1] = src[1];
+        }
+        return;
+      }
       const int orow = out_row(mi);
 #pragma unroll
       for (int j = 0; j < NCH / 2; ++j) {
@@ -1068,9 +1093,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         }
       } else {
         uint4 rcur[NCH / 2 > 0 ? NCH / 2 : 1];
+        haff_f32x4 rcur32[R32 ? NCH / 2 : 1][2];
         if constexpr (RES) {
 #pragma unroll
-          for (int j = 0; j < NCH / 2; ++j) rcur[j] = rnext[j];
+          for (int j = 0; j < NCH / 2; ++j) {
+            if constexpr (R32) { rcur32[j][0] = rnext32[j][0]; rcur32[j][1] = rnext32[j][1]; }
+            else rcur[j] = rnext[j];
+          }
           if (mi + 1 < TM) fetch_r(mi + 1);
         }
 #pragma unroll
@@ -1085,11 +1114,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
               v8[r] = __builtin_bit_cast(float, tx);
               v8[4 + r] = __builtin_bit_cast(float, ty);
             }
+            if constexpr (R32) {   // fp32 stream: add, write the fp32 sums back in place; the bf16 copy leaves below
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v8[e] += rcur32[j][0][e];
+                v8[4 + e] += rcur32[j][1][e];
+              }
+              haff_f32x4* xd = reinterpret_cast<haff_f32x4*>(x_lane + mi * x_pass + 128 * j);
+              xd[0] = haff_f32x4{v8[0], v8[1], v8[2], v8[3]};
+              xd[1] = haff_f32x4{v8[4], v8[5], v8[6], v8[7]};
+            } else {
             const unsigned w[4] = {rcur[j].x, rcur[j].y, rcur[j].z, rcur[j].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v8[2 * e] += __builtin_bit_cast(float, w[e] << 16);
               v8[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            }
             }
             q = haff_u32x4{pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]), pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7])};
             if constexpr (ALL) {
@@ -1720,6 +1760,8 @@ struct StreamCapTable {
 };
 StreamCapTable g_stream_caps;
 }  // namespace
+// (library-internal: the other persistent kernels — window attention — size their grids by the same per-stream setting)
+int haff_internal_stream_cap(void* stream) { return g_stream_caps.get(stream); }
 extern "C" int haff_gemm_stream_cap(void* stream, int cap) {
   if (!(cap >= 8 && cap <= 256 && (cap & 7) == 0)) return g_stream_caps.get(stream);   // not a valid cap: a query
   const int old = g_stream_caps.set(stream, cap);
@@ -1765,7 +1807,8 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
                     a16(p.resid) && (!p.resid || (p.ldr & 7) == 0) && a16(p.ln_stats) && a16(p.ln_colsum) && a16(p.row_map) &&
                     (!p.ln_colsum || p.ln_stats);
     if (ok && haff_gemm_spec_enabled()) {
-      const unsigned f = (p.bias ? GF_BIAS : 0u) | (p.ln_stats ? GF_LN : 0u) | (p.ln_colsum ? GF_CSUM : 0u) | (p.resid ? GF_RES : 0u) |
+      const unsigned f = (p.bias ? GF_BIAS : 0u) | (p.ln_stats ? GF_LN : 0u) | (p.ln_colsum ? GF_CSUM : 0u) |
+                         ((p.resid || p.res32) ? GF_RES : 0u) | (p.res32 ? GF_RES32 : 0u) |
                          (p.stat_out ? GF_STAT : 0u) | (p.row_map ? GF_MAP : 0u) | (p.hm_d ? GF_HM : 0u) | (p.rope_cs ? GF_ROPE : 0u) |
                          ((unsigned)p.act << GF_ACT_SHIFT);
       const bool mfull = (p.M % 256) == 0;
@@ -1780,6 +1823,7 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
       HAFF_SPEC(GF_BIAS | GF_LN | GF_CSUM | GF_MAP | GF_HM, false)
       HAFF_SPEC(GF_BIAS | GF_LN | GF_CSUM | GELU_, false)
       HAFF_SPEC(GF_BIAS | GF_RES | GF_STAT, false)
+      HAFF_SPEC(GF_BIAS | GF_RES | GF_STAT | GF_RES32, false)   // ... on the fp32 residual stream (haff_gemm_bf16_rowstats32)
       // Llama prefill (64 x 291 rows: ragged last M-tile): q|k|v with RoPE, o_proj / down_proj, gate|up; CLIP and everything plain
       HAFF_SPEC(GF_ROPE | GF_RAGM, false)
       HAFF_SPEC(GF_RES | GF_RAGM, false)
@@ -1811,6 +1855,7 @@ static int launch_gemm(const GemmArgs& p, hipStream_t s, int nbatch = 1) {
 #undef HAFF_SPEC192
     }
   }
+  if (p.res32) return HAFF_ERR_UNSUPPORTED;   // the fp32 residual stream exists in its specialised instance only
   if (p.swiglu) {
     if (p.out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, pl);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, pl);
@@ -2065,6 +2110,33 @@ extern "C" int haff_gemm_bf16_rowstats(const void* A, long lda, const int* a_map
   else if (K >= 5120 && tn <= 8) p.group_m = 2;
   else if (tn <= 16) p.group_m = 4;
   return launch_gemm<256, 256, 2, 4>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// haff_gemm_bf16_rowstats on an fp32 residual stream (round 6; the "fused fp32 stream" of DESIGN.md section 2): X32 f32 [M][ldx] is
+// read, X32 + A.W^T + bias written back IN PLACE in fp32, C16 bf16 [M][ldc] receives the same values rounded once — the operand of
+// the next haff_gemm_bf16_ln, whose folded LayerNorm takes the statistics emitted here (stat_out, from the fp32 values). The
+// stream itself is never rounded between blocks. Same shape contract as haff_gemm_bf16_rowstats; ldx % 4 == 0.
+extern "C" int haff_gemm_bf16_rowstats32(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw,
+                                         float* X32, long ldx, void* C16, long ldc, const float* bias, int M, int N, int K,
+                                         float* stat_out, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !X32 || !C16 || !stat_out || !bias) return HAFF_ERR_BAD_ARG;
+  if ((K & 7) || (lda & 7) || (ldw & 7) || (ldc & 7) || (ldx & 3)) return HAFF_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(C16) & 15) ||
+      (reinterpret_cast<uintptr_t>(X32) & 15) || (reinterpret_cast<uintptr_t>(stat_out) & 7) || (reinterpret_cast<uintptr_t>(bias) & 15))
+    return HAFF_ERR_BAD_ARG;
+  if ((M % 256) || (N % 256) || (K % BK) || (a_map && a_rows <= 0)) return HAFF_ERR_UNSUPPORTED;
+  if ((long)(a_map ? a_rows : M) * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return HAFF_ERR_UNSUPPORTED;
+  GemmArgs p{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), ldw, C16, ldc,
+             bias, nullptr, 0, nullptr, a_map, 8, nullptr, nullptr, M, N, K, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  p.stat_out = stat_out;
+  p.stat_slots = N / 64;
+  p.res32 = X32;
+  p.ld32 = ldx;
+  const int tn = N / 256;   // raster depth: the rule of gemm_bf16_impl
+  if (tn <= 5) p.group_m = 1;
+  else if (K >= 5120 && tn <= 8) p.group_m = 2;
+  else if (tn <= 16) p.group_m = 4;
+  return launch_gemm<256, 256, 2, 4>(p, reinterpret_cast<hipStream_t>(stream));   // always meets the specialised instance's contract
 }
 
 // Product with a LayerNorm / RMSNorm folded in (see GemmArgs::ln_stats): the normalised activations never exist in

@@ -497,6 +497,11 @@ extern "C" int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, l
     if (grid_w != grid_h || (n_windows % (p.wps * p.wps)) != 0 || pad_token < 0 || q_st != k_st ||
         (pad_token + 1) * k_st * 2 >= (1L << 32) || pad_token * k_st < (long)(n_windows - 1) * k_sb)
       return HAFF_ERR_BAD_ARG;
+    // the V pad row is reached as pad base + (v - k) in ONE unsigned 32-bit byte offset (issue_dma: nx_pad_base + chunk +
+    // vmk_bytes): the SUM must fit too — on head-major planes both terms are ~ part * 2 bytes and wrap together from ~171
+    // frames per pass on; the caller keeps the token-major layout then
+    const long dvk = reinterpret_cast<const bf16_t*>(v) - reinterpret_cast<const bf16_t*>(k);
+    if ((pad_token * k_st + dvk + d) * 2 >= (1L << 32)) return HAFF_ERR_UNSUPPORTED;
   }
   using C = WinCfg<80, 14>;
   // the attribute is per device and this entry point keeps no state: set it on every call (a host-side table write)
@@ -505,7 +510,9 @@ extern "C" int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, l
     return HAFF_ERR_LAUNCH;
   // persistent: one 7-wave workgroup per CU (150 KB LDS); a multiple of 8 workgroups keeps the item -> XCD mapping
   const int n_items = n_windows * H;
-  dim3 grid(n_items < 256 ? n_items : 256), block(C::NTHREADS);
+  // ... fewer when the caller capped this stream's persistent launches (haff_gemm_stream_cap: CUs left to another stream)
+  const int cap = haff_internal_stream_cap(stream);
+  dim3 grid(n_items < cap ? n_items : cap), block(C::NTHREADS);
   hipLaunchKernelGGL((window_attn_kernel<80, 14>), grid, block, C::LDS_BYTES, reinterpret_cast<hipStream_t>(stream), p);
   return haff_check_launch();
 }

@@ -36,6 +36,8 @@ _PROTOS = {
                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_gemm_bf16_rowstats": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                 c_long, c_int, c_int, c_int, c_void_p, c_void_p],
+    "haff_gemm_bf16_rowstats32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p,
+                                  c_int, c_int, c_int, c_void_p, c_void_p],
     "haff_gemm_f32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                       c_int, c_int, c_int, c_int, c_int, c_void_p],
     "haff_attention_bf16": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,

@@ -27,7 +27,8 @@ N_IMG_PAD = 255  # LISA.py:461
 
 
 class LisaMI355:
-    def __init__(self, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", sam_chunk=8, fp32_tail=True, fp32_stream=False):
+    def __init__(self, cfg, state_dict, dtype=torch.bfloat16, device="cuda:0", sam_chunk=8, fp32_tail=True, fp32_stream=False,
+                 neck_f32=False):
         if not torch.cuda.is_available():
             raise RuntimeError("LisaMI355 needs an MI355X (HIP device); there is no CPU fallback for the hot path")
         from .lib import load_library
@@ -40,8 +41,20 @@ class LisaMI355:
         # evaluate() call, None = every launch on all CUs, or an explicit list of workgroup caps per encoder chunk;
         # sam_waits_for_prefill "auto" | True | False (late mode: the encoder starts behind the prefill on the GPU too).
         self.sam_chunk_caps = "auto"
+        # Round 6: TWO encoder passes side by side, each on half the CUs its turn would take (two HIP streams, each launch capped
+        # at cap / 2 workgroups): the persistent GEMM tiles of ONE launch reach their epilogues in the same microsecond on every CU
+        # (a 64 MiB burst per round of tiles); two half-chip launch sequences drift against each other, so
+        # one half's epilogue bursts and its HBM-bound kernels (window attention, statistics) run under the other half's K loops.
+        # Frames are independent through the whole encoder (image_encoder.py:110-125), results are bit-identical. False = passes
+        # one after another on the whole chip (rounds 1-5).
+        self.sam_dual_streams = False
+        self._sam_stream2 = torch.cuda.Stream(device=self.device)
+        self._dual_warm = set()
         self.sam_waits_for_prefill = "auto"
+        self.calibrate_overlap = True         # False: the plan uses overlap.NOMINAL (round 5's fitted constants) whatever the device
+        self.last_rates = None
         self.expected_new_tokens = 8          # what the plan assumes a reply takes ("Sure, ... [SEG] ." templates) when max_new_tokens is larger
+        self._dual_active = False
         self._plan = (None, False, None)      # (caps, wait, chunk) of the evaluate() call in flight (no caps outside one)
         self.last_plan = (None, False, None)  # ... of the last evaluate() call (what bench.py reports)
         # The SAM encoder runs on its own HIP stream beside the language model and joins before the mask decoders
@@ -77,6 +90,7 @@ class LisaMI355:
         # stream kept in fp32 between the bf16 MFMA products (2.8x closer to the reference on the image embedding at depth 32)
         self.sam_encoder.fp32_stream = fp32_stream in (True, "sam", "both")
         self.llm.fp32_stream = fp32_stream in (True, "llm", "both")
+        self.sam_encoder.neck_f32 = bool(neck_f32) and dtype == torch.bfloat16    # the ViT-H neck on the f32-input MFMA path (sam.py)
         self.w_proj = sd["model.mm_projector.weight"].to(dev, dtype).contiguous()
         self.b_proj = _f32(sd["model.mm_projector.bias"], dev)
         self.fc0 = (sd["model.text_hidden_fcs.0.0.weight"].to(dev, tail).contiguous(), _f32(sd["model.text_hidden_fcs.0.0.bias"], dev))
@@ -252,6 +266,8 @@ class LisaMI355:
         "auto": overlap.plan, decided per evaluate() call."""
         caps = self._plan[0]
         cap = caps[min(n, len(caps) - 1)] if caps and self.overlap_streams else 256
+        if self._dual_active:
+            cap = max(8, (cap // 2) // 8 * 8)      # this pass shares its turn with the pass on the other encoder stream
         if cap == 256:
             yield
             return
@@ -266,28 +282,56 @@ class LisaMI355:
         c = self._plan[2] if self.sam_chunk == "auto" else self.sam_chunk
         return int(c) if c else max(1, min(int(frames), 8))
 
+    def _encoder_passes(self, F, rows_of):
+        """The ViT over F frames in passes of `_chunk(F)` frames; rows_of(i, n) -> the patch rows of frames i .. i+n. Every pass
+        writes its slice of ONE embedding tensor (torch.cat of four 67 MB pieces was 0.7 ms at the end of the encoder)."""
+        enc = self.sam_encoder
+        ch = self._chunk(F)
+        emb = torch.empty((F, enc.cfg.grid ** 2, enc.cfg.out_chans), dtype=torch.float32 if enc.emb_f32 else enc.dtype, device=self.device) \
+            if F > ch else None
+        starts = list(range(0, F, ch))
+        # two passes at a time on two streams (sam_dual_streams): pass sizes seen for the first time run alone once (their gather
+        # maps and lazily built tables are created by whoever comes first; after that both streams only read them)
+        dual = self.sam_dual_streams and emb is not None and len(starts) >= 2
+        if dual:
+            sizes = {min(ch, F - i) for i in starts}
+            if not sizes <= self._dual_warm:
+                self._dual_warm |= sizes
+                dual = False
+        if not dual:
+            for n, i in enumerate(starts):
+                k = min(ch, F - i)
+                with self._chunk_cap(n, F):
+                    y = enc.forward_rows(rows_of(i, k), k, out=None if emb is None else emb[i:i + k])
+            return y if emb is None else emb
+        cur, s2 = torch.cuda.current_stream(self.device), self._sam_stream2
+        s2.wait_stream(cur)
+        self._dual_active = True
+        try:
+            for n, i in enumerate(starts):
+                k = min(ch, F - i)
+                # pass n of a pair takes the plan's cap of the pair's FIRST pass (both halves of one turn)
+                with torch.cuda.stream(s2 if n & 1 else cur), self._chunk_cap(n & ~1, F):
+                    enc.forward_rows(rows_of(i, k), k, out=emb[i:i + k])
+                if n == len(starts) - 2 and len(starts) & 1:
+                    # an odd pass out at the end: it runs alone on its turn's full cap, behind both halves
+                    cur.wait_stream(s2)
+                    self._dual_active = False
+        finally:
+            self._dual_active = False
+        cur.wait_stream(s2)
+        return emb
+
     @torch.no_grad()
     def get_visual_embs(self, images):
         """LISA.py:157-168 without the per-image python loop; chunked to bound activation memory."""
-        outs = []
-        ch = self._chunk(images.shape[0])
-        for n, i in enumerate(range(0, images.shape[0], ch)):
-            with self._chunk_cap(n, images.shape[0]):
-                outs.append(self.sam_encoder(images[i:i + ch].to(self.device)))
-        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        enc = self.sam_encoder
+        return self._encoder_passes(images.shape[0], lambda i, k: enc.patch_rows_from_nchw(images[i:i + k].to(self.device, enc.dtype)))
 
     @torch.no_grad()
     def get_visual_embs_u8(self, frames, mean, std):
-        enc, F = self.sam_encoder, frames.shape[0]
-        ch = self._chunk(F)
-        # every pass writes its slice of ONE embedding tensor (torch.cat of four 67 MB pieces was 0.7 ms at the end of the encoder)
-        emb = torch.empty((F, enc.cfg.grid ** 2, enc.cfg.out_chans), dtype=torch.float32 if enc.emb_f32 else enc.dtype, device=self.device) \
-            if F > ch else None
-        for n, i in enumerate(range(0, F, ch)):
-            fr = frames[i:i + ch]
-            with self._chunk_cap(n, F):
-                y = enc.forward_rows(enc.patch_rows_from_u8(fr, mean, std), fr.shape[0], out=None if emb is None else emb[i:i + fr.shape[0]])
-        return y if emb is None else emb
+        enc = self.sam_encoder
+        return self._encoder_passes(frames.shape[0], lambda i, k: enc.patch_rows_from_u8(frames[i:i + k], mean, std))
 
     @torch.no_grad()
     def get_visual_embs_frames(self, frames, mean, std):
@@ -381,8 +425,11 @@ class LisaMI355:
         caps, wait = None, False
         if self.overlap_streams:
             if self.sam_chunk_caps == "auto":
+                # the work model's rates follow THIS device (two timed probes, once per process: overlap.calibrate)
+                rates = overlap.calibrate(self.device) if self.calibrate_overlap and n_frames >= overlap.MIN_FRAMES else overlap.NOMINAL
+                self.last_rates = rates
                 caps, wait = overlap.plan(self.cfg, n_frames, chunk, input_ids.shape[1],
-                                          min(max_new_tokens, self.expected_new_tokens), late)
+                                          min(max_new_tokens, self.expected_new_tokens), late, rates)
             elif self.sam_chunk_caps:
                 caps, wait = list(self.sam_chunk_caps), late
             if self.sam_waits_for_prefill != "auto":

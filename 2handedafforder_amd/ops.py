@@ -102,6 +102,35 @@ def linear_rowstats(x, w, bias, resid, eps, out=None, a_map=None):
     return out, stats
 
 
+def rowstats32_gemm(x, w, bias, x32, out16, a_map=None):
+    """The product of linear_rowstats32 alone (one haff_gemm_bf16_rowstats32 launch): returns the partial sums fp32 [M, N/64, 2]."""
+    lib = load_library()
+    M = a_map.numel() if a_map is not None else x.shape[0]
+    N, K = w.shape
+    part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device)
+    rc = lib.haff_gemm_bf16_rowstats32(x.data_ptr(), x.stride(0), _p(a_map), x.shape[0], w.data_ptr(), w.stride(0), x32.data_ptr(),
+                                       x32.stride(0), out16.data_ptr(), out16.stride(0), _p(bias), M, N, K, part.data_ptr(), _stream())
+    check(rc, "haff_gemm_bf16_rowstats32")
+    return part
+
+
+def linear_rowstats32(x, w, bias, x32, out16, eps, a_map=None):
+    """x32 += x @ w.T + bias IN PLACE on the fp32 residual stream, out16 = bf16(x32) (the next product's operand), and the
+    {mean, rstd} of every row of the new x32 as fp32 [M, 2] (haff_gemm_bf16_rowstats32 + haff_row_stats_finalize)."""
+    lib = load_library()
+    _req(x, "x")
+    M = a_map.numel() if a_map is not None else x.shape[0]
+    N, K = w.shape
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] == K
+    assert linear_rowstats_supported(M, N, K, x.dtype, 0) and x32.dtype == torch.float32 and out16.dtype == torch.bfloat16
+    assert x32.shape == (M, N) and out16.shape == (M, N) and x32.stride(1) == 1 and out16.stride(1) == 1 and bias is not None
+    part = rowstats32_gemm(x, w, bias, x32, out16, a_map)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    check(lib.haff_row_stats_finalize(part.data_ptr(), stats.data_ptr(), M, N // 64, N, float(eps), _stream()),
+          "haff_row_stats_finalize")
+    return stats
+
+
 def rope_permute_rows(w):
     """The row order haff_gemm_bf16_qkv_rope wants for the fused q|k|v weights [3*H*128, K]: inside every 256-row tile, natural
     row wn*64 + t*16 + i takes logical row (wn>>1)*128 + (t>>1)*64 + (wn&1)*32 + (t&1)*16 + i."""

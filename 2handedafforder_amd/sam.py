@@ -9,8 +9,6 @@ but batched over frames and prompts, channels-last everywhere, weights re-laid-o
 """
 import math
 
-import os
-
 import torch
 
 from . import ops
@@ -90,6 +88,13 @@ class SamEncoderHip:
         # distance to the reference at depth 32: tools/full_frame_parity.py) disappear. Costs the folded norms (LayerNorm kernels
         # come back) and doubles the epilogue traffic of proj / lin2. Off by default.
         self.fp32_stream = False
+        # ... round 6: the FUSED form — the proj / lin2 epilogue writes the fp32 stream AND its bf16 copy (haff_gemm_bf16_rowstats32),
+        # the norms stay folded (their operand is the copy); taken whenever fp32_stream is on and the shapes allow (ViT-H geometry,
+        # >= 2 frames per pass). False: round 5's unfused form everywhere (A/B).
+        self.fused_fp32_stream = True
+        # the neck on the f32-input MFMA path (bf16 mode): see forward_rows
+        self.neck_f32 = False
+        self._neck32 = None
         self._pos32 = None
 
     @staticmethod
@@ -147,8 +152,10 @@ class SamEncoderHip:
         nb, ntok = B * nw2, s.window * s.window
         w, bias = (blk["wqkv_f"], blk["bqkv_f"]) if folded else (blk["wqkv"], blk["bqkv"])
         kw = dict(ln_stats=st, ln_colsum=blk["sqkv"]) if folded else {}
-        if self.head_major_windows and ops.linear_heads_supported(x.shape[0], 3 * C, C, hd, H, x.dtype):
-            part = (nb + 1) * H * ntok * hd
+        part = (nb + 1) * H * ntok * hd
+        # (the window kernel reaches V's pad row through one 32-bit byte offset of ~ 2 planes: 2 * part * 2 bytes must stay under
+        # 4 GiB — passes of > 170 frames keep the token-major buffer; haff_window_attention_bf16 refuses the wrap either way)
+        if self.head_major_windows and ops.linear_heads_supported(x.shape[0], 3 * C, C, hd, H, x.dtype) and 4 * part + 4 * hd < (1 << 32):
             planes = torch.empty((3, nb + 1, H, ntok, hd), dtype=x.dtype, device=x.device)
             ops.linear_heads(x, w, bias, self._head_major_window_map(B), planes, hd, H, part, ntok * hd, **kw)
             planes[:, nb, :, 0, :].copy_(blk["bqkv"].view(3, H, hd))   # the pad token: qkv of a zero row = the bias
@@ -168,28 +175,54 @@ class SamEncoderHip:
         return ops.patchify_u8(frames, s.patch, s.grid, s.grid, 3 * s.patch * s.patch, mean, std, self.dtype)
 
     def forward_rows(self, rows, B, taps=None, out=None):
+        """Patch rows -> image embedding [B, N, out_chans] (image_encoder.py:110-125,177-193). One body for the three forms of the
+        residual stream x [B*N, C]:
+          bf16 (default)     x is bf16; proj / lin2 add into it (and, when the shapes allow, emit the LayerNorm statistics of the
+                             rows they wrote); norm1 -> qkv and norm2 -> lin1 are folded into the products.
+          fp32, fused        (fp32_stream, round 6) x is fp32 and x16 its bf16 copy, BOTH written by the proj / lin2 epilogue
+                             (ops.linear_rowstats32): the stream is never rounded between blocks, the folded norms stay, the
+                             products' operand is one rounding of the stream.
+          fp32, unfused      (fp32_stream where the fused form's shapes are not met, or fused_fp32_stream = False: round 5's form)
+                             LayerNorm kernels read fp32 and round the NORMALISED row to bf16; proj / lin2 take and write fp32."""
         s = self.cfg
         C, g, H, hd = s.embed_dim, s.grid, s.heads, self.hd
         N = g * g
-        s32 = bool(self.fp32_stream) and self.dtype == torch.bfloat16
+        bf = torch.bfloat16
+        s32 = bool(self.fp32_stream) and self.dtype == bf
         if s32:
             if self._pos32 is None:
                 self._pos32 = self.pos.float()
             x = ops.linear(rows, self.w_patch, bias=self.b_patch, out_dtype=torch.float32)
             x = ops.add_bcast(x, self._pos32, mod=N, out=x)
-            return self._forward_rows_fp32_stream(x, B, taps, out)
-        x = ops.linear(rows, self.w_patch, bias=self.b_patch)
-        x = ops.add_bcast(x, self.pos, mod=N, out=x)
+        else:
+            x = ops.linear(rows, self.w_patch, bias=self.b_patch)
+            x = ops.add_bcast(x, self.pos, mod=N, out=x)
         scale = hd ** -0.5
+        compact_ok = self.compact_windows and self.dtype == bf and s.window == 14 and hd == 80
         # folded norms: {mean, rstd} of the rows of x, handed from the product that WROTE x (proj / lin2 epilogues sum their own
         # results: ops.linear_rowstats) to the product that normalises it; None = take a statistics pass (ops.row_stats)
         carry = self.fold_norms and self.producer_stats and \
             ops.linear_rowstats_supported(x.shape[0], C, C, self.dtype, 0 if self.producer_stats == "force" else 160)
+        fused32 = s32 and self.fused_fp32_stream and carry and compact_ok    # (every residual product then has whole rows, no row map)
+        fold = self.fold_norms and (not s32 or fused32)
+        x16 = x.to(bf) if fused32 else None       # the products' operand: the stream rounded once (kept up to date by the epilogues)
+        nkw = {"out_dtype": bf} if s32 else {}
         st = None
+
+        def stats():
+            return st if st is not None else ops.row_stats(x, 1e-6)
+
+        def add_product(a2, w, b, a_map=None, row_map=None):
+            """x += a2 @ w.T + b (image_encoder.py:186-188 / :193); returns the statistics of the new rows or None."""
+            if fused32:
+                return ops.linear_rowstats32(a2, w, b, x, x16, 1e-6, a_map=a_map)
+            if carry and row_map is None and not s32:
+                return ops.linear_rowstats(a2, w, b, x, 1e-6, out=x, a_map=a_map)[1]
+            ops.linear(a2, w, bias=b, resid=x, a_map=a_map, row_map=row_map, out=x)
+            return None
         for i, blk in enumerate(self.blocks):
-            compact = (self.compact_windows and not blk["global"] and self.dtype == torch.bfloat16 and s.window == 14
-                       and hd == 80)
-            if compact:
+            xa = x16 if fused32 else x
+            if compact_ok and not blk["global"]:
                 # Windowed block, real tokens only: the padded window rows (16 % of the rows at 64x64 / 14) are never
                 # normalised, projected or written. qkv rows are scattered straight into the window-major layout;
                 # the fused window kernel substitutes the one "pad token" row (qkv of a zero token = the bias, since
@@ -198,28 +231,23 @@ class SamEncoderHip:
                 _, nw2 = self._window_maps(B)
                 inv = self._compact_window_map(B)
                 nb, ntok, S = B * nw2, s.window * s.window, s.window
-                if self.fold_norms:
-                    q, k, v, pad = self._windowed_qkv(x, blk, B, st if st is not None else ops.row_stats(x, 1e-6), True)
+                if fold:
+                    q, k, v, pad = self._windowed_qkv(xa, blk, B, stats(), True)
                 else:
-                    q, k, v, pad = self._windowed_qkv(ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6), blk, B, None, False)
+                    q, k, v, pad = self._windowed_qkv(ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, **nkw), blk, B, None, False)
                 a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=pad)
                 del q, k, v
-                if carry:
-                    _, st = ops.linear_rowstats(a.view(nb * ntok, C), blk["wproj"], blk["bproj"], x, 1e-6, out=x, a_map=inv)
-                else:
-                    ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, a_map=inv, out=x)
-                    st = None
+                st = add_product(a.view(nb * ntok, C), blk["wproj"], blk["bproj"], a_map=inv)
             else:
                 if blk["global"]:
                     nb, ntok, S, row_map = B, N, g, None
-                    if self.fold_norms:
-                        qkv = ops.linear(x, blk["wqkv_f"], bias=blk["bqkv_f"],
-                                         ln_stats=st if st is not None else ops.row_stats(x, 1e-6), ln_colsum=blk["sqkv"])
+                    if fold:
+                        qkv = ops.linear(xa, blk["wqkv_f"], bias=blk["bqkv_f"], ln_stats=stats(), ln_colsum=blk["sqkv"])
                     else:
-                        qkv = ops.linear(ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6), blk["wqkv"], bias=blk["bqkv"])
+                        qkv = ops.linear(ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, **nkw), blk["wqkv"], bias=blk["bqkv"])
                 else:
                     win, nw2 = self._window_maps(B)
-                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, in_map=win)
+                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, in_map=win, **nkw)
                     nb, ntok, S, row_map = B * nw2, s.window * s.window, s.window, win
                     qkv = ops.linear(xn, blk["wqkv"], bias=blk["bqkv"])
                 q5 = qkv.view(nb, ntok, 3, H, hd)
@@ -235,83 +263,34 @@ class SamEncoderHip:
                     a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
                     del relh, relw
                 del qkv
-                if carry and row_map is None:
-                    _, st = ops.linear_rowstats(a.view(nb * ntok, C), blk["wproj"], blk["bproj"], x, 1e-6, out=x)
-                else:
-                    ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
-                    st = None
-            if self.fold_norms:
-                h = ops.linear(x, blk["w1_f"], bias=blk["b1_f"], act=ops.ACT_GELU,
-                               ln_stats=st if st is not None else ops.row_stats(x, 1e-6), ln_colsum=blk["s1"])
+                st = add_product(a.view(nb * ntok, C), blk["wproj"], blk["bproj"], row_map=row_map)
+            if fold:
+                h = ops.linear(x16 if fused32 else x, blk["w1_f"], bias=blk["b1_f"], act=ops.ACT_GELU, ln_stats=stats(), ln_colsum=blk["s1"])
             else:
-                h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6)
+                h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, **nkw)
                 h = ops.linear(h, blk["w1"], bias=blk["b1"], act=ops.ACT_GELU)
-            if carry:
-                _, st = ops.linear_rowstats(h, blk["w2"], blk["b2"], x, 1e-6, out=x)
-            else:
-                ops.linear(h, blk["w2"], bias=blk["b2"], resid=x, out=x)
-                st = None
+            st = add_product(h, blk["w2"], blk["b2"])
             if taps is not None:
                 taps[f"block{i}"] = x.float().view(B, g, g, C).cpu()
-        y = ops.linear(x, self.w_neck0)
+        o = None if out is None else out.view(B * N, s.out_chans)
+        if self.neck_f32 and self.dtype == bf:
+            # the neck (image_encoder.py:88-107: 1x1 conv, LayerNorm2d, 3x3 conv, LayerNorm2d) on the f32-input MFMA path: its four
+            # tensors are the last roundings in front of the embedding and nothing averages them out afterwards; 7.5 GFLOP per frame
+            if self._neck32 is None:
+                self._neck32 = (self.w_neck0.float(), self.w_neck2.float())
+            y = ops.linear(x if s32 else x.float(), self._neck32[0])
+            y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
+            cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
+            y = ops.linear(cols, self._neck32[1])
+            if not self.emb_f32:
+                return ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6, out=o, out_dtype=bf).view(B, N, s.out_chans)
+            return ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6, out=o).view(B, N, s.out_chans)
+        y = ops.linear(x16 if fused32 else (x.to(bf) if s32 else x), self.w_neck0)
         y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
         cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
         y = ops.linear(cols, self.w_neck2, out_dtype=torch.float32 if self.emb_f32 else None)
         # (out: a [B, N, out_chans] slice of the caller's embedding buffer — several passes fill one tensor, no torch.cat)
-        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6, out=None if out is None else out.view(B * N, s.out_chans))
-        return y.view(B, N, s.out_chans)
-
-    def _forward_rows_fp32_stream(self, x, B, taps=None, out=None):
-        """The blocks on an fp32 residual stream x [B*N, C] (see fp32_stream): LayerNorm kernels fp32 -> bf16, bf16 MFMA products,
-        proj / lin2 with fp32 residual in and fp32 out (haff_gemm_bf16*'s out_f32 epilogue). image_encoder.py:177-193."""
-        s = self.cfg
-        C, g, H, hd = s.embed_dim, s.grid, s.heads, self.hd
-        N = g * g
-        scale = hd ** -0.5
-        bf = torch.bfloat16
-        for i, blk in enumerate(self.blocks):
-            compact = self.compact_windows and not blk["global"] and s.window == 14 and hd == 80
-            if compact:
-                _, nw2 = self._window_maps(B)
-                inv = self._compact_window_map(B)
-                nb, ntok, S = B * nw2, s.window * s.window, s.window
-                xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, out_dtype=bf)
-                q, k, v, pad = self._windowed_qkv(xn, blk, B, None, False)
-                a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S, grid=g, pad_token=pad)
-                del q, k, v
-                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, a_map=inv, out=x)
-            else:
-                if blk["global"]:
-                    nb, ntok, S, row_map = B, N, g, None
-                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, out_dtype=bf)
-                else:
-                    win, nw2 = self._window_maps(B)
-                    xn = ops.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, in_map=win, out_dtype=bf)
-                    nb, ntok, S, row_map = B * nw2, s.window * s.window, s.window, win
-                qkv = ops.linear(xn, blk["wqkv"], bias=blk["bqkv"])
-                q5 = qkv.view(nb, ntok, 3, H, hd)
-                q, k, v = q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 1].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3)
-                if not blk["global"] and ops.window_attention_supported(q, S):
-                    a = ops.window_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
-                elif blk["global"] and self.fused_global and ops.global_attention_supported(q, k, v, S):
-                    a = ops.global_attention(q, k, v, scale, blk["rel_h"], blk["rel_w"], S)
-                else:
-                    relh, relw = ops.relpos_tables(q, blk["rel_h"], blk["rel_w"], S)
-                    a = ops.attention(q, k, v, scale, relh=relh, relw=relw, S=S)
-                    del relh, relw
-                del qkv
-                ops.linear(a.view(nb * ntok, C), blk["wproj"], bias=blk["bproj"], resid=x, row_map=row_map, out=x)
-            h = ops.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, out_dtype=bf)
-            h = ops.linear(h, blk["w1"], bias=blk["b1"], act=ops.ACT_GELU)
-            ops.linear(h, blk["w2"], bias=blk["b2"], resid=x, out=x)
-            if taps is not None:
-                taps[f"block{i}"] = x.float().view(B, g, g, C).cpu()
-        y = ops.linear(x.to(bf), self.w_neck0)
-        y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
-        cols = ops.im2col3x3(y.view(B, g, g, s.out_chans))
-        y = ops.linear(cols, self.w_neck2, out_dtype=torch.float32 if self.emb_f32 else None)
-        # (out: a [B, N, out_chans] slice of the caller's embedding buffer — several passes fill one tensor, no torch.cat)
-        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6, out=None if out is None else out.view(B * N, s.out_chans))
+        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6, out=o)
         return y.view(B, N, s.out_chans)
 
     def __call__(self, images, taps=None):

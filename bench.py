@@ -105,6 +105,17 @@ class GemmMeter:
             meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + M * N), False, 2.0 * N * K, "qkv_rope", (M, N, K)))
             return q
         ops.rowstats_gemm, ops.qkv_rope = timed_rs, timed_qr
+        self._orig_rs32 = ops.rowstats32_gemm
+
+        def timed_rs32(x, w, bias, x32, out16, a_map=None):   # (round 6) the same products on the fp32 residual stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            part = meter._orig_rs32(x, w, bias, x32, out16, a_map)
+            e1.record()
+            M, K, N = out16.shape[0], x.shape[1], w.shape[0]
+            meter.records.append((e0, e1, 2.0 * M * K * N, 2.0 * (M * K + N * K + 5 * M * N) + 8.0 * M * (N // 64), False, 2.0 * N * K, "rowstats32", (M, N, K)))
+            return part
+        ops.rowstats32_gemm = timed_rs32
         # round 5: the windowed q|k|v products scatter head-major (haff_gemm_bf16_heads): same tile kernel, same bookkeeping
         self._orig_lh = ops.linear_heads
 
@@ -123,6 +134,7 @@ class GemmMeter:
     def __exit__(self, *exc):
         ops.linear = self._orig
         ops.rowstats_gemm, ops.qkv_rope = self._orig_rs, self._orig_qr
+        ops.rowstats32_gemm = self._orig_rs32
         ops.linear_heads = self._orig_lh
 
     def summary(self):
@@ -443,8 +455,21 @@ def cpu_full_frame(cfg, text_tokens, n_gen, threads):
                                                                            cfg.llm.layers, threads)}
 
 
-def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf16", "fp32"), attribution=True, seed=1234,
-                      variants=None):
+def _streams_fused(m):
+    """bf16 mode, both residual streams fp32 (ViT-H: the fused form of round 6 — proj / lin2 write the fp32 stream and its bf16 copy)."""
+    m.sam_encoder.fp32_stream = m.llm.fp32_stream = True
+
+
+def _streams_fused_neck(m):
+    _streams_fused(m)
+    m.sam_encoder.neck_f32 = True
+
+
+FULL_FRAME_VARIANTS = {"bf16_fp32_stream": _streams_fused, "bf16_fp32_stream_f32neck": _streams_fused_neck}
+
+
+def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf16", "fp32"), attribution=False, seed=1234,
+                      variants=None, field="gaussian"):
     """The 'mask IoU vs ref' half of the metric AT THE HEADLINE GEOMETRY: ONE full-depth frame (BASELINE.json configs[1]: every
     ViT-H block, CLIP layer and Llama layer; 1024^2 uint8 frame, 36-id prompt, n_gen forced answer tokens with one [SEG]) through
     LisaMI355.evaluate in each numeric mode and through the CPU oracle ON THE SAME WEIGHTS — the set is generated once in HBM
@@ -454,10 +479,15 @@ def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf1
     uint8 frame like the timed step does. The oracle's exact pass is timed: it IS cpu_baseline's one real frame (no second CPU
     frame in the run). attribution=True adds the oracle's bf16-points mode for one stack at a time and for all three (one stage
     re-run per variant: oracle.lisa_evaluate(points=, memo=)). Returns {"parity": {...}, "cpu_frame": {...}} or {"skipped": why}.
-    variants: optional {name: callable(model)} applied to a bf16 model before its run (A/B of numeric options)."""
+    variants: optional {name: callable(model)} applied to a bf16 model before its run (A/B of numeric options; default
+    FULL_FRAME_VARIANTS). field: "gaussian" = the bench's noise frame on the weights as generated (a random decoder's logit field:
+    Gaussian around 0); "two_plateau" = a two-region frame and the hypernetwork biases of both decoders re-aimed so that the
+    oracle's logit field is +-10 on the regions with a thin boundary, as a trained checkpoint's is (tools/parity_bimodal.py's
+    construction at full size; the same patched weights go to the oracle and to every HIP model)."""
     from collections import OrderedDict
     import numpy as np
     from oracle import lisa_oracle as O
+    V = "model.visual_model"
     shapes = hw.all_shapes(cfg)
     n_par = sum(int(np.prod(sh)) for sh in shapes.values())
     try:
@@ -477,14 +507,59 @@ def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf1
     sizes = [(S, S)]
     sd_dev = hw.make_state_dict_device(cfg, seed, device, torch.bfloat16)
     frames, _, ids, forced = make_inputs(cfg, 1, text_tokens, n_gen, device, seed=seed)
+    region = None
+    if field == "two_plateau":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import parity_bimodal as PB
+        fr, region = PB.two_region_frame_u8(S, seed)
+        frames = fr.to(device)
     frame_np = frames[0].cpu().numpy()
     images = O.sam_preprocess(frame_np, S)[None]
     clip = CLIPImageProcessor().preprocess(frame_np, return_tensors="pt")["pixel_values"].float()
 
-    if variants is None:   # the bf16 mode with both residual streams in fp32 rides along by default
-        def _streams(m):
-            m.sam_encoder.fp32_stream = m.llm.fp32_stream = True
-        variants = {"bf16_fp32_stream": _streams}
+    # the oracle first (round 6): its exact pass is the reference of every HIP run below, and in the two-plateau case it is what
+    # the weights are patched from
+    t0 = time.perf_counter()
+    sd = OrderedDict((k, v.cpu().float()) for k, v in sd_dev.items())
+    t_copy = time.perf_counter() - t0
+    memo, taps = {}, {}
+    kw = dict(max_new_tokens=n_gen, forced_answer=forced.cpu(), use_cache=True, memo=memo)
+    field_diag = None
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        r_ids, r_left, r_right, r_tax = O.lisa_evaluate(sd, cfg, clip, images, ids.cpu(), sizes, sizes, taps=taps, **kw)
+        t_frame = time.perf_counter() - t0
+        if field == "two_plateau":
+            g2 = (cfg.sam.grid,) * 2
+            pe = O.sam_dense_pe(sd, V + ".prompt_encoder", g2)
+            sp, de = O.sam_prompt_encoder_text(sd, V + ".prompt_encoder", taps["pred_embeddings"][0].unsqueeze(1), g2)
+            field_diag = {}
+            for side, tax_on in (("left", True), ("right", False)):
+                key, new_bias, d = PB.plateau_bias(O, sd, f"{V}.mask_decoder_{side}", taps["image_embeddings"], pe, sp, de, tax_on, region)
+                sd[key] = new_bias
+                sd_dev[key] = new_bias.to(device, torch.bfloat16)
+                field_diag[side] = d
+            outs = {}
+            for side, tax_on in (("left", True), ("right", False)):
+                lo = O.sam_mask_decoder(sd, f"{V}.mask_decoder_{side}", taps["image_embeddings"], pe, sp, de, tax_on)
+                outs[side] = O.sam_postprocess_masks(lo[0], S, sizes[0], sizes[0])[:, 0]
+                if tax_on:
+                    r_tax = [lo[2]]
+            r_left, r_right = [outs["left"]], [outs["right"]]
+        ref = {"left": r_left[0], "right": r_right[0]}
+        oracle_variants = {}
+        if attribution and field == "gaussian":
+            t0 = time.perf_counter()
+            for tag, pts in (("sam", ("sam",)), ("llama", ("llama",)), ("clip", ("clip",)), ("all", ("sam", "clip", "llama"))):
+                _, vl, vr, _ = O.lisa_evaluate(sd, cfg, clip, images, ids.cpu(), sizes, sizes, points=pts, **kw)
+                oracle_variants[tag] = {"left": vl[0], "right": vr[0]}
+            t_attr = time.perf_counter() - t0
+        else:
+            attribution = False
+    del sd, memo
+
+    if variants is None:
+        variants = FULL_FRAME_VARIANTS
     runs = [(m, None) for m in modes] + [(k, f) for k, f in variants.items()]
     hip = {}
     for name, tweak in runs:
@@ -511,29 +586,8 @@ def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf1
                      "emb": emb.float().view(1, g, g, -1).permute(0, 3, 1, 2).contiguous().cpu(), "first_call_s": first_call_s}
         del model, hidden, pred, emb, left, right
         torch.cuda.empty_cache()
-
-    t0 = time.perf_counter()
-    sd = OrderedDict()
-    for k in list(sd_dev.keys()):
-        sd[k] = sd_dev.pop(k).cpu().float()
     del sd_dev
     torch.cuda.empty_cache()
-    t_copy = time.perf_counter() - t0
-    memo, taps = {}, {}
-    kw = dict(max_new_tokens=n_gen, forced_answer=forced.cpu(), use_cache=True, memo=memo)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        r_ids, r_left, r_right, r_tax = O.lisa_evaluate(sd, cfg, clip, images, ids.cpu(), sizes, sizes, taps=taps, **kw)
-        t_frame = time.perf_counter() - t0
-        ref = {"left": r_left[0], "right": r_right[0]}
-        oracle_variants = {}
-        if attribution:
-            t0 = time.perf_counter()
-            for tag, pts in (("sam", ("sam",)), ("llama", ("llama",)), ("clip", ("clip",)), ("all", ("sam", "clip", "llama"))):
-                _, vl, vr, _ = O.lisa_evaluate(sd, cfg, clip, images, ids.cpu(), sizes, sizes, points=pts, **kw)
-                oracle_variants[tag] = {"left": vl[0], "right": vr[0]}
-            t_attr = time.perf_counter() - t0
-    del sd, memo
 
     def rel(a, b):
         return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
@@ -567,14 +621,18 @@ def parity_full_frame(cfg, device, threads, text_tokens=32, n_gen=8, modes=("bf1
         return out
 
     seg_rows = O.seg_token_mask(r_ids, cfg.seg_token_idx)
-    field = {h: {"std": ref[h].std().item(), "abs_max": ref[h].abs().max().item(), "positive_frac": (ref[h] > 0).float().mean().item()}
-             for h in ("left", "right")}
+    field_name = field
+    field_stats = {h: {"std": ref[h].std().item(), "abs_max": ref[h].abs().max().item(), "positive_frac": (ref[h] > 0).float().mean().item(),
+                       "frac_within_5pct_of_scale_of_threshold": (ref[h].abs() < 0.05 * ref[h].abs().max()).float().mean().item()}
+                   for h in ("left", "right")}
     par = {"what": "ONE full-depth frame: %s, %dx%d uint8 frame, %d-id prompt (T = %d), %d forced answer tokens with one [SEG]; HIP "
                    "path from the uint8 frame (device ingest), oracle from inference.preprocess + CLIPImageProcessor; ONE weight set "
                    "(device generator, seed %d, bf16 values; fp32 mode and the oracle see the same values widened)" %
                    (cfg.name, S, S, ids.shape[1], ids.shape[1] + 255, n_gen, seed),
            "reference": "/root/reference/2Haff/model/LISA.py:432-534 (evaluate) restated in oracle/lisa_oracle.py",
-           "oracle_logit_field": field}
+           "oracle_logit_field": field_stats, "field": field_name}
+    if field_diag is not None:
+        par["two_plateau_construction"] = field_diag
     for name in hip:
         h = hip[name]
         st = mask_stats(h, ref)
@@ -986,6 +1044,8 @@ def main(argv=None):
                     help="workgroups per persistent GEMM launch for each encoder chunk (haff_gemm_stream_cap), e.g. 256,256,224,224; "
                          "'auto' = LisaMI355's rule, 'off' = one per CU everywhere (A/B)")
     ap.add_argument("--sam-waits-for-prefill", default="auto", choices=["auto", "on", "off"])
+    ap.add_argument("--sam-dual-streams", default="auto", choices=["auto", "on", "off"],
+                    help="two encoder passes side by side on half the CUs each (LisaMI355.sam_dual_streams; round 6) / one after another")
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--fold-norms", action="store_true", help="(default since round 3 for the ViT-H geometry; kept for old command lines)")
@@ -1009,6 +1069,9 @@ def main(argv=None):
     ap.add_argument("--fp32-stream", default="off", choices=["off", "sam", "llm", "both"],
                     help="bf16 mode with the ViT-H and / or Llama residual stream kept in fp32 between the bf16 MFMA products "
                          "(LisaMI355(fp32_stream=...): 2-3x closer to the reference at depth 32; DESIGN.md section 2)")
+    ap.add_argument("--neck-f32", action="store_true", help="bf16 mode: the ViT-H neck on the f32-input MFMA path (LisaMI355(neck_f32=True))")
+    ap.add_argument("--unfused-fp32-stream", action="store_true",
+                    help="--fp32-stream sam/both: round 5's unfused form (LayerNorm kernels on the fp32 stream) instead of the fused epilogue (A/B)")
     ap.add_argument("--no-full-frame-parity", action="store_true",
                     help="parity: skip the one full-depth frame against the oracle on shared weights (~31 GB host RAM, ~1 min of CPU)")
     ap.add_argument("--attribution", action="store_true",
@@ -1058,7 +1121,8 @@ def main(argv=None):
     if args.fold_norms:
         cfg.sam.fold_norms = True
     model = LisaMI355(cfg, sd, dtype=run_dtype, device=device, sam_chunk="auto" if args.sam_chunk == "auto" else int(args.sam_chunk),
-                      fp32_stream=False if args.fp32_stream == "off" else args.fp32_stream)
+                      fp32_stream=False if args.fp32_stream == "off" else args.fp32_stream, neck_f32=args.neck_f32)
+    model.sam_encoder.fused_fp32_stream = not args.unfused_fp32_stream
     if args.fold_norms:
         model.sam_encoder.fold_norms = True
     model.overlap_streams = not args.single_stream
@@ -1066,6 +1130,8 @@ def main(argv=None):
         model.sam_waits_for_prefill = args.sam_waits_for_prefill == "on"
     model.sam_chunk_caps = {"auto": "auto", "off": None}.get(args.sam_caps) if args.sam_caps in ("auto", "off") else \
         [int(c) for c in args.sam_caps.split(",")]
+    if args.sam_dual_streams != "auto":
+        model.sam_dual_streams = args.sam_dual_streams == "on"
     if args.tables_global:
         model.sam_encoder.fused_global = False
     if args.no_fold_norms:
@@ -1185,10 +1251,11 @@ def main(argv=None):
                          "answer tokens with [SEG], KV-cached greedy decode, random-init weights; CLIP + SAM preprocessing of the "
                          "uint8 frames on the device inside the step" % (cfg.name, B, S, S, args.text_tokens, T_exp, args.n_gen),
                          B, {"hip_streams": 2 if model.overlap_streams else 1, "fp32_decoder_tail": bool(model.fp32_tail),
-                             "fp32_residual_stream": args.fp32_stream,
+                             "fp32_residual_stream": args.fp32_stream, "neck_f32": bool(args.neck_f32),
+                             "overlap_rates": model.last_rates.source if model.last_rates is not None else None,
                              # how the two streams shared the CUs in the timed steps (overlap.py): frames per encoder pass, workgroups per
                              # persistent GEMM launch of each pass (null = one per CU everywhere)
-                             "sam_chunk": plan_timed[2], "sam_chunk_workgroup_caps": plan_timed[0],
+                             "sam_chunk": plan_timed[2], "sam_chunk_workgroup_caps": plan_timed[0], "sam_dual_streams": bool(model.sam_dual_streams),
                              "sam_waits_for_prefill": plan_timed[1]})
         line["roofline"] = roofline
         line["rccl_ranks"] = n_ranks
@@ -1263,7 +1330,8 @@ def main(argv=None):
             del model
             line["parity"] = parity_vs_oracle(device)
             # which entry of the parity objects belongs to the number this line prints (the compact line quotes that one)
-            line["parity"]["timed_mode"] = "fp32" if f32_mode else ("bf16" if args.fp32_stream == "off" else "bf16_fp32_stream")
+            line["parity"]["timed_mode"] = "fp32" if f32_mode else ("bf16" if args.fp32_stream == "off" else
+                                                                    ("bf16_fp32_stream_f32neck" if args.neck_f32 else "bf16_fp32_stream"))
             if full_parity is not None:
                 line["parity"]["full_frame"] = full_parity.get("parity", full_parity)
                 line["parity"]["gate"]["failed"] += (full_parity.get("parity") or {}).get("gate", {}).get("failed", [])

@@ -83,7 +83,8 @@ int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C,
 int haff_gemm_bf16_heads(const void* A, long lda, const void* W, long ldw, void* C, const float* bias, const int* row_map,
                          const float* ln_stats, const float* ln_colsum, int M, int N, int K, int d, int heads, long part_stride,
                          long head_stride, void* stream);
-/* How many workgroups the persistent 8-wave tile launches enqueued ON `stream` take from now on (256 = one per CU, the default;
+/* How many workgroups the persistent launches (the 8-wave GEMM tile; since round 6 also the window-attention kernel) enqueued ON
+ * `stream` take from now on (256 = one per CU, the default;
  * read when a launch is enqueued or captured). Scheduling, not arithmetic: results are bit-identical for every value. The caller
  * lowers it for the launches of ONE stream so that kernels of another stream find free CUs while they run — LisaMI355.evaluate does
  * for the later passes of the SAM encoder (image_encoder.py:107-121) on its encoder stream, which run beside the HBM-bound decode
@@ -110,6 +111,15 @@ int haff_gemm_bf16_qkv_rope(const void* A, long lda, const void* Wp, long ldw, v
 int haff_gemm_bf16_rowstats(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, void* C,
                             long ldc, const float* bias, const void* resid, long ldr, int M, int N, int K,
                             float* stat_out, void* stream);
+/* haff_gemm_bf16_rowstats on an FP32 residual stream (the timed mode's option `fp32_stream`): X32 f32
+ * [M][ldx] is read and X32 + A.W^T + bias written back IN PLACE in fp32 (the residual adds of image_encoder.py:186-193 no longer
+ * round the stream to bf16 twice per block); C16 bf16 [M][ldc] receives the same sums rounded once — the MFMA operand of the next
+ * haff_gemm_bf16_ln, whose folded LayerNorm takes stat_out (f32 [M][N/64][2], from the fp32 sums) through
+ * haff_row_stats_finalize. a_map: optional A-side gather. Whole 256 x 256 tiles only (M % 256 == 0, N % 256 == 0, K % 64 == 0),
+ * ldx % 4 == 0, bias required; otherwise HAFF_ERR_UNSUPPORTED (-2) / HAFF_ERR_BAD_ARG (-1). */
+int haff_gemm_bf16_rowstats32(const void* A, long lda, const int* a_map, long a_rows, const void* W, long ldw, float* X32,
+                              long ldx, void* C16, long ldc, const float* bias, int M, int N, int K, float* stat_out,
+                              void* stream);
 /* parity-mode twin: everything f32. K % 4 == 0, lda/ldw % 4 == 0. */
 int haff_gemm_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, const float* bias,
                   const float* resid, long ldr, const int* row_map, int M, int N, int K, int act, int swiglu,

@@ -272,9 +272,19 @@ def test_stream_schedules_do_not_change_results(dev):
         assert all(torch.equal(a, b) for a, b in zip(refs[chunk], got)), (chunk, caps, wait, two)
         if two and caps not in (None, "auto"):
             assert model.last_plan[0] == caps and model.last_plan[1] == (wait is True or wait == "auto")   # 5 frames: late mode
+    # round 6: two encoder passes side by side on half the CUs each (sam_dual_streams) — scheduling only as well: even and odd
+    # pass counts (an odd pass out runs alone), with explicit caps and without, from frames_u8-free inputs the pairing is off
+    model.sam_dual_streams = True
+    for chunk, caps in ((2, None), (2, [256, 128, 64]), (1, [256, 256, 32, 32, 32]), (1, None), (3, [96, 160])):
+        model.sam_chunk, model.sam_chunk_caps, model.sam_waits_for_prefill, model.overlap_streams = chunk, caps, "auto", True
+        for _ in range(2):      # (the first call of a pass size runs its passes one after another: warm-up of the gather maps)
+            got = run()
+            assert all(torch.equal(a, b) for a, b in zip(refs[chunk], got)), ("dual", chunk, caps)
+    model.sam_dual_streams = False
     from haff import ops
     # every evaluate() leaves both streams' settings where it found them
     assert ops.gemm_stream_cap(0) == 256 and ops.gemm_stream_cap(0, stream=model._sam_stream) == 256
+    assert ops.gemm_stream_cap(0, stream=model._sam_stream2) == 256
 
 
 def test_sam_vith_width_windowed_blocks(dev):
@@ -339,6 +349,28 @@ def test_sam_vith_width_windowed_blocks(dev):
     d_s = (out_s - ref_cl).abs().max().item() / scale
     print(f"folded norms + producer statistics vs oracle {d_s:.3e}, vs statistics pass {(out_s - out_n).abs().max().item() / scale:.3e}")
     assert d_s <= 1.5e-2 and (out_s - out_n).abs().max().item() / scale <= 1.5e-2
+    # fp32 RESIDUAL STREAM (round 6): fused — proj / lin2 write the fp32 stream and its bf16 copy in one epilogue
+    # (haff_gemm_bf16_rowstats32), norms stay folded — against round 5's unfused form (LayerNorm kernels on the fp32 stream) and the
+    # oracle: the stream taps of both must be closer to the oracle's than the bf16 stream's, and close to each other
+    with torch.no_grad():
+        enc.producer_stats, enc.fp32_stream, enc.fused_fp32_stream = "force", True, True
+        taps_f = {}
+        out_32f = enc(images.to(dev), taps_f).float().cpu()
+        enc.fused_fp32_stream = False
+        taps_u = {}
+        out_32u = enc(images.to(dev), taps_u).float().cpu()
+        enc.fused_fp32_stream, enc.neck_f32 = True, True
+        out_32n = enc(images.to(dev)).float().cpu()
+        enc.neck_f32, enc.fp32_stream, enc.producer_stats = False, False, True
+    for i in range(3):
+        ref_t = taps_ref[f"block{i}"]
+        rf, ru, rb = [((t[f"block{i}"] - ref_t).pow(2).mean().sqrt() / ref_t.pow(2).mean().sqrt()).item() for t in (taps_f, taps_u, taps_c)]
+        print(f"vit-h width block{i} stream rms rel: fused fp32 {rf:.3e}, unfused fp32 {ru:.3e}, bf16 {rb:.3e}")
+        assert rf < rb and ru < rb, (i, rf, ru, rb)
+        assert rf <= 1.6 * ru + 1e-4, (i, rf, ru)       # fused rounds the stream once per operand, unfused the normalised row: same size
+    d32 = [(o - ref_cl).abs().max().item() / scale for o in (out_32f, out_32u, out_32n)]
+    print(f"fp32 stream vs oracle: fused {d32[0]:.3e}, unfused {d32[1]:.3e}, fused + f32 neck {d32[2]:.3e} (bf16 stream {d_s:.3e})")
+    assert max(d32) <= 1.5e-2
 
 
 def test_decode_graphs_match_eager(dev):

@@ -823,6 +823,52 @@ def test_linear_rowstats(dev, M, N, K, gather):
     assert torch.equal(o1, o2) and torch.equal(s1, s2)
 
 
+@pytest.mark.parametrize("M,N,K,gather", [(2048, 1280, 1280, False), (1024, 1280, 5120, False), (1536, 1280, 1280, True)])
+def test_linear_rowstats32_fp32_residual_stream(dev, M, N, K, gather):
+    """haff_gemm_bf16_rowstats32 (round 6, the fused fp32 residual stream): x32 += A.W^T + bias in place in fp32 — within fp32
+    accumulation noise of the fp64 sum, i.e. NOT rounded to bf16; out16 is exactly the bf16 rounding of the stored fp32 rows; the
+    {mean, rstd} handed on are those of the fp32 rows; the product part equals haff_gemm_bf16's accumulators (same tile, same K
+    loop: x32_new - x32_old == the bf16-free product to fp32 rounding of the add); repeat launches are bit-identical."""
+    ops = _ops()
+    x = _rand((M + 300 if gather else M, K), dev, torch.bfloat16, 90)
+    w = _rand((N, K), dev, torch.bfloat16, 91, K ** -0.5)
+    bias = _rand((N,), dev, torch.float32, 92)
+    x32_0 = _rand((M, N), dev, torch.float32, 93, 3.0) + 2.0
+    a_map = None
+    if gather:
+        g = torch.Generator(device="cpu").manual_seed(94)
+        a_map = torch.randperm(M + 300, generator=g)[:M].to(torch.int32).to(dev)
+    xa = x if a_map is None else x[a_map.long()]
+    exact = x32_0.double() + xa.double() @ w.double().T + bias.double()
+
+    def run():
+        x32 = x32_0.clone()
+        out16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        st = ops.linear_rowstats32(x, w, bias, x32, out16, 1e-6, a_map=a_map)
+        torch.cuda.synchronize()
+        return x32, out16, st
+    x32, out16, st = run()
+    err = (x32.double() - exact).abs().max().item()
+    assert err <= 2e-5 * exact.abs().max().item(), err          # fp32 accumulation over K, far below a bf16 ulp (4e-3 relative)
+    assert torch.equal(out16, x32.to(torch.bfloat16)), "the bf16 copy is not the RNE rounding of the stored fp32 stream"
+    mean = exact.mean(1)
+    rstd = (exact.var(1, unbiased=False) + 1e-6).rsqrt()
+    assert (st[:, 0].double() - mean).abs().max().item() <= 1e-4 * mean.abs().max().item() + 1e-5
+    assert ((st[:, 1].double() - rstd).abs() / rstd).max().item() <= 2e-4
+    # the same product through haff_gemm_bf16 with an fp32 residual and fp32 output (the unfused form's epilogue)
+    ref32 = ops.linear(x, w, bias=bias, resid=x32_0.clone(), a_map=a_map, out_dtype=torch.float32)
+    assert (ref32 - x32).abs().max().item() <= 2e-5 * exact.abs().max().item()
+    x32b, out16b, stb = run()
+    assert torch.equal(x32, x32b) and torch.equal(out16, out16b) and torch.equal(st, stb)
+    # contract: shapes that are not whole 256 x 256 tiles are refused, nothing is written
+    import haff.ops as hops
+    lib = hops.load_library()
+    part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=dev)
+    rc = lib.haff_gemm_bf16_rowstats32(x.data_ptr(), x.stride(0), None, 0, w.data_ptr(), w.stride(0), x32.data_ptr(), x32.stride(0),
+                                       out16.data_ptr(), out16.stride(0), bias.data_ptr(), M - 16, N, K, part.data_ptr(), None)
+    assert rc == -2
+
+
 @pytest.mark.parametrize("ratio", [30.0, 100.0])
 def test_linear_rowstats_with_a_large_row_mean(dev, ratio):
     """the producer's statistics are {sum, sum of squares} of fp32 values, so the variance is a difference of two

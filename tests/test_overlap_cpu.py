@@ -27,6 +27,27 @@ def test_plan_reproduces_the_measured_optima():
     assert overlap.auto_chunk(16, True) == 16 and overlap.auto_chunk(1, True) == 1
 
 
+def test_plan_moves_smoothly_with_the_rates():
+    """calibrate() scales the rates by what the device's probes read (boxes of this pool differ by ~5 %): a uniformly faster or
+    slower box keeps every plan (only ratios enter); a box whose matrix cores / HBM differ by up to 10 % from nominal moves a cap by
+    at most one step of CAPS, never the structure (which passes are capped, whether the encoder waits)."""
+    from dataclasses import replace
+    c7 = hcfg.haff_7b()
+    N = overlap.NOMINAL
+    cases = [(64, 16, False), (32, 8, False), (16, 16, True), (8, 8, True), (4, 4, True)]
+    for f in (0.9, 0.95, 1.05, 1.1):
+        uni = replace(N, enc=N.enc * f, llm=N.llm * f, stream_bw_per_cu=tuple(v * f for v in N.stream_bw_per_cu))
+        for frames, chunk, late in cases:
+            assert overlap.plan(c7, frames, chunk, 36, 8, late, uni) == overlap.plan(c7, frames, chunk, 36, 8, late)
+        for skew in (replace(N, enc=N.enc * f, llm=N.llm * f), replace(N, stream_bw_per_cu=tuple(v * f for v in N.stream_bw_per_cu))):
+            for frames, chunk, late in cases:
+                a, wa = overlap.plan(c7, frames, chunk, 36, 8, late)
+                b, wb = overlap.plan(c7, frames, chunk, 36, 8, late, skew)
+                assert wa == wb and len(a) == len(b)
+                steps = (256,) + tuple(reversed(overlap.CAPS))
+                assert all(abs(steps.index(x) - steps.index(y)) <= 1 for x, y in zip(a, b)), (f, frames, a, b)
+
+
 def test_plans_are_well_formed():
     for cfg in (hcfg.haff_7b(), hcfg.haff_13b(), hcfg.tiny()):
         for frames in (1, 2, 3, 4, 5, 8, 13, 16, 17, 24, 32, 48, 64, 100):

@@ -37,6 +37,41 @@ def two_region_frame(S, seed, contrast=1.0):
     return torch.from_numpy(img[None].astype(np.float32)).to(torch.bfloat16).float(), torch.from_numpy(left)
 
 
+def two_region_frame_u8(S, seed):
+    """[1, S, S, 3] uint8 NHWC (what the timed step ingests) + the boolean left-region map: two flat colours either side of the same
+    wavy boundary, + noise of 5 grey levels."""
+    rng = np.random.default_rng(seed)
+    ca, cb = rng.uniform(40, 100, 3), rng.uniform(150, 220, 3)
+    yy, xx = np.mgrid[0:S, 0:S]
+    left = xx < S / 2 + S / 10 * np.sin(2 * np.pi * yy / S)
+    img = np.where(left[..., None], ca[None, None, :], cb[None, None, :]) + 5.0 * rng.standard_normal((S, S, 3))
+    return torch.from_numpy(np.clip(np.rint(img), 0, 255).astype(np.uint8))[None], torch.from_numpy(left)
+
+
+def plateau_bias(O, sd, pfx, image_embeddings, pe, sp, de, tax_on, left_region):
+    """The re-aimed last-layer bias of output_hypernetworks_mlps.0 of decoder `pfx` (see the module docstring): from the ORACLE's own
+    fp32 decoder pass on (image_embeddings, prompt) -> (state-dict key, new bias (bf16-representable fp32), diagnostics)."""
+    t = {}
+    O.sam_mask_decoder(sd, pfx, image_embeddings, pe, sp, de, tax_on, taps=t)
+    U, h = t["upscaled"][0], t["hyper"][0, 0]                 # [32, hh, ww], [32]
+    hh = U.shape[1]
+    region = torch.nn.functional.interpolate(left_region[None, None].float(), size=(hh, hh), mode="area")[0, 0]
+    inA, inB = region > 0.999, region < 0.001                 # low-res cells wholly inside a region
+    XA, XB = U[:, inA].double(), U[:, inB].double()           # [32, nA], [32, nB]
+    uA, uB = XA.mean(1), XB.mean(1)
+    # Fisher's direction: the separation of the two clusters measured in units of their own scatter is largest along
+    # Sw^-1 (uA - uB); a second vector Sw^-1 (uA + uB) carries the offset so that the plateaus sit at +M and -M
+    Sw = ((XA - uA[:, None]) @ (XA - uA[:, None]).T + (XB - uB[:, None]) @ (XB - uB[:, None]).T) / (XA.shape[1] + XB.shape[1])
+    Sw = Sw + 1e-6 * torch.trace(Sw) / Sw.shape[0] * torch.eye(Sw.shape[0], dtype=torch.float64)
+    w1, w2 = torch.linalg.solve(Sw, uA - uB), torch.linalg.solve(Sw, uA + uB)
+    A2 = torch.stack([torch.stack([w1 @ uA, w2 @ uA]), torch.stack([w1 @ uB, w2 @ uB])])
+    ab = torch.linalg.solve(A2, torch.tensor([M_PLATEAU, -M_PLATEAU], dtype=torch.float64))
+    hp = (ab[0] * w1 + ab[1] * w2).float()
+    key = f"{pfx}.output_hypernetworks_mlps.0.layers.2.bias"
+    new_bias = (sd[key] + (hp - h)).to(torch.bfloat16).float()
+    return key, new_bias, {"plateau_gap_in_U": float((uA - uB).float().norm()), "hyper_norm": float(hp.norm())}
+
+
 def build_case(cfg_name="tiny", seed=3, contrast=1.0):
     """-> dict(cfg, sd (modified, bf16-representable), images, images_clip, ids, forced, diag) ; the oracle is the only forward used."""
     from oracle import lisa_oracle as O
@@ -56,26 +91,8 @@ def build_case(cfg_name="tiny", seed=3, contrast=1.0):
         pe = O.sam_dense_pe(sd, V + ".prompt_encoder", g)
         sp, de = O.sam_prompt_encoder_text(sd, V + ".prompt_encoder", taps["pred_embeddings"][0].unsqueeze(1), g)
         for side, tax in (("left", True), ("right", False)):
-            t = {}
-            O.sam_mask_decoder(sd, f"{V}.mask_decoder_{side}", taps["image_embeddings"], pe, sp, de, tax, taps=t)
-            U, h = t["upscaled"][0], t["hyper"][0, 0]                 # [32, hh, ww], [32]
-            hh = U.shape[1]
-            region = torch.nn.functional.interpolate(left[None, None].float(), size=(hh, hh), mode="area")[0, 0]
-            inA, inB = region > 0.999, region < 0.001                 # low-res cells wholly inside a region
-            XA, XB = U[:, inA].double(), U[:, inB].double()           # [32, nA], [32, nB]
-            uA, uB = XA.mean(1), XB.mean(1)
-            # Fisher's direction: the separation of the two clusters measured in units of their own scatter is largest along
-            # Sw^-1 (uA - uB); a second vector Sw^-1 (uA + uB) carries the offset so that the plateaus sit at +M and -M
-            Sw = ((XA - uA[:, None]) @ (XA - uA[:, None]).T + (XB - uB[:, None]) @ (XB - uB[:, None]).T) / (XA.shape[1] + XB.shape[1])
-            Sw = Sw + 1e-6 * torch.trace(Sw) / Sw.shape[0] * torch.eye(Sw.shape[0], dtype=torch.float64)
-            w1, w2 = torch.linalg.solve(Sw, uA - uB), torch.linalg.solve(Sw, uA + uB)
-            A2 = torch.stack([torch.stack([w1 @ uA, w2 @ uA]), torch.stack([w1 @ uB, w2 @ uB])])
-            ab = torch.linalg.solve(A2, torch.tensor([M_PLATEAU, -M_PLATEAU], dtype=torch.float64))
-            hp = (ab[0] * w1 + ab[1] * w2).float()
-            uA, uB = uA.float(), uB.float()
-            key = f"{V}.mask_decoder_{side}.output_hypernetworks_mlps.0.layers.2.bias"
-            sd[key] = (sd[key] + (hp - h)).to(torch.bfloat16).float()
-            diag[side] = {"plateau_gap_in_U": float((uA - uB).norm()), "hyper_norm": float(hp.norm())}
+            key, new_bias, diag[side] = plateau_bias(O, sd, f"{V}.mask_decoder_{side}", taps["image_embeddings"], pe, sp, de, tax, left)
+            sd[key] = new_bias
         r_ids, r_left, r_right, r_tax = O.lisa_evaluate(sd, cfg, images_clip, images, ids, [(S, S)], [(S, S)], max_new_tokens=4,
                                                          forced_answer=forced)
     for side, m in (("left", r_left[0]), ("right", r_right[0])):
