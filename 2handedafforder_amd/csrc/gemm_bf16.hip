@@ -1760,8 +1760,6 @@ struct StreamCapTable {
 };
 StreamCapTable g_stream_caps;
 }  // namespace
-// (library-internal: the other persistent kernels — window attention — size their grids by the same per-stream setting)
-int haff_internal_stream_cap(void* stream) { return g_stream_caps.get(stream); }
 extern "C" int haff_gemm_stream_cap(void* stream, int cap) {
   if (!(cap >= 8 && cap <= 256 && (cap & 7) == 0)) return g_stream_caps.get(stream);   // not a valid cap: a query
   const int old = g_stream_caps.set(stream, cap);

@@ -124,6 +124,3 @@ static inline int haff_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? HAFF_OK : HAFF_ERR_LAUNCH;
 }
-
-// workgroups a persistent launch on `stream` may take (haff_gemm_stream_cap's per-stream table, gemm_bf16.hip); 256 = one per CU
-int haff_internal_stream_cap(void* stream);

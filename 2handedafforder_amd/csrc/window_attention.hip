@@ -510,9 +510,7 @@ extern "C" int haff_window_attention_bf16(const void* q, long q_sb, long q_sh, l
     return HAFF_ERR_LAUNCH;
   // persistent: one 7-wave workgroup per CU (150 KB LDS); a multiple of 8 workgroups keeps the item -> XCD mapping
   const int n_items = n_windows * H;
-  // ... fewer when the caller capped this stream's persistent launches (haff_gemm_stream_cap: CUs left to another stream)
-  const int cap = haff_internal_stream_cap(stream);
-  dim3 grid(n_items < cap ? n_items : cap), block(C::NTHREADS);
+  dim3 grid(n_items < 256 ? n_items : 256), block(C::NTHREADS);
   hipLaunchKernelGGL((window_attn_kernel<80, 14>), grid, block, C::LDS_BYTES, reinterpret_cast<hipStream_t>(stream), p);
   return haff_check_launch();
 }

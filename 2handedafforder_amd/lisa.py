@@ -41,20 +41,10 @@ class LisaMI355:
         # evaluate() call, None = every launch on all CUs, or an explicit list of workgroup caps per encoder chunk;
         # sam_waits_for_prefill "auto" | True | False (late mode: the encoder starts behind the prefill on the GPU too).
         self.sam_chunk_caps = "auto"
-        # Round 6: TWO encoder passes side by side, each on half the CUs its turn would take (two HIP streams, each launch capped
-        # at cap / 2 workgroups): the persistent GEMM tiles of ONE launch reach their epilogues in the same microsecond on every CU
-        # (a 64 MiB burst per round of tiles); two half-chip launch sequences drift against each other, so
-        # one half's epilogue bursts and its HBM-bound kernels (window attention, statistics) run under the other half's K loops.
-        # Frames are independent through the whole encoder (image_encoder.py:110-125), results are bit-identical. False = passes
-        # one after another on the whole chip (rounds 1-5).
-        self.sam_dual_streams = False
-        self._sam_stream2 = torch.cuda.Stream(device=self.device)
-        self._dual_warm = set()
         self.sam_waits_for_prefill = "auto"
         self.calibrate_overlap = True         # False: the plan uses overlap.NOMINAL (round 5's fitted constants) whatever the device
         self.last_rates = None
         self.expected_new_tokens = 8          # what the plan assumes a reply takes ("Sure, ... [SEG] ." templates) when max_new_tokens is larger
-        self._dual_active = False
         self._plan = (None, False, None)      # (caps, wait, chunk) of the evaluate() call in flight (no caps outside one)
         self.last_plan = (None, False, None)  # ... of the last evaluate() call (what bench.py reports)
         # The SAM encoder runs on its own HIP stream beside the language model and joins before the mask decoders
@@ -266,8 +256,6 @@ class LisaMI355:
         "auto": overlap.plan, decided per evaluate() call."""
         caps = self._plan[0]
         cap = caps[min(n, len(caps) - 1)] if caps and self.overlap_streams else 256
-        if self._dual_active:
-            cap = max(8, (cap // 2) // 8 * 8)      # this pass shares its turn with the pass on the other encoder stream
         if cap == 256:
             yield
             return
@@ -289,38 +277,11 @@ class LisaMI355:
         ch = self._chunk(F)
         emb = torch.empty((F, enc.cfg.grid ** 2, enc.cfg.out_chans), dtype=torch.float32 if enc.emb_f32 else enc.dtype, device=self.device) \
             if F > ch else None
-        starts = list(range(0, F, ch))
-        # two passes at a time on two streams (sam_dual_streams): pass sizes seen for the first time run alone once (their gather
-        # maps and lazily built tables are created by whoever comes first; after that both streams only read them)
-        dual = self.sam_dual_streams and emb is not None and len(starts) >= 2
-        if dual:
-            sizes = {min(ch, F - i) for i in starts}
-            if not sizes <= self._dual_warm:
-                self._dual_warm |= sizes
-                dual = False
-        if not dual:
-            for n, i in enumerate(starts):
-                k = min(ch, F - i)
-                with self._chunk_cap(n, F):
-                    y = enc.forward_rows(rows_of(i, k), k, out=None if emb is None else emb[i:i + k])
-            return y if emb is None else emb
-        cur, s2 = torch.cuda.current_stream(self.device), self._sam_stream2
-        s2.wait_stream(cur)
-        self._dual_active = True
-        try:
-            for n, i in enumerate(starts):
-                k = min(ch, F - i)
-                # pass n of a pair takes the plan's cap of the pair's FIRST pass (both halves of one turn)
-                with torch.cuda.stream(s2 if n & 1 else cur), self._chunk_cap(n & ~1, F):
-                    enc.forward_rows(rows_of(i, k), k, out=emb[i:i + k])
-                if n == len(starts) - 2 and len(starts) & 1:
-                    # an odd pass out at the end: it runs alone on its turn's full cap, behind both halves
-                    cur.wait_stream(s2)
-                    self._dual_active = False
-        finally:
-            self._dual_active = False
-        cur.wait_stream(s2)
-        return emb
+        for n, i in enumerate(range(0, F, ch)):
+            k = min(ch, F - i)
+            with self._chunk_cap(n, F):
+                y = enc.forward_rows(rows_of(i, k), k, out=None if emb is None else emb[i:i + k])
+        return y if emb is None else emb
 
     @torch.no_grad()
     def get_visual_embs(self, images):

@@ -1044,8 +1044,6 @@ def main(argv=None):
                     help="workgroups per persistent GEMM launch for each encoder chunk (haff_gemm_stream_cap), e.g. 256,256,224,224; "
                          "'auto' = LisaMI355's rule, 'off' = one per CU everywhere (A/B)")
     ap.add_argument("--sam-waits-for-prefill", default="auto", choices=["auto", "on", "off"])
-    ap.add_argument("--sam-dual-streams", default="auto", choices=["auto", "on", "off"],
-                    help="two encoder passes side by side on half the CUs each (LisaMI355.sam_dual_streams; round 6) / one after another")
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise the SAM encoder and the language model on one HIP stream (default: two streams)")
     ap.add_argument("--fold-norms", action="store_true", help="(default since round 3 for the ViT-H geometry; kept for old command lines)")
@@ -1130,8 +1128,6 @@ def main(argv=None):
         model.sam_waits_for_prefill = args.sam_waits_for_prefill == "on"
     model.sam_chunk_caps = {"auto": "auto", "off": None}.get(args.sam_caps) if args.sam_caps in ("auto", "off") else \
         [int(c) for c in args.sam_caps.split(",")]
-    if args.sam_dual_streams != "auto":
-        model.sam_dual_streams = args.sam_dual_streams == "on"
     if args.tables_global:
         model.sam_encoder.fused_global = False
     if args.no_fold_norms:
@@ -1255,7 +1251,7 @@ def main(argv=None):
                              "overlap_rates": model.last_rates.source if model.last_rates is not None else None,
                              # how the two streams shared the CUs in the timed steps (overlap.py): frames per encoder pass, workgroups per
                              # persistent GEMM launch of each pass (null = one per CU everywhere)
-                             "sam_chunk": plan_timed[2], "sam_chunk_workgroup_caps": plan_timed[0], "sam_dual_streams": bool(model.sam_dual_streams),
+                             "sam_chunk": plan_timed[2], "sam_chunk_workgroup_caps": plan_timed[0],
                              "sam_waits_for_prefill": plan_timed[1]})
         line["roofline"] = roofline
         line["rccl_ranks"] = n_ranks

@@ -83,8 +83,7 @@ int haff_gemm_bf16_ln(const void* A, long lda, const void* W, long ldw, void* C,
 int haff_gemm_bf16_heads(const void* A, long lda, const void* W, long ldw, void* C, const float* bias, const int* row_map,
                          const float* ln_stats, const float* ln_colsum, int M, int N, int K, int d, int heads, long part_stride,
                          long head_stride, void* stream);
-/* How many workgroups the persistent launches (the 8-wave GEMM tile; since round 6 also the window-attention kernel) enqueued ON
- * `stream` take from now on (256 = one per CU, the default;
+/* How many workgroups the persistent 8-wave tile launches enqueued ON `stream` take from now on (256 = one per CU, the default;
  * read when a launch is enqueued or captured). Scheduling, not arithmetic: results are bit-identical for every value. The caller
  * lowers it for the launches of ONE stream so that kernels of another stream find free CUs while they run — LisaMI355.evaluate does
  * for the later passes of the SAM encoder (image_encoder.py:107-121) on its encoder stream, which run beside the HBM-bound decode

@@ -272,19 +272,9 @@ def test_stream_schedules_do_not_change_results(dev):
         assert all(torch.equal(a, b) for a, b in zip(refs[chunk], got)), (chunk, caps, wait, two)
         if two and caps not in (None, "auto"):
             assert model.last_plan[0] == caps and model.last_plan[1] == (wait is True or wait == "auto")   # 5 frames: late mode
-    # round 6: two encoder passes side by side on half the CUs each (sam_dual_streams) — scheduling only as well: even and odd
-    # pass counts (an odd pass out runs alone), with explicit caps and without, from frames_u8-free inputs the pairing is off
-    model.sam_dual_streams = True
-    for chunk, caps in ((2, None), (2, [256, 128, 64]), (1, [256, 256, 32, 32, 32]), (1, None), (3, [96, 160])):
-        model.sam_chunk, model.sam_chunk_caps, model.sam_waits_for_prefill, model.overlap_streams = chunk, caps, "auto", True
-        for _ in range(2):      # (the first call of a pass size runs its passes one after another: warm-up of the gather maps)
-            got = run()
-            assert all(torch.equal(a, b) for a, b in zip(refs[chunk], got)), ("dual", chunk, caps)
-    model.sam_dual_streams = False
     from haff import ops
     # every evaluate() leaves both streams' settings where it found them
     assert ops.gemm_stream_cap(0) == 256 and ops.gemm_stream_cap(0, stream=model._sam_stream) == 256
-    assert ops.gemm_stream_cap(0, stream=model._sam_stream2) == 256
 
 
 def test_sam_vith_width_windowed_blocks(dev):
