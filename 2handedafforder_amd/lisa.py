@@ -56,6 +56,9 @@ class LisaMI355:
         # captured once per (batch, position) into a hipGraph and replayed. The KV cache is persistent per
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
         self.decode_graphs = True
+        # evaluate(): the last Llama layer of the prefill runs o_proj / MLP / final norm on the rows that are read only (LlamaHip.forward,
+        # keep_rows; round 6). False: every row (A/B; generate() called directly always returns every row)
+        self.prune_last_layer = True
         self._ingest = None
         self._graphs = {}
         # one memory pool shared by every captured step. Replays never overlap: every graph is replayed on the caller's stream,
@@ -99,7 +102,8 @@ class LisaMI355:
 
     # ---- a6-a8: splice + greedy generate -----------------------------------------------------------------
     @torch.no_grad()
-    def generate(self, images_clip, input_ids, max_new_tokens=32, forced_answer=None, attention_mask=None, after_prefill=None):
+    def generate(self, images_clip, input_ids, max_new_tokens=32, forced_answer=None, attention_mask=None, after_prefill=None,
+                 needed_hidden_only=False):
         """Greedy KV-cached decode (LISA.py:443-450). Rows may have different prompt lengths: input_ids is right-padded
         (utils/dataset.py:90-93) and attention_mask [B, L] (bool, True on real tokens; None = every row is full length)
         marks the real prefix of each row, as collate_fn builds it (:144-150). Row b's generated tokens are appended right
@@ -127,7 +131,18 @@ class LisaMI355:
         t_rows = lens + (n_img - 1)                      # real positions per row after the splice
         cache = self._persistent_cache(B, T + max_new_tokens)
         st = cache["book"]
-        prefill = self.llm.forward(x, cache)             # causal: a row's real positions never see its padding
+        keep = None
+        if needed_hidden_only and self.prune_last_layer:
+            # evaluate() reads two kinds of prefill rows only: each row's last real position (the first token's logits) and the
+            # positions in front of a [SEG] that is part of the PROMPT (LISA.py:457-465 gathers the state that precedes the token);
+            # the last Llama layer skips o_proj / MLP / norm for every other row (LlamaHip.forward, keep_rows)
+            b_last = torch.arange(B, device=self.device) * T + (t_rows - 1)
+            pb, pt = ((input_ids[:, 1:] == self.seg_token_idx) &
+                      (torch.arange(1, L, device=self.device)[None, :] < lens[:, None])).nonzero(as_tuple=True)
+            # id position j + 1 holds [SEG] -> seg_embeddings reads hidden row j + 255 (the reference's fixed 255-row shift, wherever
+            # the <image> sentinel sits: LISA.py:459-463)
+            keep = torch.unique(torch.cat([b_last, pb * T + pt + (n_img - 1)]))
+        prefill = self.llm.forward(x, cache, keep_rows=keep)   # causal: a row's real positions never see its padding
         if after_prefill is not None:                    # work the caller wants enqueued (elsewhere) behind the prefill
             after_prefill()
         hidden, out_ids = st["hidden"], st["out_ids"]    # persistent [B, tmax, H] / [B, tmax]: the decode graph writes into them
@@ -399,7 +414,7 @@ class LisaMI355:
         if not late:
             launch_sam()
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask,
-                                           after_prefill=launch_sam if late else None)
+                                           after_prefill=launch_sam if late else None, needed_hidden_only=True)
         emb = sam_out[0]
         self._plan = (None, False, chunk)     # the encoder is enqueued: direct get_visual_embs* calls take no caps
         pred, frame_idx, counts = self.seg_embeddings(output_ids, hidden)

@@ -154,8 +154,13 @@ class LlamaHip:
                 "pos": torch.zeros((B,), dtype=torch.int32, device=self.device),
                 "nk": torch.ones((B,), dtype=torch.int32, device=self.device)}
 
-    def forward(self, x, cache):
-        """x [B,T,H] embeddings of the next T positions; appends to the cache; returns post-norm hidden [B,T,H]."""
+    def forward(self, x, cache, keep_rows=None):
+        """x [B,T,H] embeddings of the next T positions; appends to the cache; returns post-norm hidden [B,T,H].
+        keep_rows (round 6; int64 [n] flat row indices b * T + t, or None = all): the rows whose FINAL hidden state the caller will
+        read. Every position still runs through every layer's attention inputs (its K / V are what later tokens attend to), but in
+        the LAST layer only these rows take o_proj, the MLP and the final norm — nothing downstream of the last layer's K / V
+        depends on the other rows (llava_llama.py:93-105 returns them, LISA.py:443-485 never looks at them); their rows of the
+        result are zero. 75 % of the last layer's linear FLOPs: 0.9 % of the step at 64 frames."""
         l = self.cfg
         B, T, H = x.shape
         nh, hd = l.heads, self.hd
@@ -184,12 +189,20 @@ class LlamaHip:
             k = kc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)[:, :, :tk]
             v = vc.view(B, cache["tmax"], nh, hd).permute(0, 2, 1, 3)[:, :, :tk]
             a = ops.attention(q, k, v, hd ** -0.5, causal=T > 1, q_pos0=tk - T)
-            x = ops.linear(a.view(B * T, H), L["wo"], resid=x, out=x)
+            a2 = a.view(B * T, H)
+            if keep_rows is not None and li == len(self.layers) - 1:
+                a2, x = a2.index_select(0, keep_rows), x.index_select(0, keep_rows)   # (row gathers: the products below see n rows)
+            x = ops.linear(a2, L["wo"], resid=x, out=x)
             h = ops.rmsnorm(x, L["n2"], l.rms_eps, out_dtype=nd)
             g = ops.linear(h, L["wgu"], swiglu=True)
             x = ops.linear(g, L["wd"], resid=x, out=x)
         cache["len"] = pos0 + T
-        return ops.rmsnorm(x, self.norm, l.rms_eps, out_dtype=nd).view(B, T, H)
+        y = ops.rmsnorm(x, self.norm, l.rms_eps, out_dtype=nd)
+        if keep_rows is not None:
+            full = torch.zeros((B * T, H), dtype=y.dtype, device=y.device)
+            full.index_copy_(0, keep_rows, y)
+            y = full
+        return y.view(B, T, H)
 
     def decode_rows(self, x1, cache):
         """One KV-cached position per row at PER-ROW positions: x1 [B,1,H] is the embedding of row b's next token, which

@@ -1057,6 +1057,8 @@ def main(argv=None):
     ap.add_argument("--sam-beside-decode", default="auto", choices=["auto", "on", "off"],
                     help="where the SAM encoder is enqueued on its stream: on = behind the prefill (beside the HBM-bound decode steps), "
                          "off = first (beside CLIP + prefill), auto = by batch size (lisa.py)")
+    ap.add_argument("--no-prune-last-layer", action="store_true",
+                    help="Llama prefill: the last layer's o_proj / MLP / norm on every row instead of the rows evaluate() reads (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: skip the one real end-to-end CPU frame (~31 GB host RAM, ~1 min)")
     ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
@@ -1128,6 +1130,8 @@ def main(argv=None):
         model.sam_waits_for_prefill = args.sam_waits_for_prefill == "on"
     model.sam_chunk_caps = {"auto": "auto", "off": None}.get(args.sam_caps) if args.sam_caps in ("auto", "off") else \
         [int(c) for c in args.sam_caps.split(",")]
+    if args.no_prune_last_layer:
+        model.prune_last_layer = False
     if args.tables_global:
         model.sam_encoder.fused_global = False
     if args.no_fold_norms:

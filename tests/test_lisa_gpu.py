@@ -421,6 +421,69 @@ def test_multiple_and_missing_seg_tokens(dev):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_last_layer_pruning_keeps_every_row_that_is_read(dev, mode):
+    """Round 6: in evaluate() the last Llama layer of the prefill runs o_proj / MLP / final norm only on the rows that are read —
+    each row's last real position (first-token logits) and the state in front of a [SEG] that is part of the PROMPT (LISA.py:457-465
+    gathers hidden[j + 255] for every id position j + 1 that holds [SEG]). Ragged prompts, one prompt WITH a [SEG] in it, one whose
+    first generated token is [SEG] (its state is the prefill's last row) and one without any: ids, masks and taxonomy equal the
+    unpruned run's (fp32: to 1e-5 of the scale — the selected rows take the few-rows product kernels instead of the big tile, another
+    summation order; bf16: inside the bf16 band) and the oracle's; the kept hidden rows are the ones seg_embeddings reads."""
+    from haff.lisa import LisaMI355
+    from oracle import lisa_oracle as O
+    cfg, sd, images, images_clip, _, _ = _setup("tiny", mode, B=3)
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
+    S = cfg.sam.img_size
+    head = [cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]
+    prompts = [head + [11, 12, cfg.seg_token_idx, 14, 15], head + [21, 22, 23], head + [31, 32, 33, 34, 35, 36, 37]]
+    Lmax = max(len(p) for p in prompts)
+    ids = torch.full((3, Lmax), cfg.pad_token_id, dtype=torch.long)
+    mask = torch.zeros((3, Lmax), dtype=torch.bool)
+    for b, p in enumerate(prompts):
+        ids[b, :len(p)] = torch.tensor(p)
+        mask[b, :len(p)] = True
+    forced = torch.tensor([[7, 9, cfg.seg_token_idx, cfg.eos_token_id], [cfg.seg_token_idx, 8, cfg.eos_token_id, 0], [5, 6, 7, cfg.eos_token_id]])
+    sizes = [(S, S)] * 3
+    args = (images_clip.to(dev), images.to(dev), ids.to(dev), sizes, sizes)
+    with torch.no_grad():
+        assert model.prune_last_layer
+        po, pl, pr, pt = model.evaluate(*args, max_new_tokens=4, forced_answer=forced, attention_mask=mask)
+        model.prune_last_layer = False
+        fo, fl, fr_, ft = model.evaluate(*args, max_new_tokens=4, forced_answer=forced, attention_mask=mask)
+        model.prune_last_layer = True
+        # the rows the pruned prefill keeps, against the full prefill's
+        _, h_full = model.generate(args[0], args[2], 4, forced, mask)
+        _, h_keep = model.generate(args[0], args[2], 4, forced, mask, needed_hidden_only=True)
+    assert torch.equal(po, fo)
+    assert [m.shape[0] for m in pl] == [2, 1, 0] and [m.shape[0] for m in fl] == [2, 1, 0]    # prompt [SEG] + generated [SEG]; one; none
+    tol = 1e-5 if mode == "f32" else 2e-2
+    for got, ref in zip(pl + pr, fl + fr_):
+        if ref.numel():
+            assert (got - ref).abs().max().item() <= tol * ref.abs().max().item()
+    for got, ref in zip(pt, ft):
+        if ref.numel():
+            assert (got - ref).abs().max().item() <= (1e-5 if mode == "f32" else 2e-3)
+    T = Lmax + 255
+    nz = h_keep[:, :T].float().abs().sum(-1) > 0
+    want = torch.zeros_like(nz)
+    for b, p in enumerate(prompts):
+        want[b, len(p) + 255 - 1] = True
+        nz[b, len(p) + 255:] = False      # (behind a row's last real token: the states of ITS generated tokens, written by the decode steps)
+    want[0, 5 + 255] = True          # id position 6 of row 0 is [SEG]: the state at id position 5
+    assert torch.equal(nz.cpu(), want.cpu()), "the pruned prefill keeps exactly the rows evaluate() reads"
+    e = (h_keep[:, :T][nz] - h_full[:, :T][nz]).float().abs().max().item()
+    assert e <= tol * h_full[:, :T][nz].float().abs().max().item()
+    with torch.no_grad():
+        for b, p in enumerate(prompts[:2]):
+            one = torch.tensor([p])
+            ro, rl, rr, rt = O.lisa_evaluate(sd, cfg, images_clip[b:b + 1], images[b:b + 1], one, sizes[:1], sizes[:1],
+                                             max_new_tokens=4, forced_answer=forced[b:b + 1], use_cache=True)
+            assert rl[0].shape == pl[b].shape
+            scale = rl[0].abs().max().item()
+            assert (pl[b].cpu() - rl[0]).abs().max().item() <= (1e-3 if mode == "f32" else 1.5e-2 * scale)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_ragged_prompts_equal_batch1_runs(dev, mode):
     """Batched evaluate() over three prompts of DIFFERENT lengths (right-padded ids + attention mask, the padding rule of
     utils/dataset.py:90-93,144-150) == three independent batch-1 runs: output ids (left-aligned per row), [SEG] position
