@@ -23,6 +23,18 @@
 // the P.V MFMA from registers and V^T fragments come from transposed LDS reads with the same permuted k order.
 #include "haff_common.h"
 
+// Ablation hooks (counter / timing experiments: WRONG results) exist only in builds made with -DHAFF_TUNING
+// (tools/build_window_variant.sh): HAFF_WIN_NOKREAD / _NOVREAD leave out the K / V^T fragment reads from LDS, HAFF_WIN_NOSCR the
+// trips of the rel-pos terms through the wave-private scratch, HAFF_WIN_NODMA the HBM -> LDS staging.
+#ifndef HAFF_TUNING
+#undef HAFF_WIN_NOKREAD
+#undef HAFF_WIN_NOVREAD
+#undef HAFF_WIN_NOSCR
+#undef HAFF_WIN_NODMA
+#undef HAFF_WIN_RS
+#undef HAFF_WIN_KLAST_OLD
+#endif
+
 namespace {
 
 struct WinArgs {
@@ -71,7 +83,14 @@ struct WinCfg {
   static constexpr int KSTR = D * 2 + 16 * KPC;   // bytes
   static constexpr int VSTR = D * 2;
   static constexpr int NKS = (S + 1) / 2;       // P.V k-steps: two key tiles (grid rows) each
-  static constexpr int RS = 36;                 // scratch row stride in floats
+#ifdef HAFF_WIN_RS
+  static constexpr int RS = HAFF_WIN_RS;
+#else
+  // scratch row stride in floats: 52 since round 6 (36 before). The scratch's 16-B writes at a 144-B row stride and the rel_w
+  // reads behind them were half of the kernel's LDS bank-conflict cycles (tools/pmc_window_lds.sh: 6.45e6 of 12.5e6 per 32-frame
+  // launch; 40 -> 19.8e6, 44 -> 6.6e6, 52 -> 6.3e6 in all, 68 = 36: profiles/r6_pmc_window_attn_lds_ablation.txt)
+  static constexpr int RS = 52;
+#endif
   static constexpr int QPW = 2;                 // q-tiles (query-grid rows) per wave per item
   static constexpr int NWAVES = (S + QPW - 1) / QPW;   // 7 waves cover the 14 grid rows exactly
   static constexpr int NTHREADS = 64 * NWAVES;
@@ -200,6 +219,10 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
       const unsigned m0v = nx_lds0 + i * C::NTHREADS * 16;
       const bool is_pad = (int)(slot_pad[i] >> 28) >= nx_pad_h0 || (int)((slot_pad[i] >> 24) & 15u) >= nx_pad_w0;
       const unsigned off = is_pad ? nx_pad_base + (slot_pad[i] & 0xffu) + ((slot_pad[i] >> 23) & 1u) * vmk_bytes : slot_off[i];
+#ifdef HAFF_WIN_NODMA
+      asm volatile("" ::"v"(off), "s"(m0v));
+      continue;
+#endif
       if ((i + 1) * C::NTHREADS <= C::PAD_SLOTS || (i * C::NTHREADS + wave * 64) < C::PAD_SLOTS)   // wave-uniform
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(nx_kb), "s"(m0v)
                      : "memory");
@@ -315,6 +338,10 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tw[1][kd], qraw[kd], t1, 0, 0, 0);
         }
         float a[4] = {t0[0], t0[1], t0[2], t0[3]}, b[4] = {t1[0], t1[1], t1[2], t1[3]};
+#ifdef HAFF_WIN_NOSCR
+#pragma unroll
+        for (int j = 0; j < 4; ++j) relw4[j] = kw_ok[j] ? (a[j] + b[j]) * WLOG2E : -INFINITY;
+#else
         store4(scr + fr * C::RS + 4 * fh, a);
         store4(scr + fr * C::RS + 16 + 4 * fh, b);
         __builtin_amdgcn_wave_barrier();
@@ -324,6 +351,7 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
           relw4[j] = kw_ok[j] ? scr[fr * C::RS + r] * WLOG2E : -INFINITY;   // masked key columns stay -inf through the MFMAs
         }
         __builtin_amdgcn_wave_barrier();
+#endif
       }
       // ---- rel_h: same through the same scratch; r = qh - kh + S-1 is wave-uniform per key tile ----
       {
@@ -334,12 +362,17 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th[1][kd], qraw[kd], t1, 0, 0, 0);
         }
         float a[4] = {t0[0], t0[1], t0[2], t0[3]}, b[4] = {t1[0], t1[1], t1[2], t1[3]};
+#ifdef HAFF_WIN_NOSCR
+#pragma unroll
+        for (int kt = 0; kt < S; ++kt) relh_t[kt] = (a[kt & 3] + b[kt & 3]) * WLOG2E;
+#else
         store4(scr + fr * C::RS + 4 * fh, a);
         store4(scr + fr * C::RS + 16 + 4 * fh, b);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int kt = 0; kt < S; ++kt) relh_t[kt] = scr[fr * C::RS + (qh - kt + S - 1)] * WLOG2E;
         __builtin_amdgcn_wave_barrier();
+#endif
       }
 
       WTRACE(2 + 5 * t);
@@ -354,7 +387,15 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
       // the zero-padded last k-step (d = 80: columns 64..95) would read 32 bytes PAST an unpadded row for fh >= 2 — the next key's
       // first chunks, or V behind the last K row: finite only if the neighbour is (Inf / NaN x a zero Q column = NaN in ANOTHER
       // key's score). Those lanes re-read the row's own last chunk instead (the global kernel's k_lane2 does the same).
+#ifdef HAFF_WIN_KLAST_OLD
       const int koff_last = min(fh * 16 + (C::NKD - 1) * 64, D * 2 - 16);
+#else
+      // (round 6) ... and the two lanes groups past the row's end (fh >= 2, zero Q columns) take the two chunks IN FRONT of the last
+      // k-step's, so that the four lanes of a key still cover 64 contiguous bytes of its row (rotated): the same bank pattern as the
+      // full k-steps. Three lanes on one chunk (rounds 4-5) made this read a 2-way bank conflict (tools/pmc_window_lds.sh).
+      const int koff_last = (D * 2 - (C::NKD - 1) * 64 == 32) ? (C::NKD - 1) * 64 - 32 + ((fh + 2) & 3) * 16
+                                                              : min(fh * 16 + (C::NKD - 1) * 64, D * 2 - 16);
+#endif
 #pragma unroll
       for (int g0 = 0; g0 < S; g0 += KG) {
 #pragma unroll
@@ -362,7 +403,11 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
 #pragma unroll
           for (int kt = g0; kt < g0 + KG && kt < S; ++kt) {
             // A operand row = key (kh = kt, kw = fr)
+#ifdef HAFF_WIN_NOKREAD
+            const bf16x8 kf = qs[(kd + 1) % C::NKD];
+#else
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * S + qcol) * C::KSTR + (kd == C::NKD - 1 ? koff_last : fh * 16 + kd * 64));
+#endif
             sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qs[kd], sacc[kt], 0, 0, 0);
           }
         }
@@ -414,9 +459,14 @@ __global__ __launch_bounds__((WinCfg<D, S>::NTHREADS)) void window_attn_kernel(W
         const unsigned char* v1 = sV + (t1 * S + vkw) * C::VSTR + 8 * tr_p;
 #pragma unroll
         for (int dt = 0; dt < C::ND; ++dt) {
+#ifdef HAFF_WIN_NOVREAD
+          const bf16x8 vf = qs[dt % C::NKD];
+          asm volatile("" ::"v"(v0), "v"(v1));
+#else
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds_v4_ptr)(v0 + 32 * dt));
           const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds_v4_ptr)(v1 + 32 * dt));
           const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
           oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
         }
       }
