@@ -1247,9 +1247,12 @@ def main(argv=None):
         }
         T_exp = 4 + args.text_tokens + cfg.clip.n_patches - 1
         line = base_line(fps, world, args.steps, args.warmup, ms_per_step,
-                         "BASELINE.json configs[2]: %s, %d x %dx%d uint8 NHWC frames/step/GPU, %d-token prompt (T=%d), %d forced "
+                         "BASELINE.json %s: %s, %d x %dx%d uint8 NHWC frames/step/GPU, %d-token prompt (T=%d), %d forced "
                          "answer tokens with [SEG], KV-cached greedy decode, random-init weights; CLIP + SAM preprocessing of the "
-                         "uint8 frames on the device inside the step" % (cfg.name, B, S, S, args.text_tokens, T_exp, args.n_gen),
+                         "uint8 frames on the device inside the step" % (
+                             {("2HandedAfforder-7B", 64): "configs[2]", ("2HandedAfforder-7B", 1): "configs[1]",
+                              ("2HandedAfforder-13B", 8): "configs[4]"}.get((cfg.name, B), "geometry (no BASELINE config of this batch)"),
+                             cfg.name, B, S, S, args.text_tokens, T_exp, args.n_gen),
                          B, {"hip_streams": 2 if model.overlap_streams else 1, "fp32_decoder_tail": bool(model.fp32_tail),
                              "fp32_residual_stream": args.fp32_stream, "neck_f32": bool(args.neck_f32),
                              "overlap_rates": model.last_rates.source if model.last_rates is not None else None,
