@@ -362,6 +362,23 @@ def splice_embeddings(sd, input_ids, image_features):
     return torch.stack(rows, dim=0)
 
 
+def splice_labels(input_ids, labels, n_img=N_IMG_PAD + 1):
+    """The labels of prepare_inputs_labels_for_multimodal, mm_use_im_start_end branch (llava_arch.py:195-208,247-249): IGNORE_INDEX
+    over the n_img spliced image rows, every other label where its id went. Pinned against the reference's own method
+    (tests/golden/llava_glue_tiny.npz)."""
+    lab = []
+    for b in range(input_ids.shape[0]):
+        p = int(torch.where(input_ids[b] == IMAGE_TOKEN_INDEX)[0][0])
+        lab.append(torch.cat([labels[b, :p], torch.full((n_img,), -100, dtype=labels.dtype), labels[b, p + 1:]]))
+    return torch.stack(lab)
+
+
+def splice_attention_mask(attention_mask, n_img=N_IMG_PAD + 1):
+    """... and its attention mask (llava_arch.py:332-345, equal-length rows): n_img - 1 True columns on the LEFT of the caller's mask."""
+    pad = torch.ones((attention_mask.shape[0], n_img - 1), dtype=attention_mask.dtype)
+    return torch.cat([pad, attention_mask], dim=1)
+
+
 def seg_token_mask(output_ids, seg_token_idx, n_pad=N_IMG_PAD):
     """LISA.py:457-465: mask[:, 255 + j] is set iff token j+1 is [SEG]."""
     m = output_ids[:, 1:] == seg_token_idx
@@ -579,12 +596,7 @@ def lisa_model_forward(sd, cfg, batch, lora=None, lora_alpha=16.0, ce_loss_weigh
     x = splice_embeddings(sdw, input_ids, img)
     hidden = llama_forward(sdw, x, cfg.llm)
     logits = F.linear(hidden, sdw["lm_head.weight"])
-    # labels get IGNORE_INDEX over the spliced image span (llava_arch.py:195-205)
-    lab = []
-    for b in range(input_ids.shape[0]):
-        p = int(torch.where(input_ids[b] == IMAGE_TOKEN_INDEX)[0][0])
-        lab.append(torch.cat([labels[b, :p], torch.full((N_IMG_PAD + 1,), -100, dtype=labels.dtype), labels[b, p + 1:]]))
-    lab = torch.stack(lab)
+    lab = splice_labels(input_ids, labels)
     ce = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), lab[:, 1:].reshape(-1), ignore_index=-100)
     last = text_hidden_fcs(sdw, hidden)
     pred = last[m]

@@ -254,6 +254,107 @@ def host_goldens():
     print("host helpers ok:", c.get_prompt()[:80].replace("\n", "\\n"))
 
 
+def llava_glue_golden(name, cfg, seed):
+    """Rows a4-a6 through the REFERENCE'S OWN glue code (round 6): `CLIPVisionTower.forward / feature_select`
+    (llava/model/multimodal_encoder/clip_encoder.py:31-60) and `LlavaMetaForCausalLM.encode_images /
+    prepare_inputs_labels_for_multimodal` (llava/model/llava_arch.py:93-347), both imported by file path (the package's __init__ pulls
+    llava_llama.py, whose AutoConfig.register fails under transformers 5.15 — llava_arch.py itself imports cleanly). The methods run
+    untouched on duck-typed collaborators: a transformers CLIPVisionModel of the tiny geometry carrying the filler's weights placed in
+    a CLIPVisionTower made without its network-fetching __init__, an nn.Embedding + nn.Linear projector with the filler's weights as
+    the "model", a config object with mm_use_im_start_end = True (train_ds.py:76 / inference.py default). Inference-shaped rows
+    (labels = None) and training-shaped rows (labels, a right-padded attention mask) are captured."""
+    import types
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    base = "/root/reference/2Haff/model/llava/model"
+    if "/root/reference/2Haff" not in sys.path:
+        sys.path.insert(0, "/root/reference/2Haff")      # llava_arch.py: `from utils.utils import ...`
+    pkg = importlib.util.module_from_spec(importlib.util.spec_from_file_location(
+        "ref_llava_model", os.path.join(base, "__init__.py"), submodule_search_locations=[base]))
+    sys.modules["ref_llava_model"] = pkg                 # NOT executed
+    sub = types.ModuleType("ref_llava_model.multimodal_encoder")
+    sub.__path__ = [os.path.join(base, "multimodal_encoder")]
+    sys.modules["ref_llava_model.multimodal_encoder"] = sub
+    spec = importlib.util.spec_from_file_location("ref_llava_model.llava_arch", os.path.join(base, "llava_arch.py"))
+    arch = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = arch
+    spec.loader.exec_module(arch)
+    clip_mod = sys.modules["ref_llava_model.multimodal_encoder.clip_encoder"]
+
+    c, l = cfg.clip, cfg.llm
+    sd = hw.make_state_dict(cfg, seed, {**hw.clip_shapes(c), **{k: v for k, v in hw.llm_shapes(cfg).items()
+                                                                 if k.startswith("model.mm_projector") or k == "model.embed_tokens.weight"}})
+    hc = CLIPVisionConfig(hidden_size=c.hidden, intermediate_size=c.mlp, num_hidden_layers=c.layers, num_attention_heads=c.heads,
+                          image_size=c.image, patch_size=c.patch, hidden_act="quick_gelu", layer_norm_eps=c.eps,
+                          attn_implementation="eager")
+    vm = CLIPVisionModel(hc).eval()
+    pre = "model.vision_tower.vision_tower."
+    own = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    if not any(k.startswith("vision_model.") for k in vm.state_dict()):
+        own = {k[len("vision_model."):]: v for k, v in own.items()}
+    missing, unexpected = vm.load_state_dict(own, strict=False)
+    assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
+    tower = clip_mod.CLIPVisionTower.__new__(clip_mod.CLIPVisionTower)      # its __init__ fetches a config from the hub
+    torch.nn.Module.__init__(tower)
+    tower.is_loaded, tower.vision_tower_name = True, "tiny-clip (seeded filler)"
+    tower.select_layer, tower.select_feature, tower.vision_tower = c.select_layer, "patch", vm
+
+    class Inner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed_tokens = torch.nn.Embedding(l.vocab, l.hidden)
+            self.mm_projector = torch.nn.Linear(c.hidden, l.hidden)
+            self.embed_tokens.weight.data.copy_(sd["model.embed_tokens.weight"])
+            self.mm_projector.weight.data.copy_(sd["model.mm_projector.weight"])
+            self.mm_projector.bias.data.copy_(sd["model.mm_projector.bias"])
+            self.vision_tower = tower
+
+        def get_vision_tower(self):
+            return self.vision_tower
+
+    class Host(torch.nn.Module, arch.LlavaMetaForCausalLM):     # the reference's mixin; none of its methods is overridden
+        def __init__(self):
+            super().__init__()
+            self.inner = Inner()
+            self.config = types.SimpleNamespace(mm_use_im_start_end=True, tune_mm_mlp_adapter=False)
+
+        def get_model(self):
+            return self.inner
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    host = Host().eval()
+    rng = np.random.default_rng(seed + 5000)
+    B, Ltxt = 3, 9
+    images = torch.from_numpy(rng.standard_normal((B, 3, c.image, c.image), dtype=np.float32))
+    head = [cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]
+    ids = torch.tensor([head + rng.integers(3, min(l.vocab, cfg.seg_token_idx) - 1, size=Ltxt).tolist() for _ in range(B)])
+    ids[1, -3] = cfg.seg_token_idx
+    with torch.no_grad():
+        feats = host.encode_images(images)                        # clip_encoder.forward -> feature_select -> mm_projector
+        # inference shape: HF generate hands an all-ones mask, no labels
+        am = torch.ones_like(ids, dtype=torch.bool)
+        _, am_out, _, emb, lab_none = host.prepare_inputs_labels_for_multimodal(ids, am, None, None, images)
+        assert lab_none is None
+        # training shape: labels with the instruction masked, right padding on two rows (collate_fn, utils/dataset.py:90-150)
+        ids_t = ids.clone()
+        labels = ids.clone()
+        labels[:, :6] = -100
+        am_t = torch.ones_like(ids, dtype=torch.bool)
+        for b, n_pad in ((0, 2), (2, 4)):
+            ids_t[b, -n_pad:] = cfg.pad_token_id
+            labels[b, -n_pad:] = -100
+            am_t[b, -n_pad:] = False
+        _, am_t_out, _, emb_t, lab_t = host.prepare_inputs_labels_for_multimodal(ids_t, am_t, None, labels, images)
+    # (the images are not stored: numpy's PCG64 stream of `seed + 5000` reproduces them, the first draw of that generator)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, images_checksum=float(images.double().sum()), input_ids=ids.numpy(),
+                        image_features=feats.numpy(), attention_mask_out=am_out.numpy(), inputs_embeds=emb.numpy(),
+                        input_ids_train=ids_t.numpy(), labels_train=labels.numpy(), attention_mask_train=am_t.numpy(),
+                        attention_mask_train_out=am_t_out.numpy(), inputs_embeds_train=emb_t.numpy(), labels_train_out=lab_t.numpy())
+    print(name, "features", tuple(feats.shape), "embeds", tuple(emb.shape), "labels", tuple(lab_t.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -264,6 +365,7 @@ def main():
     llama_golden("llama_tiny", hcfg.tiny(), seed=13)
     clip_golden("clip_tiny", hcfg.tiny(), seed=14)
     host_goldens()
+    llava_glue_golden("llava_glue_tiny", hcfg.tiny(), seed=16)
 
 
 if __name__ == "__main__":

@@ -421,6 +421,43 @@ def test_multiple_and_missing_seg_tokens(dev):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_clip_projector_splice_match_the_reference_own_glue(dev, mode):
+    """Rows a4-a6 of the HIP path against what the REFERENCE'S OWN code returned (tests/golden/llava_glue_tiny.npz, written by
+    oracle/make_golden.py::llava_glue_golden from clip_encoder.py:31-60 and llava_arch.py:93-347): CLIP tower + feature select +
+    projector (LisaMI355.encode_images) and the embedding splice (haff_embed_splice) — fp32 mode within 1e-4, bf16 within the
+    bf16 band; the rows that are pure gathers of the embedding table are exact in fp32."""
+    import haff  # noqa: F401
+    from haff import config as hcfg, ops, weights as hw
+    from haff.lisa import LisaMI355
+    cfg = hcfg.tiny()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llava_glue_tiny.npz"))
+    seed = int(g["seed"])
+    sub = {**hw.clip_shapes(cfg.clip), **{k: v for k, v in hw.llm_shapes(cfg).items()
+                                          if k.startswith("model.mm_projector") or k == "model.embed_tokens.weight"}}
+    sd = hw.make_state_dict(cfg, 3)
+    sd.update(hw.make_state_dict(cfg, seed, sub))          # the generator's CLIP / projector / embedding weights
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)
+    images = torch.from_numpy(np.random.default_rng(seed + 5000).standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
+    ref_f, ref_e = torch.from_numpy(g["image_features"]), torch.from_numpy(g["inputs_embeds"])
+    with torch.no_grad():
+        feats = model.encode_images(images.to(dev, dtype))
+        ids = torch.from_numpy(g["input_ids"]).to(dev)
+        img_pos = (ids == -200).int().argmax(1).to(torch.int32)
+        emb = ops.embed_splice(ids.clamp_min(-200).contiguous(), img_pos, model.llm.embed, feats.contiguous())
+    tol = 1e-4 if mode == "f32" else 2e-2
+    assert feats.shape == ref_f.shape and (feats.float().cpu() - ref_f).abs().max().item() <= tol * ref_f.abs().max().item()
+    assert emb.shape == ref_e.shape and (emb.float().cpu() - ref_e).abs().max().item() <= tol * ref_e.abs().max().item()
+    if mode == "f32":
+        txt = torch.ones(ref_e.shape[1], dtype=torch.bool)
+        txt[2:2 + 256] = False                       # rows 2 .. 257 are the image features, the others gathers of the table
+        assert torch.equal(emb.cpu()[:, txt], ref_e[:, txt])
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_last_layer_pruning_keeps_every_row_that_is_read(dev, mode):
     """Round 6: in evaluate() the last Llama layer of the prefill runs o_proj / MLP / final norm only on the rows that are read —
     each row's last real position (first-token logits) and the state in front of a [SEG] that is part of the PROMPT (LISA.py:457-465

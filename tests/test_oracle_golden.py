@@ -119,6 +119,43 @@ def test_clip_against_transformers():
     assert _maxerr(f, g["features"]) < 1e-4
 
 
+def _glue_case():
+    cfg = hcfg.tiny()
+    g = _load("llava_glue_tiny")
+    seed = int(g["seed"])
+    shapes = {**hw.clip_shapes(cfg.clip), **{k: v for k, v in hw.llm_shapes(cfg).items()
+                                             if k.startswith("model.mm_projector") or k == "model.embed_tokens.weight"}}
+    sd = hw.make_state_dict(cfg, seed, shapes)
+    images = torch.from_numpy(np.random.default_rng(seed + 5000).standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6     # the generator's images, reproduced
+    return cfg, g, sd, images
+
+
+def test_llava_glue_against_the_reference_own_methods():
+    """Rows a4-a6 (round 6): the oracle's encode_images / splice_embeddings / splice_labels / splice_attention_mask against what the
+    REFERENCE'S OWN code returned for the same weights and inputs — CLIPVisionTower.forward + feature_select (clip_encoder.py:31-60),
+    LlavaMetaForCausalLM.encode_images and prepare_inputs_labels_for_multimodal (llava_arch.py:93-347), run by
+    oracle/make_golden.py::llava_glue_golden. Until round 6 this glue was pinned by restatement only."""
+    cfg, g, sd, images = _glue_case()
+    with torch.no_grad():
+        feats = O.encode_images(sd, cfg, images)
+    assert feats.shape == (3, 256, cfg.llm.hidden) and _maxerr(feats, g["image_features"]) < 1e-4
+    ids = torch.from_numpy(g["input_ids"])
+    emb = O.splice_embeddings(sd, ids, torch.from_numpy(g["image_features"]))
+    assert emb.shape == g["inputs_embeds"].shape and torch.equal(emb, torch.from_numpy(g["inputs_embeds"]))     # a gather + concat: exact
+    am = O.splice_attention_mask(torch.ones_like(ids, dtype=torch.bool))
+    assert torch.equal(am, torch.from_numpy(g["attention_mask_out"]))
+    # training-shaped rows: right padding + labels
+    ids_t, lab = torch.from_numpy(g["input_ids_train"]), torch.from_numpy(g["labels_train"])
+    emb_t = O.splice_embeddings(sd, ids_t, torch.from_numpy(g["image_features"]))
+    assert torch.equal(emb_t, torch.from_numpy(g["inputs_embeds_train"]))
+    assert torch.equal(O.splice_labels(ids_t, lab), torch.from_numpy(g["labels_train_out"]))
+    assert torch.equal(O.splice_attention_mask(torch.from_numpy(g["attention_mask_train"])), torch.from_numpy(g["attention_mask_train_out"]))
+    # the [SEG] row rule on these ids (LISA.py:457-465): the state in front of the token, shifted by the 255 image rows
+    m = O.seg_token_mask(ids, cfg.seg_token_idx)
+    assert m.shape == (3, emb.shape[1] - 1) and m[1].nonzero().flatten().tolist() == [255 + ids.shape[1] - 4] and not m[0].any()
+
+
 def test_seg_token_rule_and_losses_closed_form():
     """LISA.py:457-465 — position 255+j is selected iff token j+1 is [SEG]."""
     ids = torch.tensor([[1, 321, -200, 322, 7, 8, 320, 9, 2], [1, 321, -200, 322, 320, 5, 6, 320, 2]])
