@@ -355,6 +355,77 @@ def llava_glue_golden(name, cfg, seed):
     print(name, "features", tuple(feats.shape), "embeds", tuple(emb.shape), "labels", tuple(lab_t.shape))
 
 
+def lisa_evaluate_golden(ref, name, cfg, seed):
+    """`LISAForCausalLM.evaluate` and `get_visual_embs` THEMSELVES (model/LISA.py:432-534, :157-168) — the [SEG] row rule with its
+    255-row shift, text_hidden_fcs, the cumsum split of the prompt embeddings over the samples, the per-sample prompt encoder / two
+    mask decoders / postprocess loop and the `[:, 0]` slicing. LISA.py cannot be imported here (its first import, llava_llama.py,
+    fails in AutoConfig.register under transformers 5.15: an ordinary error), so the two method definitions are taken out of its
+    syntax tree UNCHANGED, compiled under LISA.py's own file name and bound to a host object whose collaborators are: the
+    reference's Sam built from its own classes with the filler's weights (`model.visual_model`), `model.text_hidden_fcs` constructed
+    as LISA.py:93-101 does, `seg_token_idx`, and a `generate()` that returns the output ids and last-step hidden states the CPU
+    oracle produced for the same inputs (HF generate is third-party; Llama / CLIP are pinned against transformers separately).
+    `Tensor.cuda()` is the identity for the duration of the call: the method moves two helper tensors to a GPU this container does
+    not have. What is stored: the inputs evaluate() saw (ids, hidden states, frames by seed, sizes) and everything it returned."""
+    import ast
+    import types
+    from oracle import lisa_oracle as O
+    path = "/root/reference/2Haff/model/LISA.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LISAForCausalLM")
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("get_visual_embs", "evaluate")]
+    assert [f.name for f in fns] == ["get_visual_embs", "evaluate"]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+
+    s, l = cfg.sam, cfg.llm
+    sd = hw.make_state_dict(cfg, seed)
+    sam = build_ref_sam(ref, s)
+    missing, unexpected = sam.load_state_dict({k[len("model.visual_model."):]: v for k, v in sd.items()
+                                               if k.startswith("model.visual_model.")}, strict=False)
+    assert not unexpected and all(("point_embeddings" in m or "not_a_point" in m or "mask_downscaling" in m) for m in missing)
+    fcs = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(l.hidden, l.hidden), torch.nn.ReLU(inplace=True),
+                                                   torch.nn.Linear(l.hidden, cfg.out_dim), torch.nn.Dropout(0.0))]).eval()
+    fcs[0][0].load_state_dict({"weight": sd["model.text_hidden_fcs.0.0.weight"], "bias": sd["model.text_hidden_fcs.0.0.bias"]})
+    fcs[0][2].load_state_dict({"weight": sd["model.text_hidden_fcs.0.2.weight"], "bias": sd["model.text_hidden_fcs.0.2.bias"]})
+
+    rng = np.random.default_rng(seed + 6000)
+    B, S = 3, s.img_size
+    images = torch.from_numpy(rng.standard_normal((B, 3, S, S), dtype=np.float32))
+    images_clip = torch.from_numpy(rng.standard_normal((B, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    head = [cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]
+    ids = torch.tensor([head + rng.integers(3, 300, size=8).tolist() for _ in range(B)])
+    forced = torch.tensor([[7, cfg.seg_token_idx, 9, cfg.seg_token_idx, cfg.eos_token_id],     # two [SEG]
+                           [5, 6, 7, 8, cfg.eos_token_id],                                     # none -> empty masks
+                           [cfg.seg_token_idx, 8, 9, 11, cfg.eos_token_id]])                   # the first generated token
+    resize_list = [(S, S), (S, S - 32), (S - 64, S)]
+    original_size_list = [(S, S), (S // 2 + 3, S // 2 - 10), (150, 200)]
+    with torch.no_grad():
+        out_ids, hidden = O.lisa_generate(sd, cfg, images_clip, ids, 5, forced_answer=forced, use_cache=True)
+
+    class Host:
+        pass
+    host = Host()
+    host.seg_token_idx = cfg.seg_token_idx
+    host.model = types.SimpleNamespace(visual_model=sam, text_hidden_fcs=fcs)
+    host.get_visual_embs = types.MethodType(ns["get_visual_embs"], host)
+    host.generate = lambda **kw: types.SimpleNamespace(sequences=out_ids, hidden_states=[hidden])
+    cuda_was = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        r_ids, r_left, r_right, r_tax = ns["evaluate"](host, images_clip, images, ids, resize_list, original_size_list,
+                                                       max_new_tokens=5, tokenizer=None)
+    finally:
+        torch.Tensor.cuda = cuda_was
+    assert torch.equal(r_ids, out_ids) and [m.shape[0] for m in r_left] == [2, 0, 1]
+    arrays = {"seed": seed, "input_ids": ids.numpy(), "forced": forced.numpy(), "output_ids": out_ids.numpy(), "hidden": hidden.numpy(),
+              "resize_list": np.array(resize_list), "original_size_list": np.array(original_size_list),
+              "images_checksum": float(images.double().sum())}
+    for i in range(B):
+        arrays[f"left{i}"], arrays[f"right{i}"], arrays[f"tax{i}"] = r_left[i].numpy(), r_right[i].numpy(), r_tax[i].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print(name, "masks per sample", [tuple(m.shape) for m in r_left], "taxonomy", [tuple(t.shape) for t in r_tax])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -366,6 +437,7 @@ def main():
     clip_golden("clip_tiny", hcfg.tiny(), seed=14)
     host_goldens()
     llava_glue_golden("llava_glue_tiny", hcfg.tiny(), seed=16)
+    lisa_evaluate_golden(ref, "lisa_evaluate_tiny", hcfg.tiny(), seed=17)
 
 
 if __name__ == "__main__":

@@ -421,6 +421,54 @@ def test_multiple_and_missing_seg_tokens(dev):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_evaluate_matches_the_reference_own_evaluate(dev, mode):
+    """LisaMI355.evaluate END TO END against what the reference's OWN `LISAForCausalLM.evaluate` source returned
+    (tests/golden/lisa_evaluate_tiny.npz: LISA.py:432-534 run unchanged on the reference's Sam classes by
+    oracle/make_golden.py::lisa_evaluate_golden, its generate() fed by the CPU oracle): three frames, two [SEG] / none / one,
+    three different (resize, original) size pairs. fp32 mode: ids equal, masks within 1e-3 (north_star's tolerance), taxonomy
+    within 1e-5; bf16: inside the bf16 band."""
+    import haff  # noqa: F401
+    from haff import config as hcfg, weights as hw
+    from haff.lisa import LisaMI355
+    cfg = hcfg.tiny()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lisa_evaluate_tiny.npz"))
+    seed = int(g["seed"])
+    sd = hw.make_state_dict(cfg, seed)
+    S = cfg.sam.img_size
+    rng = np.random.default_rng(seed + 6000)
+    images = torch.from_numpy(rng.standard_normal((3, 3, S, S), dtype=np.float32))
+    images_clip = torch.from_numpy(rng.standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)      # (the golden is the exact forward of the unrounded weights: the band below covers the weights' rounding too)
+    resize = [tuple(int(v) for v in r) for r in g["resize_list"]]
+    orig = [tuple(int(v) for v in r) for r in g["original_size_list"]]
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
+    ids, forced = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["forced"])
+    with torch.no_grad():
+        out_ids, left, right, tax = model.evaluate(images_clip.to(dev), images.to(dev), ids.to(dev), resize, orig,
+                                                   max_new_tokens=5, forced_answer=forced)
+    assert torch.equal(out_ids.cpu(), torch.from_numpy(g["output_ids"]))
+    assert [m.shape[0] for m in left] == [2, 0, 1] and [m.shape[0] for m in right] == [2, 0, 1]
+    for i in range(3):
+        for got, key in ((left[i], f"left{i}"), (right[i], f"right{i}"), (tax[i], f"tax{i}")):
+            ref = torch.from_numpy(g[key])
+            assert tuple(got.shape) == tuple(ref.shape), (key, got.shape, ref.shape)
+            if ref.numel() == 0:
+                continue
+            err = (got.float().cpu() - ref).abs().max().item()
+            if key.startswith("tax"):
+                assert err <= (1e-5 if mode == "f32" else 3e-3), (key, err)
+            elif mode == "f32":
+                assert err <= 1e-3, (key, err)
+                safe = ref.abs() > 1e-3
+                assert torch.equal((got.cpu() > 0)[safe], (ref > 0)[safe])
+            else:
+                assert err <= 3e-2 * ref.abs().max().item(), (key, err / ref.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_clip_projector_splice_match_the_reference_own_glue(dev, mode):
     """Rows a4-a6 of the HIP path against what the REFERENCE'S OWN code returned (tests/golden/llava_glue_tiny.npz, written by
     oracle/make_golden.py::llava_glue_golden from clip_encoder.py:31-60 and llava_arch.py:93-347): CLIP tower + feature select +

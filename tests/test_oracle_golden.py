@@ -156,6 +156,42 @@ def test_llava_glue_against_the_reference_own_methods():
     assert m.shape == (3, emb.shape[1] - 1) and m[1].nonzero().flatten().tolist() == [255 + ids.shape[1] - 4] and not m[0].any()
 
 
+def test_lisa_evaluate_against_the_reference_own_method():
+    """LISAForCausalLM.evaluate ITSELF (LISA.py:432-534 + get_visual_embs :157-168; its source run unchanged by
+    oracle/make_golden.py::lisa_evaluate_golden on the reference's Sam classes, fed the ids / hidden states below) against the oracle's
+    lisa_evaluate on the same ids / hidden states (injected through `memo`): the [SEG] row rule, text_hidden_fcs, the cumsum split,
+    the per-sample decoders, postprocess to three different (resize, original) size pairs, empty masks for a sample without [SEG].
+    Until round 6 this part of the oracle was pinned by restatement only."""
+    cfg = hcfg.tiny()
+    g = _load("lisa_evaluate_tiny")
+    seed = int(g["seed"])
+    sd = hw.make_state_dict(cfg, seed)
+    S = cfg.sam.img_size
+    rng = np.random.default_rng(seed + 6000)
+    images = torch.from_numpy(rng.standard_normal((3, 3, S, S), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6
+    resize = [tuple(int(v) for v in r) for r in g["resize_list"]]
+    orig = [tuple(int(v) for v in r) for r in g["original_size_list"]]
+    out_ids, hidden = torch.from_numpy(g["output_ids"]), torch.from_numpy(g["hidden"])
+    memo = {("gen", False, False): (out_ids, hidden)}
+    with torch.no_grad():
+        ids, left, right, tax = O.lisa_evaluate(sd, cfg, None, images, torch.from_numpy(g["input_ids"]), resize, orig,
+                                                max_new_tokens=5, forced_answer=torch.from_numpy(g["forced"]), memo=memo)
+    assert torch.equal(ids, out_ids)
+    for i in range(3):
+        for got, key in ((left[i], f"left{i}"), (right[i], f"right{i}"), (tax[i], f"tax{i}")):
+            assert tuple(got.shape) == g[key].shape, (key, got.shape, g[key].shape)
+            if got.numel():
+                assert _maxerr(got, g[key]) < 2e-4, (key, _maxerr(got, g[key]))
+    assert [m.shape[0] for m in left] == [2, 0, 1]
+    # ... and the oracle's OWN generate reproduces the ids / hidden states the fixture was generated from (Llama / CLIP are pinned
+    # against transformers in the tests above)
+    images_clip = torch.from_numpy(rng.standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    with torch.no_grad():
+        o2, h2 = O.lisa_generate(sd, cfg, images_clip, torch.from_numpy(g["input_ids"]), 5, forced_answer=torch.from_numpy(g["forced"]), use_cache=True)
+    assert torch.equal(o2, out_ids) and _maxerr(h2, g["hidden"]) < 1e-5
+
+
 def test_seg_token_rule_and_losses_closed_form():
     """LISA.py:457-465 — position 255+j is selected iff token j+1 is [SEG]."""
     ids = torch.tensor([[1, 321, -200, 322, 7, 8, 320, 9, 2], [1, 321, -200, 322, 320, 5, 6, 320, 2]])
