@@ -426,6 +426,114 @@ def lisa_evaluate_golden(ref, name, cfg, seed):
     print(name, "masks per sample", [tuple(m.shape) for m in r_left], "taxonomy", [tuple(t.shape) for t in r_tax])
 
 
+def lisa_model_forward_golden(ref, name, cfg, seed):
+    """`LISAForCausalLM.model_forward` ITSELF (model/LISA.py:175-430) with the module's own `dice_loss` / `sigmoid_ce_loss` (:16-59):
+    the training-time [SEG] row rule, the `offset` regrouping of the prompt embeddings, the per-sample decoders postprocessed to the
+    LABEL shape, the taxonomy-weighted logits, the six losses and their normalisations — and the `inference=True` return. Same
+    technique as lisa_evaluate_golden: the definitions are taken out of LISA.py's syntax tree unchanged and compiled under its file
+    name; `super().forward(...)` (LlavaLlamaForCausalLM.forward -> HF Llama: third party, pinned against transformers separately)
+    resolves to a base class whose forward returns the hidden states / logits / CE loss the CPU oracle computes for the same batch
+    (encode_images -> splice -> llama_forward -> lm_head -> shift-by-one CE, llava_llama.py:93-118). `Tensor.cuda()` is the identity and
+    stdout is swallowed for the call (the method prints "Training")."""
+    import ast
+    import contextlib
+    import io
+    import types
+    from typing import List
+    from oracle import lisa_oracle as O
+    path = "/root/reference/2Haff/model/LISA.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    losses = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("dice_loss", "sigmoid_ce_loss")]
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LISAForCausalLM")
+    meths = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("get_visual_embs", "model_forward")]
+    assert len(losses) == 2 and [m.name for m in meths] == ["get_visual_embs", "model_forward"]
+    base_src = ast.parse("class _LlmBase:\n    def forward(self, **kw):\n        return self._llm(**kw)\n").body[0]
+    host_cls = ast.ClassDef(name="LISAForCausalLM", bases=[ast.Name(id="_LlmBase", ctx=ast.Load())], keywords=[], body=meths,
+                            decorator_list=[])
+    mod = ast.fix_missing_locations(ast.Module(body=losses + [base_src, host_cls], type_ignores=[]))
+    ns = {"torch": torch, "F": torch.nn.functional, "nn": torch.nn, "List": List}
+    exec(compile(mod, path, "exec"), ns)
+
+    s, l = cfg.sam, cfg.llm
+    sd = hw.make_state_dict(cfg, seed)
+    sam = build_ref_sam(ref, s)
+    missing, unexpected = sam.load_state_dict({k[len("model.visual_model."):]: v for k, v in sd.items()
+                                               if k.startswith("model.visual_model.")}, strict=False)
+    assert not unexpected and all(("point_embeddings" in m or "not_a_point" in m or "mask_downscaling" in m) for m in missing)
+    fcs = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(l.hidden, l.hidden), torch.nn.ReLU(inplace=True),
+                                                   torch.nn.Linear(l.hidden, cfg.out_dim), torch.nn.Dropout(0.0))]).eval()
+    fcs[0][0].load_state_dict({"weight": sd["model.text_hidden_fcs.0.0.weight"], "bias": sd["model.text_hidden_fcs.0.0.bias"]})
+    fcs[0][2].load_state_dict({"weight": sd["model.text_hidden_fcs.0.2.weight"], "bias": sd["model.text_hidden_fcs.0.2.bias"]})
+
+    rng = np.random.default_rng(seed + 7000)
+    b, S, H0, W0 = 3, s.img_size, 120, 90
+    images = torch.from_numpy(rng.standard_normal((b, 3, S, S), dtype=np.float32))
+    images_clip = torch.from_numpy(rng.standard_normal((b, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    head = [cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]
+    # image 0 carries TWO conversations (offset 0, 2, 3, 4): the regrouping by `offset` is exercised
+    ids = torch.tensor([head + rng.integers(3, 300, size=10).tolist() for _ in range(4)])
+    ids[:, -3], ids[:, -1] = cfg.seg_token_idx, cfg.eos_token_id
+    labels = ids.clone()
+    labels[:, :9] = -100
+    offset = torch.tensor([0, 2, 3, 4])
+    n_masks = [2, 1, 1]
+    masks_l = [(torch.from_numpy(rng.random((n, H0, W0))) > 0.5).float() for n in n_masks]
+    masks_r = [(torch.from_numpy(rng.random((n, H0, W0))) > 0.6).float() for n in n_masks]
+    tax = torch.tensor([[0.0, 0.0, 1.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]])
+    batch = dict(images=images, images_clip=images_clip, input_ids=ids, labels=labels, attention_masks=torch.ones_like(ids, dtype=torch.bool),
+                 offset=offset, masks_list_left=masks_l, masks_list_right=masks_r, taxonomies_list=tax,
+                 label_list=[{"left": torch.zeros(H0, W0), "right": torch.zeros(H0, W0)} for _ in range(b)],
+                 resize_list=[(S, S - 32), (S, S), (S - 64, S)], inference=False)
+
+    def llm(images=None, attention_mask=None, input_ids=None, labels=None, output_hidden_states=True):
+        img = O.encode_images(sd, cfg, images)
+        hidden = O.llama_forward(sd, O.splice_embeddings(sd, input_ids, img), cfg.llm)
+        logits = torch.nn.functional.linear(hidden, sd["lm_head.weight"])
+        loss = None
+        if labels is not None:
+            lab = O.splice_labels(input_ids, labels)
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), lab[:, 1:].reshape(-1), ignore_index=-100)
+        # llava_llama.py:124-135: every layer's states (a tuple, the last one post-norm) in training mode, the post-norm tensor in eval
+        return types.SimpleNamespace(hidden_states=(hidden,) if host.training else hidden, logits=logits, loss=loss)
+
+    host = ns["LISAForCausalLM"]()
+    host._llm = llm
+    host.seg_token_idx = cfg.seg_token_idx
+    host.model = types.SimpleNamespace(visual_model=sam, text_hidden_fcs=fcs)
+    host.ce_loss = torch.nn.CrossEntropyLoss(reduction="mean")                # LISA.py:151
+    host.ce_loss_weight, host.bce_loss_weight, host.dice_loss_weight = 1.0, 2.0, 0.5   # train_ds.py:92-94
+    # every sample of this batch has ONE mask per decoder call except sample 0 (two conversations -> two [SEG] -> two masks): the
+    # reference stacks the per-sample predictions, so the mask counts must agree; samples 1, 2 get their single mask repeated
+    cuda_was = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    try:
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            # (a) equal mask counts: the three samples with one conversation each
+            one = dict(batch, input_ids=ids[1:], labels=labels[1:], attention_masks=batch["attention_masks"][1:], offset=torch.tensor([0, 1, 2, 3]),
+                       masks_list_left=[m[:1] for m in masks_l], masks_list_right=[m[:1] for m in masks_r])
+            host.training = True
+            out["train"] = host.model_forward(**one)
+            # (b) inference=True on ONE image with two conversations (LISA.py:210-232 asserts a single CLIP image)
+            inf = dict(batch, images=images[:1], images_clip=images_clip[:1], input_ids=ids[:2], labels=labels[:2],
+                       attention_masks=batch["attention_masks"][:2], offset=torch.tensor([0, 2]), masks_list_left=masks_l[:1],
+                       masks_list_right=masks_r[:1], taxonomies_list=tax[:1], label_list=batch["label_list"][:1],
+                       resize_list=batch["resize_list"][:1], inference=True)
+            host.training = False
+            out["inference"] = host.model_forward(**inf)
+    finally:
+        torch.Tensor.cuda = cuda_was
+    arrays = {"seed": seed, "input_ids": ids.numpy(), "labels": labels.numpy(), "taxonomies": tax.numpy(),
+              "resize_list": np.array(batch["resize_list"]), "label_hw": np.array([H0, W0]),
+              "images_checksum": float(images.double().sum())}
+    for k, v in out["train"].items():
+        arrays["train_" + k] = np.float64(v.item())
+    for k in ("pred_masks_left", "pred_masks_right", "pred_taxonomies"):
+        arrays["inference_" + k] = out["inference"][k].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print(name, {k: round(float(v), 6) for k, v in out["train"].items()}, "inference masks", tuple(out["inference"]["pred_masks_left"].shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -438,6 +546,7 @@ def main():
     host_goldens()
     llava_glue_golden("llava_glue_tiny", hcfg.tiny(), seed=16)
     lisa_evaluate_golden(ref, "lisa_evaluate_tiny", hcfg.tiny(), seed=17)
+    lisa_model_forward_golden(ref, "lisa_model_forward_tiny", hcfg.tiny(), seed=18)
 
 
 if __name__ == "__main__":

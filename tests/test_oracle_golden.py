@@ -9,6 +9,8 @@ import pytest
 import torch
 
 import haff  # noqa: F401
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # tests/golden_cases.py
 from haff import config as hcfg
 from haff import weights as hw
 from oracle import lisa_oracle as O
@@ -190,6 +192,26 @@ def test_lisa_evaluate_against_the_reference_own_method():
     with torch.no_grad():
         o2, h2 = O.lisa_generate(sd, cfg, images_clip, torch.from_numpy(g["input_ids"]), 5, forced_answer=torch.from_numpy(g["forced"]), use_cache=True)
     assert torch.equal(o2, out_ids) and _maxerr(h2, g["hidden"]) < 1e-5
+
+
+def test_lisa_model_forward_against_the_reference_own_method():
+    """LISAForCausalLM.model_forward ITSELF (LISA.py:175-430, with the module's own dice_loss / sigmoid_ce_loss; run unchanged by
+    oracle/make_golden.py::lisa_model_forward_golden on the reference's Sam classes, its `super().forward` served by the oracle's
+    language-model functions) against the oracle's lisa_model_forward on the same batch: the six losses of a three-sample training
+    batch to 1e-5, and the `inference=True` return (one image, two conversations: the `offset` regrouping) to 2e-4."""
+    from golden_cases import model_forward_case
+    cfg = hcfg.tiny()
+    sd, train, infer, g = model_forward_case(cfg)
+    with torch.no_grad():
+        out = O.lisa_model_forward(sd, cfg, train)
+        inf = O.lisa_model_forward(sd, cfg, infer)
+    for k in ("loss", "ce_loss", "taxonomy_ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss"):
+        want = float(g["train_" + k])
+        assert abs(float(out[k]) - want) <= 1e-5 * max(1.0, abs(want)), (k, float(out[k]), want)
+    for k in ("pred_masks_left", "pred_masks_right", "pred_taxonomies"):
+        assert tuple(inf[k].shape) == g["inference_" + k].shape
+        assert _maxerr(inf[k], g["inference_" + k]) < 2e-4, k
+    assert inf["pred_masks_left"].shape[:2] == (1, 2)       # one image, the two [SEG] of its two conversations
 
 
 def test_seg_token_rule_and_losses_closed_form():

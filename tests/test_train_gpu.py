@@ -34,6 +34,45 @@ def test_model_forward_loss_and_grads_match_oracle(dev, mode):
     check_forward_backward(dev, cfg, mode, make_batch(cfg), min_tensors=150)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_losses_match_the_reference_own_model_forward(dev, mode):
+    """LisaTrainable.forward (HIP) against what the reference's OWN `LISAForCausalLM.model_forward` source returned
+    (tests/golden/lisa_model_forward_tiny.npz: LISA.py:175-430 + its dice_loss / sigmoid_ce_loss, run unchanged by
+    oracle/make_golden.py::lisa_model_forward_golden): the six losses of a three-sample batch (fp32 mode 1e-4, bf16 3e-2) and the
+    `inference=True` masks / taxonomy of one image with two conversations. LoRA B starts at zero, so the adapted model IS the base."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import haff  # noqa: F401
+    from golden_cases import model_forward_case
+    from haff import config as hcfg, weights as hw
+    from haff.train_model import LisaTrainable
+    cfg = hcfg.tiny()
+    sd, train, infer, g = model_forward_case(cfg)
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)
+    model = LisaTrainable(cfg, sd, dtype=dtype, device=dev, lora_dropout=0.0, seed=3)
+    to_dev = lambda b: {k: (v.to(dev) if torch.is_tensor(v) else ([m.to(dev) for m in v] if k.startswith("masks_list") else v)) for k, v in b.items()}  # noqa: E731
+    out = model(**to_dev(train))
+    ltol = 1e-4 if mode == "f32" else 3e-2
+    for k in ("loss", "ce_loss", "taxonomy_ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss"):
+        want = float(g["train_" + k])
+        print(f"{mode} {k}: hip {float(out[k].detach()):.6f} reference {want:.6f}")
+        assert abs(float(out[k].detach()) - want) <= ltol * max(1.0, abs(want)), k
+    with torch.no_grad():
+        inf = model(**to_dev(infer))
+    for k in ("pred_masks_left", "pred_masks_right", "pred_taxonomies"):
+        ref = torch.from_numpy(g["inference_" + k])
+        got = inf[k].float().cpu()
+        assert tuple(got.shape) == tuple(ref.shape), (k, got.shape, ref.shape)
+        err = (got - ref).abs().max().item()
+        if k == "pred_taxonomies":
+            assert err <= (1e-5 if mode == "f32" else 3e-3), (k, err)
+        else:
+            assert err <= (1e-3 if mode == "f32" else 3e-2 * ref.abs().max().item()), (k, err)
+
+
 def grad_class(key):
     """Tensor class of a trainable parameter (the reference's trainable set: train_ds.py:192-244)."""
     if "lora_A" in key:
