@@ -10,9 +10,13 @@ Pinning (see oracle/make_golden.py and tests/test_oracle_golden.py):
   * Llama / CLIP arithmetic lives in third-party `transformers` (pinned ==4.31.0 by 2Haff/requirements.txt:20,
     absent from /root/reference); it is checked against the container's transformers 5.x LlamaModel /
     CLIPVisionModel, which implement the same published math;
-  * the LISA glue (LISA.py, llava_arch.py, llava_llama.py) cannot be imported here (needs transformers 4.31 and
-    hard-codes .cuda()); it is restated from the source text and pinned by construction tests — that part of
-    the parity is "pinned by restatement only".
+  * the LISA / LLaVA glue: `import model.LISA` fails here (transformers 4.31 internals, .cuda() calls), but since round 6 the
+    reference's OWN definitions are what the fixtures come from — clip_encoder.py / llava_arch.py imported by file path
+    (encode_images, prepare_inputs_labels_for_multimodal), LISAForCausalLM.evaluate / get_visual_embs / model_forward and
+    dice_loss / sigmoid_ce_loss taken out of LISA.py's syntax tree unchanged and run on the reference's Sam classes with the
+    third-party language-model calls served by this file's Llama / CLIP functions (oracle/make_golden.py: llava_glue_golden,
+    lisa_evaluate_golden, lisa_model_forward_golden). Restated-only now: the lines of llava_llama.py:93-135 around the third-party
+    calls (lm_head, shift-by-one CE) and HF generate's greedy loop.
 
 Every function cites the reference lines it follows (paths relative to /root/reference/2Haff/).
 """
