@@ -355,6 +355,134 @@ def llava_glue_golden(name, cfg, seed):
     print(name, "features", tuple(feats.shape), "embeds", tuple(emb.shape), "labels", tuple(lab_t.shape))
 
 
+def _load_ref_llava_arch():
+    """llava_arch.py + multimodal_encoder/clip_encoder.py of the reference, by file path (the package __init__ is NOT executed: it pulls
+    llava_llama.py, whose AutoConfig.register fails under transformers 5.15). -> (llava_arch module, clip_encoder module)."""
+    import types
+    base = "/root/reference/2Haff/model/llava/model"
+    if "ref_llava_model.llava_arch" in sys.modules:
+        return sys.modules["ref_llava_model.llava_arch"], sys.modules["ref_llava_model.multimodal_encoder.clip_encoder"]
+    if "/root/reference/2Haff" not in sys.path:
+        sys.path.insert(0, "/root/reference/2Haff")      # llava_arch.py: `from utils.utils import ...`
+    pkg = importlib.util.module_from_spec(importlib.util.spec_from_file_location(
+        "ref_llava_model", os.path.join(base, "__init__.py"), submodule_search_locations=[base]))
+    sys.modules["ref_llava_model"] = pkg
+    sub = types.ModuleType("ref_llava_model.multimodal_encoder")
+    sub.__path__ = [os.path.join(base, "multimodal_encoder")]
+    sys.modules["ref_llava_model.multimodal_encoder"] = sub
+    spec = importlib.util.spec_from_file_location("ref_llava_model.llava_arch", os.path.join(base, "llava_arch.py"))
+    arch = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = arch
+    spec.loader.exec_module(arch)
+    return arch, sys.modules["ref_llava_model.multimodal_encoder.clip_encoder"]
+
+
+def _ref_clip_tower(clip_mod, cfg, sd):
+    """The reference's CLIPVisionTower around a transformers CLIPVisionModel of the tiny geometry with the filler's weights (its
+    __init__, which fetches a config from the hub, is bypassed)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    c = cfg.clip
+    hc = CLIPVisionConfig(hidden_size=c.hidden, intermediate_size=c.mlp, num_hidden_layers=c.layers, num_attention_heads=c.heads,
+                          image_size=c.image, patch_size=c.patch, hidden_act="quick_gelu", layer_norm_eps=c.eps,
+                          attn_implementation="eager")
+    vm = CLIPVisionModel(hc).eval()
+    pre = "model.vision_tower.vision_tower."
+    own = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    if not any(k.startswith("vision_model.") for k in vm.state_dict()):
+        own = {k[len("vision_model."):]: v for k, v in own.items()}
+    missing, unexpected = vm.load_state_dict(own, strict=False)
+    assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
+    tower = clip_mod.CLIPVisionTower.__new__(clip_mod.CLIPVisionTower)
+    torch.nn.Module.__init__(tower)
+    tower.is_loaded, tower.vision_tower_name = True, "tiny-clip (seeded filler)"
+    tower.select_layer, tower.select_feature, tower.vision_tower = c.select_layer, "patch", vm
+    return tower
+
+
+def llava_llama_forward_golden(name, cfg, seed):
+    """`LlavaLlamaForCausalLM.forward` ITSELF (llava/model/language_model/llava_llama.py:55-135: multimodal splice -> LlamaModel ->
+    lm_head -> shift-by-one CE; which hidden states it returns in training / eval mode) — its definition taken out of the file's
+    syntax tree unchanged (the module cannot be imported: AutoConfig.register fails) and bound to a host that also carries the
+    reference's LlavaMetaForCausalLM mixin (imported by path: the REAL encode_images / prepare_inputs_labels_for_multimodal) and whose
+    `model` is transformers' LlamaModel of the tiny geometry with the filler's weights + the projector + the reference's
+    CLIPVisionTower. Nothing of this repo's oracle runs inside the call: the whole language half of a training step and of an
+    evaluation forward — reference glue around third-party models — is what the fixture holds."""
+    import ast
+    import types
+    from typing import List, Optional, Tuple, Union
+    from torch.nn import CrossEntropyLoss
+    from transformers import LlamaConfig, LlamaModel
+    from transformers.modeling_outputs import CausalLMOutputWithPast
+    arch, clip_mod = _load_ref_llava_arch()
+    path = "/root/reference/2Haff/model/llava/model/language_model/llava_llama.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LlavaLlamaForCausalLM")
+    fwd = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward"]
+    ns = {"torch": torch, "Optional": Optional, "List": List, "Union": Union, "Tuple": Tuple,
+          "CausalLMOutputWithPast": CausalLMOutputWithPast, "CrossEntropyLoss": CrossEntropyLoss}
+    exec(compile(ast.Module(body=fwd, type_ignores=[]), path, "exec"), ns)
+
+    c, l = cfg.clip, cfg.llm
+    sd = hw.make_state_dict(cfg, seed, {**hw.clip_shapes(c), **hw.llm_shapes(cfg)})
+    hc = LlamaConfig(vocab_size=l.vocab, hidden_size=l.hidden, intermediate_size=l.ffn, num_hidden_layers=l.layers,
+                     num_attention_heads=l.heads, num_key_value_heads=l.heads, rms_norm_eps=l.rms_eps, rope_theta=l.rope_theta,
+                     max_position_embeddings=2048, attention_bias=False, mlp_bias=False, tie_word_embeddings=False,
+                     attn_implementation="eager")
+    lm = LlamaModel(hc)
+    own = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.layers.") or k in ("model.embed_tokens.weight", "model.norm.weight")}
+    missing, unexpected = lm.load_state_dict(own, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    lm.mm_projector = torch.nn.Linear(c.hidden, l.hidden)
+    lm.mm_projector.load_state_dict({"weight": sd["model.mm_projector.weight"], "bias": sd["model.mm_projector.bias"]})
+    # (the tower is deliberately NOT registered as a child module of `lm`: transformers 5.x collects `output_hidden_states` through
+    # forward hooks it installs on every submodule of the model being called — a CLIP model hanging under LlamaModel gets its layer
+    # outputs re-recorded by the Llama call and returns a hidden_states tuple of another length the next time, so hidden_states[-2]
+    # is another layer. Under the reference's transformers 4.31 the tuple is built by a plain loop and no such coupling exists.)
+    tower = _ref_clip_tower(clip_mod, cfg, sd)
+    lm.get_vision_tower = lambda: tower
+
+    class Host(torch.nn.Module, arch.LlavaMetaForCausalLM):
+        forward = ns["forward"]
+
+        def __init__(self):
+            super().__init__()
+            self.model = lm
+            self.lm_head = torch.nn.Linear(l.hidden, l.vocab, bias=False)
+            self.lm_head.weight.data.copy_(sd["lm_head.weight"])
+            self.config = types.SimpleNamespace(output_attentions=False, output_hidden_states=False, use_return_dict=True,
+                                                vocab_size=l.vocab, mm_use_im_start_end=True, tune_mm_mlp_adapter=False)
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    host = Host()
+    rng = np.random.default_rng(seed + 8000)
+    n, Ltxt = 3, 10
+    images = torch.from_numpy(rng.standard_normal((n, 3, c.image, c.image), dtype=np.float32))
+    head = [cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]
+    ids = torch.tensor([head + rng.integers(3, 300, size=Ltxt).tolist() for _ in range(n)])
+    ids[:, -3], ids[:, -1] = cfg.seg_token_idx, cfg.eos_token_id
+    labels = ids.clone()
+    labels[:, :9] = -100
+    am = torch.ones_like(ids, dtype=torch.bool)
+    with torch.no_grad():
+        host.train()
+        tr = host(images=images, attention_mask=am, input_ids=ids, labels=labels, output_hidden_states=True)
+        host.eval()
+        ev = host(images=images, attention_mask=am, input_ids=ids, output_hidden_states=True)
+    assert isinstance(tr.hidden_states, tuple) and torch.is_tensor(ev.hidden_states) and ev.loss is None
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, input_ids=ids.numpy(), labels=labels.numpy(),
+                        images_checksum=float(images.double().sum()), train_loss=np.float64(tr.loss.item()),
+                        train_hidden_last=tr.hidden_states[-1].numpy(), train_logits_tail=tr.logits[:, -8:].numpy(),
+                        train_logits_sum=np.float64(tr.logits.double().sum().item()), train_n_hidden=len(tr.hidden_states),
+                        eval_hidden=ev.hidden_states.numpy(), eval_logits_tail=ev.logits[:, -8:].numpy())
+    print(name, "CE", round(tr.loss.item(), 6), "hidden", tuple(ev.hidden_states.shape), "train hidden states", len(tr.hidden_states))
+
+
 def lisa_evaluate_golden(ref, name, cfg, seed):
     """`LISAForCausalLM.evaluate` and `get_visual_embs` THEMSELVES (model/LISA.py:432-534, :157-168) — the [SEG] row rule with its
     255-row shift, text_hidden_fcs, the cumsum split of the prompt embeddings over the samples, the per-sample prompt encoder / two
@@ -547,6 +675,7 @@ def main():
     llava_glue_golden("llava_glue_tiny", hcfg.tiny(), seed=16)
     lisa_evaluate_golden(ref, "lisa_evaluate_tiny", hcfg.tiny(), seed=17)
     lisa_model_forward_golden(ref, "lisa_model_forward_tiny", hcfg.tiny(), seed=18)
+    llava_llama_forward_golden("llava_llama_forward_tiny", hcfg.tiny(), seed=19)
 
 
 if __name__ == "__main__":

@@ -469,6 +469,42 @@ def test_evaluate_matches_the_reference_own_evaluate(dev, mode):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_language_half_matches_the_reference_own_forward(dev, mode):
+    """The HIP path's CLIP tower -> projector -> splice -> Llama prefill -> lm_head against what the reference's OWN
+    `LlavaLlamaForCausalLM.forward` returned over its own llava_arch / clip_encoder code and transformers' models
+    (tests/golden/llava_llama_forward_tiny.npz, oracle/make_golden.py::llava_llama_forward_golden): post-norm hidden states of every
+    position and the logits of the last 8 — fp32 mode within 2e-4, bf16 inside the bf16 band."""
+    import haff  # noqa: F401
+    from haff import config as hcfg, ops, weights as hw
+    from haff.lisa import LisaMI355
+    cfg = hcfg.tiny()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llava_llama_forward_tiny.npz"))
+    seed = int(g["seed"])
+    sd = hw.make_state_dict(cfg, 3)
+    sd.update(hw.make_state_dict(cfg, seed, {**hw.clip_shapes(cfg.clip), **hw.llm_shapes(cfg)}))   # the generator's CLIP / Llama weights
+    if mode == "bf16":
+        hw.round_to_bf16_(sd)
+    images = torch.from_numpy(np.random.default_rng(seed + 8000).standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    model = LisaMI355(cfg, sd, dtype=dtype, device=dev)
+    ids = torch.from_numpy(g["input_ids"]).to(dev)
+    with torch.no_grad():
+        feats = model.encode_images(images.to(dev, dtype))
+        img_pos = (ids == -200).int().argmax(1).to(torch.int32)
+        x = ops.embed_splice(ids.clamp_min(-200).contiguous(), img_pos, model.llm.embed, feats.contiguous())
+        cache = model.llm.new_cache(3, x.shape[1] + 1)
+        hidden = model.llm.forward(x, cache)
+        logits = model.llm.next_token_logits(hidden[:, -8:].reshape(-1, hidden.shape[-1]).contiguous()).view(3, 8, -1)
+    ref_h, ref_l = torch.from_numpy(g["eval_hidden"]), torch.from_numpy(g["eval_logits_tail"])
+    tol = 2e-4 if mode == "f32" else 3e-2
+    eh = (hidden.float().cpu() - ref_h).abs().max().item() / ref_h.abs().max().item()
+    el = (logits.float().cpu() - ref_l).abs().max().item() / ref_l.abs().max().item()
+    print(f"{mode}: hidden rel {eh:.3e}, logits rel {el:.3e}")
+    assert eh <= tol and el <= tol
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_clip_projector_splice_match_the_reference_own_glue(dev, mode):
     """Rows a4-a6 of the HIP path against what the REFERENCE'S OWN code returned (tests/golden/llava_glue_tiny.npz, written by
     oracle/make_golden.py::llava_glue_golden from clip_encoder.py:31-60 and llava_arch.py:93-347): CLIP tower + feature select +

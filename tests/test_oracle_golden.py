@@ -214,6 +214,30 @@ def test_lisa_model_forward_against_the_reference_own_method():
     assert inf["pred_masks_left"].shape[:2] == (1, 2)       # one image, the two [SEG] of its two conversations
 
 
+def test_language_half_against_the_reference_own_forward():
+    """LlavaLlamaForCausalLM.forward ITSELF (llava_llama.py:55-135, run unchanged by oracle/make_golden.py::llava_llama_forward_golden
+    over the reference's own llava_arch / clip_encoder code and transformers' LlamaModel / CLIPVisionModel; nothing of this oracle ran
+    inside it) against the oracle's chain encode_images -> splice_embeddings -> llama_forward -> lm_head -> shift-by-one CE: hidden states
+    (training mode returns every layer's, the last one post-norm; eval mode the post-norm tensor), logits and the loss."""
+    cfg = hcfg.tiny()
+    g = _load("llava_llama_forward_tiny")
+    seed = int(g["seed"])
+    sd = hw.make_state_dict(cfg, seed, {**hw.clip_shapes(cfg.clip), **hw.llm_shapes(cfg)})
+    images = torch.from_numpy(np.random.default_rng(seed + 8000).standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6
+    ids, labels = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["labels"])
+    with torch.no_grad():
+        hidden = O.llama_forward(sd, O.splice_embeddings(sd, ids, O.encode_images(sd, cfg, images)), cfg.llm)
+        logits = torch.nn.functional.linear(hidden, sd["lm_head.weight"])
+        lab = O.splice_labels(ids, labels)
+        ce = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), lab[:, 1:].reshape(-1), ignore_index=-100)
+    assert int(g["train_n_hidden"]) == cfg.llm.layers + 1
+    assert _maxerr(hidden, g["train_hidden_last"]) < 1e-4 and _maxerr(hidden, g["eval_hidden"]) < 1e-4
+    assert _maxerr(logits[:, -8:], g["train_logits_tail"]) < 1e-4 and _maxerr(logits[:, -8:], g["eval_logits_tail"]) < 1e-4
+    assert abs(float(logits.double().sum()) - float(g["train_logits_sum"])) <= 1e-5 * logits.numel() ** 0.5 * float(logits.std()) + 1e-2
+    assert abs(float(ce) - float(g["train_loss"])) <= 1e-5
+
+
 def test_seg_token_rule_and_losses_closed_form():
     """LISA.py:457-465 — position 255+j is selected iff token j+1 is [SEG]."""
     ids = torch.tensor([[1, 321, -200, 322, 7, 8, 320, 9, 2], [1, 321, -200, 322, 320, 5, 6, 320, 2]])
