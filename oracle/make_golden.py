@@ -247,10 +247,31 @@ def host_goldens():
             shapes[tag] = {"messages": [list(m) for m in msgs], "prompt": t.get_prompt()}
         t = conv.conv_templates[name]
         by_type[name] = {"roles": list(t.roles), "sep": t.sep, "sep2": t.sep2, "system": t.system, "shapes": shapes}
+    # round 6: the two pure host helpers of row a1 — `preprocess` of inference.py:90-105 and ResizeLongestSide.get_preprocess_shape of
+    # segment_anything/utils/transforms.py:102-113 — taken out of their files' syntax trees unchanged (inference.py is a script that
+    # imports cv2 at the top, transforms.py imports torchvision: neither is installed) and evaluated on a grid of sizes / a small frame
+    import ast
+    from typing import Tuple
+    ns = {"torch": torch, "F": torch.nn.functional, "Tuple": Tuple}
+    p_inf = "/root/reference/2Haff/inference.py"
+    fn = [n for n in ast.parse(open(p_inf).read(), filename=p_inf).body if isinstance(n, ast.FunctionDef) and n.name == "preprocess"]
+    exec(compile(ast.Module(body=fn, type_ignores=[]), p_inf, "exec"), ns)
+    p_tr = "/root/reference/2Haff/model/segment_anything/utils/transforms.py"
+    rls = next(n for n in ast.parse(open(p_tr).read(), filename=p_tr).body if isinstance(n, ast.ClassDef) and n.name == "ResizeLongestSide")
+    gps = [n for n in rls.body if isinstance(n, ast.FunctionDef) and n.name == "get_preprocess_shape"]
+    gps[0].decorator_list = []          # (a @staticmethod: evaluated as a plain function)
+    exec(compile(ast.Module(body=gps, type_ignores=[]), p_tr, "exec"), ns)
+    sizes = [(1024, 1024), (480, 640), (640, 480), (1080, 1920), (333, 500), (1, 7), (2047, 2049), (1023, 1025), (225, 1000), (768, 1024)]
+    shapes = [list(ns["get_preprocess_shape"](h, w, L)) for (h, w) in sizes for L in (1024, 224)]
+    rng = np.random.default_rng(77)
+    small = rng.integers(0, 256, size=(13, 20, 3), dtype=np.uint8)
+    pre = ns["preprocess"](torch.from_numpy(small).permute(2, 0, 1).contiguous(), img_size=32)    # the call of inference.py:244-250
     import json
     with open(os.path.join(OUT, "host_helpers.json"), "w") as f:
         json.dump({"prompts": prompts, "ids": ids, "conv_llava_v1_prompt": c.get_prompt(),
-                   "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2, "conv_templates": by_type}, f, indent=1)
+                   "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2, "conv_templates": by_type,
+                   "preprocess_shape_sizes": [list(t) for t in sizes], "preprocess_shapes_1024_224": shapes,
+                   "preprocess_small_frame": small.tolist(), "preprocess_small_out": pre.numpy().tolist()}, f, indent=1)
     print("host helpers ok:", c.get_prompt()[:80].replace("\n", "\\n"))
 
 

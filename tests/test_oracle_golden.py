@@ -315,6 +315,22 @@ def test_host_helpers_match_reference():
         P.get_conv("mpt")
 
 
+def test_sam_host_preprocess_against_the_reference_own_functions():
+    """Row a1's host helpers against the reference's OWN definitions (`preprocess`, inference.py:90-105; `ResizeLongestSide.
+    get_preprocess_shape`, transforms.py:102-113; taken out of their files unchanged by oracle/make_golden.py::host_goldens): the
+    resize shape for ten frame sizes at both target lengths — exact — and normalise + pad of a small uint8 frame — exact in fp32 —
+    for the product's helpers (haff.preprocess) and the oracle's."""
+    from haff import preprocess as PP
+    with open(os.path.join(GOLD, "host_helpers.json")) as f:
+        g = json.load(f)
+    got = [list(PP.get_preprocess_shape(h, w, L)) for (h, w) in g["preprocess_shape_sizes"] for L in (1024, 224)]
+    assert got == g["preprocess_shapes_1024_224"]
+    frame = np.array(g["preprocess_small_frame"], dtype=np.uint8)
+    want = torch.tensor(g["preprocess_small_out"], dtype=torch.float32)
+    assert want.shape == (3, 32, 32)
+    assert torch.equal(PP.sam_preprocess(frame, 32), want) and torch.equal(O.sam_preprocess(frame, 32), want)
+
+
 def test_collate_label_mask_follows_conv_type():
     """utils/dataset.py:95-128 under both --conv_type values: BOS and every round's instruction span (up to and including the
     separator: " ASSISTANT: " for llava_v1, "[/INST] " for llava_llama_2, with the reference's -2 correction) are -100, the answer
