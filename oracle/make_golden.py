@@ -266,12 +266,31 @@ def host_goldens():
     rng = np.random.default_rng(77)
     small = rng.integers(0, 256, size=(13, 20, 3), dtype=np.uint8)
     pre = ns["preprocess"](torch.from_numpy(small).permute(2, 0, 1).contiguous(), img_size=32)    # the call of inference.py:244-250
+    # ... and the metric's own definition: calculate_iou / calculate_iocm of train_ds.py:761-800 (the script imports
+    # deepspeed / cv2 at the top: the two definitions are taken out of its syntax tree), AverageMeter of utils/utils.py (importable)
+    p_td = "/root/reference/2Haff/train_ds.py"
+    fns = [n for n in ast.parse(open(p_td).read(), filename=p_td).body if isinstance(n, ast.FunctionDef) and n.name in ("calculate_iou", "calculate_iocm")]
+    ns2 = {"np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), p_td, "exec"), ns2)
+    mrng = np.random.default_rng(78)
+    iou_cases = []
+    for k, (pa, pb) in enumerate([(0.5, 0.5), (0.1, 0.9), (0.0, 0.3), (0.3, 0.0), (0.0, 0.0), (1.0, 1.0), (0.02, 0.02)]):
+        a, b = mrng.random((24, 31)) < pa, mrng.random((24, 31)) < pb
+        iou_cases.append({"seed_index": k, "p": [pa, pb], "iou": float(ns2["calculate_iou"](a, b)), "iocm": float(ns2["calculate_iocm"](a, b))})
+    if "/root/reference/2Haff" not in sys.path:
+        sys.path.insert(0, "/root/reference/2Haff")
+    from utils.utils import AverageMeter as RefMeter
+    m = RefMeter("MaskLoss", ":.4f")
+    for v, n_ in ((0.5, 1), (0.25, 3), (1.0 / 3.0, 2)):
+        m.update(v, n_)
+    meter = {"str": str(m), "avg": m.avg, "sum": m.sum, "count": m.count}
     import json
     with open(os.path.join(OUT, "host_helpers.json"), "w") as f:
         json.dump({"prompts": prompts, "ids": ids, "conv_llava_v1_prompt": c.get_prompt(),
                    "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2, "conv_templates": by_type,
                    "preprocess_shape_sizes": [list(t) for t in sizes], "preprocess_shapes_1024_224": shapes,
-                   "preprocess_small_frame": small.tolist(), "preprocess_small_out": pre.numpy().tolist()}, f, indent=1)
+                   "preprocess_small_frame": small.tolist(), "preprocess_small_out": pre.numpy().tolist(),
+                   "iou_cases": iou_cases, "average_meter": meter}, f, indent=1)
     print("host helpers ok:", c.get_prompt()[:80].replace("\n", "\\n"))
 
 

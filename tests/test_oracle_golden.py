@@ -331,6 +331,28 @@ def test_sam_host_preprocess_against_the_reference_own_functions():
     assert torch.equal(PP.sam_preprocess(frame, 32), want) and torch.equal(O.sam_preprocess(frame, 32), want)
 
 
+def test_metric_definitions_against_the_reference_own_functions():
+    """The metric's IoU (|A and B| / |A or B|, 0 for an empty union) and IoCM as the reference's OWN calculate_iou /
+    calculate_iocm compute them (train_ds.py:761-800, evaluated by oracle/make_golden.py::host_goldens on seven mask pairs incl.
+    empty ones) against the product's (train_ds.py validation, evaluation.py scorer), and AverageMeter's arithmetic / log format
+    against utils/utils.py's class."""
+    from haff import evaluation as EV, train_ds as TD
+    with open(os.path.join(GOLD, "host_helpers.json")) as f:
+        g = json.load(f)
+    rng = np.random.default_rng(78)
+    for case in g["iou_cases"]:
+        pa, pb = case["p"]
+        a, b = rng.random((24, 31)) < pa, rng.random((24, 31)) < pb
+        for mod in (TD, EV):
+            assert mod.calculate_iou(a, b) == pytest.approx(case["iou"], abs=1e-12), (mod.__name__, case)
+            assert mod.calculate_iocm(a, b) == pytest.approx(case["iocm"], abs=1e-12), (mod.__name__, case)
+    m = TD.AverageMeter("MaskLoss", ":.4f")
+    for v, n_ in ((0.5, 1), (0.25, 3), (1.0 / 3.0, 2)):
+        m.update(v, n_)
+    ref = g["average_meter"]
+    assert str(m) == ref["str"] and m.avg == pytest.approx(ref["avg"], abs=1e-15) and m.count == ref["count"]
+
+
 def test_collate_label_mask_follows_conv_type():
     """utils/dataset.py:95-128 under both --conv_type values: BOS and every round's instruction span (up to and including the
     separator: " ASSISTANT: " for llava_v1, "[/INST] " for llava_llama_2, with the reference's -2 correction) are -100, the answer
