@@ -284,13 +284,21 @@ def host_goldens():
     for v, n_ in ((0.5, 1), (0.25, 3), (1.0 / 3.0, 2)):
         m.update(v, n_)
     meter = {"str": str(m), "avg": m.avg, "sum": m.sum, "count": m.count}
+    # ... and the 2HANDS question / answer templates (utils/aff_dataset.py:27-46; the module imports cv2 / h5py / pycocotools at the
+    # top: its three constant assignments are evaluated out of the syntax tree)
+    p_ad = "/root/reference/2Haff/utils/aff_dataset.py"
+    assigns = [n for n in ast.parse(open(p_ad).read(), filename=p_ad).body if isinstance(n, ast.Assign)
+               and getattr(n.targets[0], "id", "") in ("DEFAULT_IMAGE_TOKEN", "SHORT_QUESTION_LIST", "ANSWER_LIST")]
+    ns3 = {}
+    exec(compile(ast.Module(body=assigns, type_ignores=[]), p_ad, "exec"), ns3)
+    templates = {"short_question_list": ns3["SHORT_QUESTION_LIST"], "answer_list": ns3["ANSWER_LIST"]}
     import json
     with open(os.path.join(OUT, "host_helpers.json"), "w") as f:
         json.dump({"prompts": prompts, "ids": ids, "conv_llava_v1_prompt": c.get_prompt(),
                    "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2, "conv_templates": by_type,
                    "preprocess_shape_sizes": [list(t) for t in sizes], "preprocess_shapes_1024_224": shapes,
                    "preprocess_small_frame": small.tolist(), "preprocess_small_out": pre.numpy().tolist(),
-                   "iou_cases": iou_cases, "average_meter": meter}, f, indent=1)
+                   "iou_cases": iou_cases, "average_meter": meter, "aff_templates": templates}, f, indent=1)
     print("host helpers ok:", c.get_prompt()[:80].replace("\n", "\\n"))
 
 

@@ -351,6 +351,10 @@ def test_metric_definitions_against_the_reference_own_functions():
         m.update(v, n_)
     ref = g["average_meter"]
     assert str(m) == ref["str"] and m.avg == pytest.approx(ref["avg"], abs=1e-15) and m.count == ref["count"]
+    # the 2HANDS question / answer templates (utils/aff_dataset.py:27-46)
+    from haff import aff_dataset as AD
+    assert list(AD.SHORT_QUESTION_LIST) == g["aff_templates"]["short_question_list"]
+    assert list(AD.ANSWER_LIST) == g["aff_templates"]["answer_list"]
 
 
 def test_collate_label_mask_follows_conv_type():
