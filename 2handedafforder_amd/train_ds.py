@@ -175,7 +175,11 @@ def collate_fn(batch, tokenizer, model_max_length=575, use_mm_start_end=True, co
     """utils/dataset.py:30-169: pad with pad_token, mask the instruction spans with -100; conv_type picks the template whose sep2
     splits the rounds and the separator that ends a round's instruction (:97-101: " ASSISTANT: " or "[/INST] ")."""
     images, clips, convs, ml, mr, labels_l, resizes, tax, offs = [], [], [], [], [], [], [], [], [0]
-    for (_, image, image_clip, conversations, m_left, m_right, taxonomy, label, resize, _q, _c, inference) in batch:
+    paths, questions, classes = [], [], []
+    for (path, image, image_clip, conversations, m_left, m_right, taxonomy, label, resize, _q, _c, inference) in batch:
+        paths.append(path)
+        questions.append(_q)
+        classes.append(_c)
         images.append(image)
         clips.append(image_clip)
         convs.extend(conversations)
@@ -213,7 +217,8 @@ def collate_fn(batch, tokenizer, model_max_length=575, use_mm_start_end=True, co
     return {"images": torch.stack(images, 0), "images_clip": torch.stack(clips, 0), "input_ids": input_ids,
             "labels": targets, "attention_masks": attention_masks, "masks_list_left": ml, "masks_list_right": mr,
             "label_list": labels_l, "resize_list": resizes, "offset": torch.LongTensor(offs),
-            "inference": batch[0][-1], "conversation_list": convs, "taxonomies_list": torch.stack(tax, 0)}
+            "inference": batch[0][-1], "conversation_list": convs, "taxonomies_list": torch.stack(tax, 0),
+            "image_paths": paths, "questions_list": questions, "sampled_classes_list": classes}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

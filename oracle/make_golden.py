@@ -292,13 +292,37 @@ def host_goldens():
     ns3 = {}
     exec(compile(ast.Module(body=assigns, type_ignores=[]), p_ad, "exec"), ns3)
     templates = {"short_question_list": ns3["SHORT_QUESTION_LIST"], "answer_list": ns3["ANSWER_LIST"]}
+    # ... and collate_fn ITSELF (utils/dataset.py:30-169: <image> -> <im_start><image><im_end>, padding, the label mask of every
+    # round's instruction span under BOTH --conv_type values, truncation, the batch dict) — the module imports cv2 / pycocotools at the
+    # top, its one function definition is taken out of the syntax tree and evaluated with the reference's own conversation_lib /
+    # tokenizer_image_token / constants in scope, on the samples and the stand-in tokenizer of tests/golden_cases.py
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_cases as GC
+    p_ds = "/root/reference/2Haff/utils/dataset.py"
+    cf = [n for n in ast.parse(open(p_ds).read(), filename=p_ds).body if isinstance(n, ast.FunctionDef) and n.name == "collate_fn"]
+    sys.path.insert(0, "/root/reference/2Haff")
+    import utils.utils as ref_uu
+    ns4 = {"torch": torch, "conversation_lib": conv, "tokenizer_image_token": mm.tokenizer_image_token,
+           "DEFAULT_IMAGE_TOKEN": cm.DEFAULT_IMAGE_TOKEN, "IGNORE_INDEX": cm.IGNORE_INDEX, "IMAGE_TOKEN_INDEX": cm.IMAGE_TOKEN_INDEX,
+           "DEFAULT_IM_START_TOKEN": ref_uu.DEFAULT_IM_START_TOKEN, "DEFAULT_IM_END_TOKEN": ref_uu.DEFAULT_IM_END_TOKEN}
+    exec(compile(ast.Module(body=cf, type_ignores=[]), p_ds, "exec"), ns4)
+    collate = {}
+    for name in ("llava_v1", "llava_llama_2"):
+        conv.default_conversation = conv.conv_templates[name]          # train_ds.py:188-190
+        batch = GC.collate_samples(lambda: conv.conv_templates[name].copy())
+        out = ns4["collate_fn"](batch, tokenizer=GC.StubSpTokenizer(), conv_type=name, use_mm_start_end=True, local_rank=-1)
+        collate[name] = {"input_ids": out["input_ids"].tolist(), "labels": out["labels"].tolist(),
+                         "attention_masks": out["attention_masks"].int().tolist(), "offset": out["offset"].tolist(),
+                         "conversation_list": out["conversation_list"], "inference": bool(out["inference"]),
+                         "taxonomies_list": out["taxonomies_list"].tolist(), "resize_list": [list(r) for r in out["resize_list"]],
+                         "images_sum": float(out["images"].double().sum()), "keys": sorted(out.keys())}
     import json
     with open(os.path.join(OUT, "host_helpers.json"), "w") as f:
         json.dump({"prompts": prompts, "ids": ids, "conv_llava_v1_prompt": c.get_prompt(),
                    "roles": list(c.roles), "sep": c.sep, "sep2": c.sep2, "conv_templates": by_type,
                    "preprocess_shape_sizes": [list(t) for t in sizes], "preprocess_shapes_1024_224": shapes,
                    "preprocess_small_frame": small.tolist(), "preprocess_small_out": pre.numpy().tolist(),
-                   "iou_cases": iou_cases, "average_meter": meter, "aff_templates": templates}, f, indent=1)
+                   "iou_cases": iou_cases, "average_meter": meter, "aff_templates": templates, "collate_fn": collate}, f, indent=1)
     print("host helpers ok:", c.get_prompt()[:80].replace("\n", "\\n"))
 
 

@@ -37,3 +37,42 @@ def model_forward_case(cfg):
                  offset=torch.tensor([0, 2]), masks_list_left=masks_l[:1], masks_list_right=masks_r[:1], taxonomies_list=tax[:1],
                  label_list=label_list[:1], resize_list=resize[:1], inference=True)
     return sd, train, infer, g
+
+
+class StubSpTokenizer:
+    """A deterministic stand-in with the PROPERTIES of the sentencepiece Llama tokenizer that the reference's collate_fn arithmetic
+    relies on (utils/dataset.py:95-140): every call prepends BOS, "</s>" is ONE token, every other character is one token; pad = 0.
+    Used identically by oracle/make_golden.py::collate_goldens (the reference's collate_fn) and by the tests (the product's)."""
+    bos_token_id, eos_token_id, pad_token_id, unk_token_id = 1, 2, 0, 0
+    model_max_length = 2048
+
+    def __call__(self, text):
+        ids = [self.bos_token_id]
+        parts = text.split("</s>")
+        for i, part in enumerate(parts):
+            ids.extend(3 + (ord(ch) % 500) for ch in part)
+            if i + 1 < len(parts):
+                ids.append(self.eos_token_id)
+        return type("Enc", (), {"input_ids": ids})()
+
+
+def collate_samples(conv_factory):
+    """Two 12-tuples in the layout the datasets emit (utils/aff_dataset.py:267-280): sample 0 with two conversations, sample 1 with one;
+    conv_factory() -> a fresh conversation object of the template under test (the reference's or the product's)."""
+    cases = [([("open the drawer", "It is [SEG]."), ("cut the bread with the knife", "Sure, [SEG].")], (8, 10)),
+             ([("pour water", "[SEG].")], (6, 8))]
+    out = []
+    for n, (qa, (h, w)) in enumerate(cases):
+        convs = []
+        for q, a in qa:
+            c = conv_factory()
+            c.messages = []
+            c.append_message(c.roles[0], "<image>\n" + "How can I perform the action '%s' in this image? Please output segmentation mask." % q)
+            c.append_message(c.roles[1], a)
+            convs.append(c.get_prompt())
+        g = torch.Generator().manual_seed(100 + n)
+        out.append(("path/%d.jpg" % n, torch.randn((3, 16, 16), generator=g), torch.randn((3, 8, 8), generator=g), convs,
+                    (torch.rand((len(convs), h, w), generator=g) > 0.5), (torch.rand((len(convs), h, w), generator=g) > 0.5),
+                    [0.0, 0.0, 1.0, 0.0] if n == 0 else [1.0, 0.0, 0.0, 0.0], {"left": torch.zeros(h, w), "right": torch.zeros(h, w)},
+                    (16, 12), [q for q, _ in qa], [q for q, _ in qa], False))
+    return out

@@ -357,6 +357,27 @@ def test_metric_definitions_against_the_reference_own_functions():
     assert list(AD.ANSWER_LIST) == g["aff_templates"]["answer_list"]
 
 
+@pytest.mark.parametrize("conv_type", ["llava_v1", "llava_llama_2"])
+def test_collate_fn_against_the_reference_own_function(conv_type):
+    """train_ds.collate_fn against the reference's OWN collate_fn (utils/dataset.py:30-169, evaluated by oracle/make_golden.py::
+    host_goldens with its own conversation_lib / tokenizer_image_token in scope) on the same samples and the same stand-in tokenizer,
+    under both --conv_type values: the <im_start><image><im_end> replacement, padded ids, the label mask of every round's instruction
+    span, attention masks, offsets, the conversation strings and the dict's key set — all exact."""
+    from golden_cases import StubSpTokenizer, collate_samples
+    from haff import prompt as P, train_ds as TD
+    with open(os.path.join(GOLD, "host_helpers.json")) as f:
+        g = json.load(f)["collate_fn"][conv_type]
+    batch = collate_samples(lambda: P.get_conv(conv_type))
+    out = TD.collate_fn(batch, StubSpTokenizer(), model_max_length=StubSpTokenizer.model_max_length, use_mm_start_end=True, conv_type=conv_type)
+    assert out["conversation_list"] == g["conversation_list"]
+    assert out["input_ids"].tolist() == g["input_ids"] and out["labels"].tolist() == g["labels"]
+    assert out["attention_masks"].int().tolist() == g["attention_masks"] and out["offset"].tolist() == g["offset"]
+    assert out["taxonomies_list"].tolist() == g["taxonomies_list"] and [list(r) for r in out["resize_list"]] == g["resize_list"]
+    assert bool(out["inference"]) == g["inference"] and sorted(out.keys()) == g["keys"]
+    assert float(out["images"].double().sum()) == pytest.approx(g["images_sum"], abs=1e-9)
+    assert any(v != -100 for v in g["labels"][0]) and g["labels"][0][0] == -100          # answers are labelled, BOS is not
+
+
 def test_collate_label_mask_follows_conv_type():
     """utils/dataset.py:95-128 under both --conv_type values: BOS and every round's instruction span (up to and including the
     separator: " ASSISTANT: " for llava_v1, "[/INST] " for llava_llama_2, with the reference's -2 correction) are -100, the answer
