@@ -16,8 +16,8 @@ Pinning (see oracle/make_golden.py and tests/test_oracle_golden.py):
     dice_loss / sigmoid_ce_loss taken out of LISA.py's syntax tree unchanged and run on the reference's Sam classes with the
     third-party language-model calls served by this file's Llama / CLIP functions (oracle/make_golden.py: llava_glue_golden,
     lisa_evaluate_golden, lisa_model_forward_golden), and LlavaLlamaForCausalLM.forward (llava_llama.py:55-135) the same way over
-    transformers' LlamaModel with no function of this file inside the call (llava_llama_forward_golden). Restated-only now: HF
-    generate's greedy loop and prepare_inputs_for_generation (llava_llama.py:137-163).
+    transformers' LlamaModel with no function of this file inside the call (llava_llama_forward_golden); the greedy loop against
+    transformers' own generate (greedy_generate_golden). Restated-only now: prepare_inputs_for_generation (llava_llama.py:137-163).
 
 Every function cites the reference lines it follows (paths relative to /root/reference/2Haff/).
 """

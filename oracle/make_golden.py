@@ -555,6 +555,45 @@ def llava_llama_forward_golden(name, cfg, seed):
     print(name, "CE", round(tr.loss.item(), 6), "hidden", tuple(ev.hidden_states.shape), "train hidden states", len(tr.hidden_states))
 
 
+def greedy_generate_golden(name, cfg, seed):
+    """The greedy loop the reference delegates to transformers (`self.generate(..., num_beams=1)`, LISA.py:443-450): argmax, append,
+    a row that emitted EOS is padded from then on, the loop ends when every row has finished or at max_new_tokens. Third-party code,
+    so the pin is transformers' own `generate` on a tiny LlamaForCausalLM carrying the filler's weights, fed the spliced embeddings
+    (clip -> projector -> splice: pinned against the reference's glue by llava_glue_golden). Random weights never emit the real EOS:
+    the EOS id of this case is the token row 0 produces at its third step (read from a first unconstrained run), so the rows stop
+    at different steps."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from oracle import lisa_oracle as O
+    l = cfg.llm
+    sd = hw.make_state_dict(cfg, seed, {**hw.clip_shapes(cfg.clip), **hw.llm_shapes(cfg)})
+    hc = LlamaConfig(vocab_size=l.vocab, hidden_size=l.hidden, intermediate_size=l.ffn, num_hidden_layers=l.layers,
+                     num_attention_heads=l.heads, num_key_value_heads=l.heads, rms_norm_eps=l.rms_eps, rope_theta=l.rope_theta,
+                     max_position_embeddings=2048, attention_bias=False, mlp_bias=False, tie_word_embeddings=False,
+                     attn_implementation="eager")
+    model = LlamaForCausalLM(hc).eval()
+    own = {k: v for k, v in sd.items() if k.startswith("model.layers.") or k in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")}
+    missing, unexpected = model.load_state_dict(own, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    rng = np.random.default_rng(seed + 9000)
+    B = 3
+    images = torch.from_numpy(rng.standard_normal((B, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    head = [cfg.bos_token_id, cfg.im_start_idx, -200, cfg.im_end_idx]
+    ids = torch.tensor([head + rng.integers(3, 300, size=7).tolist() for _ in range(B)])
+    with torch.no_grad():
+        x = O.splice_embeddings(sd, ids, O.encode_images(sd, cfg, images))
+        kw = dict(inputs_embeds=x, attention_mask=torch.ones(x.shape[:2], dtype=torch.long), do_sample=False, num_beams=1, use_cache=True)
+        free = model.generate(max_new_tokens=8, eos_token_id=None, pad_token_id=cfg.pad_token_id, **kw)
+        eos = int(free[0, 2])
+        seq = model.generate(max_new_tokens=8, eos_token_id=eos, pad_token_id=cfg.pad_token_id, **kw)
+        # row 0 alone: every row has finished after three tokens -> the loop ends early
+        kw1 = dict(kw, inputs_embeds=x[:1], attention_mask=kw["attention_mask"][:1])
+        seq1 = model.generate(max_new_tokens=8, eos_token_id=eos, pad_token_id=cfg.pad_token_id, **kw1)
+    assert seq1.shape[1] == 3
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, input_ids=ids.numpy(), images_checksum=float(images.double().sum()),
+                        free_tokens=free.numpy(), eos_token_id=eos, tokens=seq.numpy(), tokens_row0_alone=seq1.numpy())
+    print(name, "free", free.tolist(), "eos", eos, "with eos", seq.tolist(), "row 0 alone", seq1.tolist())
+
+
 def lisa_evaluate_golden(ref, name, cfg, seed):
     """`LISAForCausalLM.evaluate` and `get_visual_embs` THEMSELVES (model/LISA.py:432-534, :157-168) — the [SEG] row rule with its
     255-row shift, text_hidden_fcs, the cumsum split of the prompt embeddings over the samples, the per-sample prompt encoder / two
@@ -748,6 +787,7 @@ def main():
     lisa_evaluate_golden(ref, "lisa_evaluate_tiny", hcfg.tiny(), seed=17)
     lisa_model_forward_golden(ref, "lisa_model_forward_tiny", hcfg.tiny(), seed=18)
     llava_llama_forward_golden("llava_llama_forward_tiny", hcfg.tiny(), seed=19)
+    greedy_generate_golden("greedy_generate_tiny", hcfg.tiny(), seed=20)
 
 
 if __name__ == "__main__":

@@ -469,6 +469,40 @@ def test_evaluate_matches_the_reference_own_evaluate(dev, mode):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_greedy_decode_matches_transformers_generate(dev, mode):
+    """LisaMI355.generate (KV-cached greedy decode, hipGraph per step) against transformers' own `generate(num_beams=1)` on the same
+    weights (tests/golden/greedy_generate_tiny.npz, oracle/make_golden.py::greedy_generate_golden): the free-running tokens, a row
+    that emits EOS at its third step and is padded from then on, and the early end of the loop when every row has finished."""
+    import copy
+    import haff  # noqa: F401
+    from haff import config as hcfg, weights as hw
+    from haff.lisa import LisaMI355
+    cfg = hcfg.tiny()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "greedy_generate_tiny.npz"))
+    seed = int(g["seed"])
+    sd = hw.make_state_dict(cfg, 3)
+    sd.update(hw.make_state_dict(cfg, seed, {**hw.clip_shapes(cfg.clip), **hw.llm_shapes(cfg)}))
+    images = torch.from_numpy(np.random.default_rng(seed + 9000).standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6
+    dtype = torch.float32 if mode == "f32" else torch.bfloat16
+    ids = torch.from_numpy(g["input_ids"]).to(dev)
+    L = ids.shape[1]
+    cfg_eos = copy.deepcopy(cfg)
+    cfg_eos.eos_token_id = int(g["eos_token_id"])
+    for c, key, n in ((cfg, "free_tokens", 3), (cfg_eos, "tokens", 3), (cfg_eos, "tokens_row0_alone", 1)):
+        model = LisaMI355(c, sd, dtype=dtype, device=dev)
+        with torch.no_grad():
+            out, _ = model.generate(images[:n].to(dev, dtype), ids[:n], 8)
+        got, want = out[:, L:].cpu().tolist(), g[key].tolist()
+        if mode == "f32":
+            assert got == want, (key, got, want)
+        else:   # bf16: an argmax between two near-equal logits may go the other way; every token up to a first such flip must agree
+            agree = sum(int(a == b) for ra, rb in zip(got, want) for a, b in zip(ra, rb))
+            assert agree >= 0.9 * sum(len(r) for r in want), (key, got, want)
+        del model
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_language_half_matches_the_reference_own_forward(dev, mode):
     """The HIP path's CLIP tower -> projector -> splice -> Llama prefill -> lm_head against what the reference's OWN
     `LlavaLlamaForCausalLM.forward` returned over its own llava_arch / clip_encoder code and transformers' models

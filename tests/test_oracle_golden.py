@@ -238,6 +238,38 @@ def test_language_half_against_the_reference_own_forward():
     assert abs(float(ce) - float(g["train_loss"])) <= 1e-5
 
 
+def _greedy_case():
+    import copy
+    cfg = hcfg.tiny()
+    g = _load("greedy_generate_tiny")
+    seed = int(g["seed"])
+    sd = hw.make_state_dict(cfg, seed, {**hw.clip_shapes(cfg.clip), **hw.llm_shapes(cfg)})
+    images = torch.from_numpy(np.random.default_rng(seed + 9000).standard_normal((3, 3, cfg.clip.image, cfg.clip.image), dtype=np.float32))
+    assert abs(float(images.double().sum()) - float(g["images_checksum"])) < 1e-6
+    cfg_eos = copy.deepcopy(cfg)
+    cfg_eos.eos_token_id = int(g["eos_token_id"])
+    return cfg, cfg_eos, g, sd, images
+
+
+def test_greedy_loop_against_transformers_generate():
+    """The greedy loop the reference delegates to transformers' `generate(num_beams=1)` (LISA.py:443-450) — argmax, append, pad a row
+    after its EOS, stop when every row has finished — as transformers' own generate runs it on a tiny LlamaForCausalLM with the
+    filler's weights (oracle/make_golden.py::greedy_generate_golden), against the oracle's lisa_generate in BOTH schedules (full
+    recompute per token as the reference does, and KV-cached): free-running tokens, a row that stops early and is padded, and the
+    early end of the loop when every row has finished."""
+    cfg, cfg_eos, g, sd, images = _greedy_case()
+    ids = torch.from_numpy(g["input_ids"])
+    L = ids.shape[1]
+    with torch.no_grad():
+        for use_cache in (False, True):
+            out, _ = O.lisa_generate(sd, cfg, images, ids, 8, use_cache=use_cache)
+            assert out[:, L:].tolist() == g["free_tokens"].tolist(), use_cache
+            out, _ = O.lisa_generate(sd, cfg_eos, images, ids, 8, use_cache=use_cache)
+            assert out[:, L:].tolist() == g["tokens"].tolist(), use_cache
+            out, _ = O.lisa_generate(sd, cfg_eos, images[:1], ids[:1], 8, use_cache=use_cache)
+            assert out[:, L:].tolist() == g["tokens_row0_alone"].tolist() and out.shape[1] == L + 3
+
+
 def test_seg_token_rule_and_losses_closed_form():
     """LISA.py:457-465 — position 255+j is selected iff token j+1 is [SEG]."""
     ids = torch.tensor([[1, 321, -200, 322, 7, 8, 320, 9, 2], [1, 321, -200, 322, 320, 5, 6, 320, 2]])
