@@ -55,6 +55,10 @@ def test_compact_line_survives_absurdly_long_free_text():
     full["cpu_baseline"]["sample"] = "s" * 5000
     full["roofline"]["kernel"] = "k" * 5000
     assert len(json.dumps(bench.compact_line(full))) <= bench.LINE_BUDGET_BYTES
+    # even a config object stuffed with junk cannot keep the line from being printed within the budget
+    full["config"].update({"junk%d" % i: "x" * 200 for i in range(40)})
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) <= bench.LINE_BUDGET_BYTES and line["value"] == full["value"] and "frac" in line["roofline"]
 
 
 def test_stub_run_prints_exactly_one_line_within_the_budget(tmp_path, monkeypatch):
