@@ -772,7 +772,7 @@ def emit(full):
                 json.dump(full, fh, indent=1)
             dst = os.path.relpath(path, ROOT)
             break
-        except OSError:
+        except (OSError, TypeError, ValueError):      # an unwritable directory or an unserialisable diagnostic must not cost the line
             continue
     full["detail"] = dst
     sys.stderr.flush()
