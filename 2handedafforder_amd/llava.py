@@ -127,6 +127,10 @@ class LlamaHip:
         self.carry_rms = dtype == torch.bfloat16 and self.hd == 128 and l.hidden % 128 == 0 and l.ffn % 128 == 0
         self.carry_rms_max_rows = 8   # the consumer side of haff_gemm_bf16_rms gathers the partials of <= 8 rows
         self._folded = None
+        # Round 6: the whole <= 8-row decode step as ONE launch (ops.decode_chain, csrc/decode_chain.hip): the five stages of every
+        # layer are workgroup ranges chained by arrival counters, weights are requested before a workgroup waits for its inputs.
+        # Same arithmetic as the five-launch layer below (bit-identical at 5..8 rows). False: the five launches per layer.
+        self.decode_chain = True      # "stages": the same kernel as one launch per (layer, stage) (tests, A/B)
         self._cs = None
         # Prefill-sized batches (>= 1024 rows: where the 8-wave tile runs anyway): RoPE and the KV-cache append ride in the q|k|v projection's epilogue
         # (ops.qkv_rope): the weights get a second, row-permuted copy on first use (+3.2 GB at 7B, +6.3 GB at 13B of 288)
@@ -256,6 +260,19 @@ class LlamaHip:
             cache["ssq"] = [torch.zeros((H // 16, 16), dtype=torch.float32, device=self.device) for _ in range(2)]
         pa, pb = cache["ssq"]
         stats = ops.row_stats(x, l.rms_eps, rms=True)
+        if self.decode_chain and x.is_contiguous() and ops.decode_chain_supported(B, H, l.ffn, nh, len(self.layers)):
+            ch = cache.get("chain")
+            if ch is None:
+                dev, bf = self.device, torch.bfloat16
+                ch = cache["chain"] = {
+                    "table": ops.decode_chain_table([(self._folded[i][0], L["wo"], self._folded[i][1], L["wd"], cache["k"][i], cache["v"][i])
+                                                     for i, L in enumerate(self.layers)]),
+                    "qkv": torch.empty((B, 3 * H), dtype=bf, device=dev), "att": torch.empty((B, H), dtype=bf, device=dev),
+                    "g": torch.empty((B, l.ffn), dtype=bf, device=dev),
+                    "sync": torch.zeros((ops.decode_chain_sync_words(len(self.layers)),), dtype=torch.int32, device=dev)}
+            ops.decode_chain(ch["table"], len(self.layers), x, ch["qkv"], ch["att"], ch["g"], pa, pb, stats, l.rms_eps, cs, nk, nh,
+                             cache["tmax"], hd ** -0.5, ch["sync"], per_stage_launches=self.decode_chain == "stages")
+            return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, 1, H)
         for li, L in enumerate(self.layers):
             wq, wgu = self._folded[li]
             if li == 0:

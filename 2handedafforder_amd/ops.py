@@ -4,6 +4,8 @@ torch is used here only for device memory and the current HIP stream; every arit
 hand-written HIP kernel. All functions require CUDA(HIP) tensors and raise if the library is missing.
 dtype policy: torch.bfloat16 = throughput mode (bf16 MFMA, fp32 accumulate), torch.float32 = parity mode.
 """
+import ctypes
+
 import torch
 
 from .lib import check, load_library
@@ -326,6 +328,60 @@ def linear_rms(x, w, resid=None, out=None, swiglu=False, ssq_in=None, ssq_out=No
                                 _p(ssq_in), 0 if ssq_in is None else ssq_in.shape[0], float(eps), _p(ssq_out), None, _stream())
     check(rc, "haff_gemm_bf16_rms")
     return out
+
+
+class ChainLayer(ctypes.Structure):
+    """haff_chain_layer of include/haff_hip.h: the six device pointers of one Llama layer on the chained decode step."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("wqkv", "wo", "wgu", "wd", "kcache", "vcache")]
+
+
+def decode_chain_supported(M, hidden, ffn, heads, n_layers):
+    return int(load_library().haff_decode_chain_supported(int(M), int(hidden), int(ffn), int(heads), int(n_layers))) > 0
+
+
+def decode_chain_sync_words(n_layers):
+    return int(load_library().haff_decode_chain_sync_words(int(n_layers)))
+
+
+def decode_chain_table(layers):
+    """layers: one (wqkv, wo, wgu, wd, kcache, vcache) tuple of bf16 tensors per layer -> the host table haff_decode_chain_bf16 takes."""
+    for row in layers:
+        for t in row:
+            _req(t, "chain operand")
+            assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    return (ChainLayer * len(layers))(*[ChainLayer(*[t.data_ptr() for t in row]) for row in layers])
+
+
+def decode_chain(table, n_layers, x, qkv, att, g, ssq_a, ssq_b, stats0, eps, cos_sin, nk_rows, heads, tmax, scale, sync,
+                 per_stage_launches=False):
+    """One KV-cached decode step of the whole Llama stack at <= 8 rows as ONE launch (haff_decode_chain_bf16): x [M,H] bf16 is
+    the residual stream (in place); qkv [M,3H], att [M,H], g [M,F], ssq_a / ssq_b f32 [H/16,16]: scratch; stats0 f32 [M,2];
+    sync uint32 (int32 tensor) [decode_chain_sync_words(n_layers)], zeroed once at allocation. per_stage_launches: the same kernel, one launch per
+    (layer, stage) — identical arithmetic without the chaining (tests, A/B)."""
+    lib = load_library()
+    _req(x, "x")
+    M, H = x.shape
+    F = g.shape[1]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and qkv.is_contiguous() and att.is_contiguous() and g.is_contiguous()
+    assert qkv.shape == (M, 3 * H) and att.shape == (M, H) and g.shape[0] == M
+    assert ssq_a.dtype == torch.float32 and ssq_a.shape == (H // 16, 16) and ssq_b.shape == (H // 16, 16)
+    assert stats0.dtype == torch.float32 and stats0.shape == (M, 2) and stats0.is_contiguous()
+    assert nk_rows.dtype == torch.int32 and nk_rows.numel() == M and cos_sin.dtype == torch.float32 and cos_sin.shape[1] == 128
+    assert sync.dtype == torch.int32 and sync.numel() >= decode_chain_sync_words(n_layers)
+    rc = lib.haff_decode_chain_bf16(table, int(n_layers), M, H, F, int(heads), x.data_ptr(), qkv.data_ptr(), att.data_ptr(),
+                                    g.data_ptr(), ssq_a.data_ptr(), ssq_b.data_ptr(), stats0.data_ptr(), float(eps),
+                                    cos_sin.data_ptr(), nk_rows.data_ptr(), int(tmax), float(scale), sync.data_ptr(),
+                                    1 if per_stage_launches else 0, _stream())
+    check(rc, "haff_decode_chain_bf16")
+    return x
+
+
+def decode_chain_status(sync, n_layers):
+    """True when every bounded wait of the chained launches so far was satisfied (synchronises the current stream)."""
+    rc = int(load_library().haff_decode_chain_status(sync.data_ptr(), int(n_layers), _stream()))
+    if rc < 0:
+        check(rc, "haff_decode_chain_status")
+    return rc == 0
 
 
 def attention(q, k, v, scale, causal=False, q_pos0=0, relh=None, relw=None, S=0, out=None):

@@ -12,11 +12,13 @@ def main():
     ap.add_argument("--config", default="7b")
     ap.add_argument("--batches", default="1,8,16,32,64")
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--no-chain", action="store_true", help="<= 8 rows: five launches per layer instead of the one chained launch per step")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = {"7b": hcfg.haff_7b, "13b": hcfg.haff_13b}[args.config]()
     model = LisaMI355(cfg, checkpoint.synthetic_state_dict(cfg, 1234, dev), dtype=torch.bfloat16, device=dev)
     model.decode_graphs = not args.eager
+    model.llm.decode_chain = not args.no_chain
     l = cfg.llm
     w_bytes = 2.0 * (l.layers * (4 * l.hidden * l.hidden + 3 * l.hidden * l.ffn) + l.vocab * l.hidden)
     T0 = 36 + 255
