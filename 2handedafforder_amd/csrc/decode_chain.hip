@@ -41,7 +41,20 @@ constexpr int CH_STAGES = 5;
 constexpr int CH_D = 128;        // head dim
 constexpr int CH_KW = 4;         // waves per workgroup: K quarters of a product, key quarters of a head
 constexpr int CH_U = 8;          // k-steps per register set (skinny_batch(1, 1) == skinny_batch(2, 1) == 8)
-constexpr int CH_PRE = 2;        // attention: trips of 16 key groups (64 keys each) whose K / V rows are requested BEFORE the wait (64 registers)
+// experiment knobs (tools/build_chain_variant.sh -DCH_...): the product build takes the defaults below
+#ifndef CH_PRE_TRIPS
+#define CH_PRE_TRIPS 4
+#endif
+#ifndef CH_SLEEP
+#define CH_SLEEP 16
+#endif
+#ifndef CH_W_NT
+#define CH_W_NT 0               // 1: non-temporal loads on the weight stream
+#endif
+#ifndef CH_U_GU
+#define CH_U_GU 8               // k-steps per register set of the gate|up stage (two weight tiles per workgroup)
+#endif
+constexpr int CH_PRE = CH_PRE_TRIPS;        // attention: trips of 16 key groups (64 keys each) whose K / V rows are requested BEFORE the wait (128 registers at 4 trips: 256 keys)
 constexpr int CH_SPIN_LIMIT = 400000;
 constexpr float CH_LOG2E = 1.4426950408889634f;
 
@@ -54,6 +67,7 @@ struct ChainArgs {
   ChainLayer L[CH_MAXL];
   bf16_t *x, *qkv, *att, *g;   // [M][H] residual stream (in / out), [M][3H], [M][H], [M][F] scratch
   float *ssq_a, *ssq_b;        // [H/16][16] partial sums of squares (o_proj -> gate|up, down_proj -> next q|k|v)
+  float* ws;                   // [H/16][2][16][16] f32: the K halves' partial tiles of o_proj / down_proj
   const float* stats0;         // [M][2] {mean, rstd} of the incoming rows (layer 0's RMSNorm)
   const float* cos_sin;        // f32 [tmax][128]
   const int* nk_rows;          // device int32 [M]: position of the new token + 1
@@ -70,21 +84,53 @@ struct ChainArgs {
 // completes a shard adds to every replica, 8 lanes of one instruction; a waiting workgroup polls ONE replica, so the pollers of a
 // stage spread over 8 lines). Every word on a 128-byte line of its own.
 constexpr int CH_SHARDS = 8;
-constexpr int CH_LINE = 32;                                  // words per line
+#ifndef CH_LINE_WORDS
+#define CH_LINE_WORDS 32
+#endif
+constexpr int CH_LINE = CH_LINE_WORDS;                       // words per counter line (32 = one 128-byte line each)
 constexpr int CH_STAGE_WORDS = 2 * CH_SHARDS * CH_LINE;      // 8 shard lines + 8 replica lines
 
+#ifdef CH_PLACE   // experiment builds only: where layer 2's workgroups ran (no atomics: the timing is the product build's)
+__device__ unsigned ch_place_buf[CH_STAGES][1024];   // (xcc << 16) | HW_ID[15:0] of wave 0
+__device__ unsigned long long ch_place_t[CH_STAGES][1024];
+extern "C" int haff_decode_chain_place_read(unsigned* host, unsigned long long* t) {
+  if (t && hipMemcpyFromSymbol(t, HIP_SYMBOL(ch_place_t), sizeof(unsigned long long) * CH_STAGES * 1024) != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(ch_place_buf), sizeof(unsigned) * CH_STAGES * 1024) == hipSuccess ? 0 : 1;
+}
+#endif
+#ifdef CH_TRACE   // experiment builds only: per (layer, stage) {first start, first wait satisfied, last wait satisfied, last end} (100 MHz clock)
+__device__ unsigned long long ch_trace_buf[CH_MAXL * CH_STAGES][4];
+#define CH_TRACE_MIN(slot, k) do { if (threadIdx.x == 0 && (blockIdx.x & 15) == 0) atomicMin(&ch_trace_buf[slot][k], (unsigned long long)wall_clock64()); } while (0)
+#define CH_TRACE_MAX(slot, k) do { if (threadIdx.x == 0 && (blockIdx.x & 15) == 0) atomicMax(&ch_trace_buf[slot][k], (unsigned long long)wall_clock64()); } while (0)
+extern "C" int haff_decode_chain_trace_read(unsigned long long* host, int reset) {
+  if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(ch_trace_buf), sizeof(unsigned long long) * CH_MAXL * CH_STAGES * 4) != hipSuccess) return 1;
+  if (reset) {
+    static unsigned long long init[CH_MAXL * CH_STAGES][4];
+    for (int i = 0; i < CH_MAXL * CH_STAGES; ++i) { init[i][0] = ~0ull; init[i][1] = ~0ull; init[i][2] = 0; init[i][3] = 0; }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ch_trace_buf), init, sizeof(init)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define CH_TRACE_MIN(slot, k) do {} while (0)
+#define CH_TRACE_MAX(slot, k) do {} while (0)
+#endif
+
 __device__ __forceinline__ void chain_wait(unsigned* sync, int idx, int replica, unsigned* err) {
+  CH_TRACE_MIN(idx + 1, 0);
   if (idx < 0) return;
   if (threadIdx.x == 0) {
     const unsigned* w = sync + (long)idx * CH_STAGE_WORDS + (CH_SHARDS + replica) * CH_LINE;
     int spins = 0;
     while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)CH_SHARDS) {
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(CH_SLEEP);
       ++spins;
       if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       if (spins > CH_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
+  CH_TRACE_MIN(idx + 1, 1);
+  CH_TRACE_MAX(idx + 1, 2);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the compiler from moving the sc1 loads above the poll
 }
@@ -93,6 +139,7 @@ __device__ __forceinline__ void chain_wait(unsigned* sync, int idx, int replica,
 // r = index of the workgroup within its stage, nb = workgroups of the stage
 __device__ __forceinline__ void chain_signal(unsigned* sync, int idx, int r, int nb) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CH_TRACE_MAX(idx, 3);
   unsigned* base = sync + (long)idx * CH_STAGE_WORDS;
   const int lane = threadIdx.x & 63;
   const int shard = r & (CH_SHARDS - 1);
@@ -126,20 +173,27 @@ __device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 
 // ---- product stage: C[M][N] = epi(X[M][K] . W[N][K]^T), M <= 8 rows, 16 * NT weight rows per workgroup ----------------------
-template <int NT, bool SWIGLU>
+// KS = 2 (o_proj, down_proj: H / 16 weight tiles, ONE per CU — and the dispatcher does not spread them one per CU: rocprof of the
+// KS = 1 form found down_proj's 256 workgroups on 210 CUs, 46 of them carrying two, and a CU takes in ~22 GB/s whatever runs on it:
+// 32 us for 90 MB): the K extent of a tile is split over TWO workgroups (2 bx = tile, half); each stores its fp32 partial tile
+// write-through, draws a ticket, and the one that draws the second ticket adds the halves in the fixed order half 0 + half 1,
+// runs the epilogue and signals the stage. 512 finer workgroups fill the chip evenly.
+template <int NT, bool SWIGLU, int KS = 1>
 __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int N, int K, const bf16_t* X, long ldx, int M, bf16_t* C,
                                               long ldc, const bf16_t* resid, long ldr, const float* ssq_in, int ssq_n, float eps,
-                                              const float* ln_stats, float* ssq_out, int bx, int nb_stage, unsigned* sync, int wait_idx,
-                                              int signal_idx, unsigned* err) {
-  constexpr int U = CH_U, KW = CH_KW;
+                                              const float* ln_stats, float* ssq_out, int bx_in, int nb_stage, unsigned* sync, int wait_idx,
+                                              int signal_idx, unsigned* err, float* ws = nullptr, unsigned* tickets = nullptr) {
+  static_assert(KS == 1 || (NT == 1 && !SWIGLU), "the K split serves the one-tile residual products");
+  const int bx = bx_in / KS, half = bx_in - bx * KS;
+  constexpr int U = NT == 2 ? CH_U_GU : CH_U, KW = CH_KW;
   __shared__ float red[KW][64][4];
   __shared__ float s_ssq[KW][16];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int fr = lane & 15, fh = lane >> 4;
   const int n0 = bx * 16 * NT;
-  const int kq = K / KW;
-  const int k_lo = wave * kq;
+  const int kq = K / (KW * KS);
+  const int k_lo = (half * KW + wave) * kq;
   const __amdgpu_buffer_rsrc_t xr = ch_rsrc(X, (unsigned)(M * ldx * 2));
   const unsigned xoff = (unsigned)((min(fr, M - 1) * ldx + k_lo + fh * 8) * 2);   // bytes
   const bf16_t* wrow[NT];
@@ -157,8 +211,17 @@ __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int 
       const int k0 = min(k + 32 * u, kq - 32), k1 = min(k + 32 * u + 32, kq - 32);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+#if CH_W_NT
+        {
+          const ch_u32x4 w0 = __builtin_nontemporal_load(reinterpret_cast<const ch_u32x4*>(wrow[t] + k0));
+          const ch_u32x4 w1 = __builtin_nontemporal_load(reinterpret_cast<const ch_u32x4*>(wrow[t] + k1));
+          wv[set][t][u] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+          wv[set][t][u + 1] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+        }
+#else
         wv[set][t][u] = *reinterpret_cast<const uint4*>(wrow[t] + k0);
         wv[set][t][u + 1] = *reinterpret_cast<const uint4*>(wrow[t] + k1);
+#endif
       }
     }
   };
@@ -166,8 +229,13 @@ __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int 
 #pragma unroll
     for (int u = 0; u < U; u += 2) {
       const int k0 = min(k + 32 * u, kq - 32), k1 = min(k + 32 * u + 32, kq - 32);
+#ifdef CH_EXP_PLAINX   // timing only: plain (L1-served) activation loads — stale data
+      xv[set][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(X) + xoff + 2 * k0);
+      xv[set][u + 1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(X) + xoff + 2 * k1);
+#else
       xv[set][u] = ld16_sc1(xr, xoff + 2 * k0);
       xv[set][u + 1] = ld16_sc1(xr, xoff + 2 * k1);
+#endif
     }
   };
   auto compute = [&](int set, int k) {
@@ -185,7 +253,7 @@ __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int 
   // the weights depend on nobody: both register sets are on their way before this workgroup asks whether its inputs exist
   load_w(0, 0);
   if (KB < kq) load_w(1, KB);
-  chain_wait(sync, wait_idx, bx & (CH_SHARDS - 1), err);
+  chain_wait(sync, wait_idx, bx_in & (CH_SHARDS - 1), err);
 
   constexpr int SSQ_M = 8;
   float ssq_a[SSQ_M], ssq_b[SSQ_M];
@@ -250,6 +318,27 @@ __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int 
   }
   if (wave != 0) return;
   const int m = fr;
+  if constexpr (KS == 2) {
+    // partial tile [half][m][16 columns] f32, write-through; the ticket decides who combines
+    float* mine = ws + (((long)bx * 2 + half) * 16 + m) * 16 + 4 * fh;
+    if (m < M) {
+      st8_sc1(mine, make_uint2(__builtin_bit_cast(unsigned, o[0][0]), __builtin_bit_cast(unsigned, o[0][1])));
+      st8_sc1(mine + 2, make_uint2(__builtin_bit_cast(unsigned, o[0][2]), __builtin_bit_cast(unsigned, o[0][3])));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if ((ticket & 1u) == 0u) return;      // first of the pair: the other workgroup finishes the tile
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (m < M) {
+      const __amdgpu_buffer_rsrc_t wr = ch_rsrc(ws, (unsigned)((long)nb_stage * 16 * 16 * 4));   // nb_stage = 2 * tiles
+      const uint4 t = ld16_sc1(wr, (unsigned)(((((long)bx * 2 + (1 - half)) * 16 + m) * 16 + 4 * fh) * 4));
+      const float other[4] = {__builtin_bit_cast(float, t.x), __builtin_bit_cast(float, t.y), __builtin_bit_cast(float, t.z), __builtin_bit_cast(float, t.w)};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[0][r] = half == 0 ? o[0][r] + other[r] : other[r] + o[0][r];   // always half 0 + half 1
+    }
+  }
   if (m < M) {
     if (ssq_in) {
       float tot = 0.f;
@@ -304,7 +393,7 @@ __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int 
       if (fh == 0) st4_sc1(ssq_out + (long)bx * 16 + fr, ssq_acc);
     }
   }
-  chain_signal(sync, signal_idx, bx, nb_stage);
+  chain_signal(sync, signal_idx, bx, nb_stage / KS);
 }
 
 // ---- attention stage: one (row, head) per workgroup, its four waves take every fourth trip of 16 keys ------------------------
@@ -480,6 +569,12 @@ __global__ __launch_bounds__(64 * CH_KW) void decode_chain_kernel(ChainArgs a) {
   int stage = 0;
   while (stage < CH_STAGES - 1 && r >= a.nb[stage]) { r -= a.nb[stage]; ++stage; }
   const ChainLayer& L = a.L[layer];
+#ifdef CH_PLACE
+  if (layer == 2 && threadIdx.x == 0 && r < 1024) {
+    ch_place_buf[stage][r] = ((unsigned)__builtin_amdgcn_s_getreg(6164) << 16) | ((unsigned)__builtin_amdgcn_s_getreg(63492) & 0xffffu);
+    ch_place_t[stage][r] = wall_clock64();
+  }
+#endif
   unsigned* err = a.sync + (long)a.n_layers * CH_STAGES * CH_STAGE_WORDS;
   const int me = layer * CH_STAGES + stage;
   const int dep = me - 1;   // stage 0 of layer l waits for stage 4 of layer l-1; (0, 0): dep = -1, no wait
@@ -493,14 +588,16 @@ __global__ __launch_bounds__(64 * CH_KW) void decode_chain_kernel(ChainArgs a) {
       chain_attention(a, L, r, a.sync, dep, me, err);
       break;
     case 2:
-      chain_product<1, false>(L.wo, H, H, a.att, H, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_a, r, a.nb[2], a.sync, dep, me, err);
+      chain_product<1, false, 2>(L.wo, H, H, a.att, H, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_a, r, a.nb[2], a.sync, dep, me, err,
+                                 a.ws, err + CH_LINE + (long)(layer * 2) * parts);
       break;
     case 3:
       chain_product<2, true>(L.wgu, 2 * F, H, a.x, H, M, a.g, F, nullptr, 0, a.ssq_a, parts, a.eps, nullptr, nullptr, r, a.nb[3], a.sync, dep,
                              me, err);
       break;
     default:
-      chain_product<1, false>(L.wd, H, F, a.g, F, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_b, r, a.nb[4], a.sync, dep, me, err);
+      chain_product<1, false, 2>(L.wd, H, F, a.g, F, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_b, r, a.nb[4], a.sync, dep, me, err,
+                                 a.ws, err + CH_LINE + (long)(layer * 2 + 1) * parts);
       break;
   }
 }
@@ -518,15 +615,16 @@ __global__ __launch_bounds__(64 * CH_KW) void decode_chain_kernel(ChainArgs a) {
 //   sync: DEVICE uint32 [haff_decode_chain_sync_words(n_layers)], zeroed once by the caller: the launch re-zeroes the counters, the
 //   last word is a sticky error flag (a wait ran out of patience: haff_decode_chain_status).
 //   per_stage_launches != 0: the same kernel as n_layers * 5 launches, one per stage (tests / A-B: identical arithmetic, no chaining).
-// hidden % 128 == 0, ffn % 128 == 0, hidden == heads * 128, hidden / 16 <= 512, M <= 8, n_layers <= 48; 16-B aligned pointers.
+// hidden % 256 == 0, ffn % 256 == 0, hidden == heads * 128, hidden / 16 <= 512, M <= 8, n_layers <= 48; 16-B aligned pointers.
 struct haff_chain_layer { const void *wqkv, *wo, *wgu, *wd; void *kcache, *vcache; };
 
 extern "C" int haff_decode_chain_bf16(const haff_chain_layer* layers, int n_layers, int M, int hidden, int ffn, int heads, void* x,
-                                      void* qkv, void* att, void* g, float* ssq_a, float* ssq_b, const float* stats0, float eps,
+                                      void* qkv, void* att, void* g, float* ssq_a, float* ssq_b, float* ws, const float* stats0, float eps,
                                       const float* cos_sin, const int* nk_rows, int tmax, float scale, unsigned* sync,
                                       int per_stage_launches, void* stream) {
   if (!layers || n_layers <= 0 || n_layers > CH_MAXL || M <= 0 || M > 8) return HAFF_ERR_BAD_ARG;
-  if (hidden <= 0 || ffn <= 0 || (hidden % 128) || (ffn % 128) || hidden != heads * CH_D || hidden / 16 > 512) return HAFF_ERR_UNSUPPORTED;
+  if (hidden <= 0 || ffn <= 0 || (hidden % 256) || (ffn % 256) || hidden != heads * CH_D || hidden / 16 > 512) return HAFF_ERR_UNSUPPORTED;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15)) return HAFF_ERR_BAD_ARG;
   if (!x || !qkv || !att || !g || !ssq_a || !ssq_b || !stats0 || !cos_sin || !nk_rows || !sync || tmax <= 0) return HAFF_ERR_BAD_ARG;
   const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(att) |
                        reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(ssq_a) | reinterpret_cast<uintptr_t>(ssq_b);
@@ -544,12 +642,15 @@ extern "C" int haff_decode_chain_bf16(const haff_chain_layer* layers, int n_laye
   for (int i = n_layers; i < CH_MAXL; ++i) a.L[i] = ChainLayer{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.x = reinterpret_cast<bf16_t*>(x); a.qkv = reinterpret_cast<bf16_t*>(qkv); a.att = reinterpret_cast<bf16_t*>(att);
   a.g = reinterpret_cast<bf16_t*>(g);
-  a.ssq_a = ssq_a; a.ssq_b = ssq_b; a.stats0 = stats0; a.cos_sin = cos_sin; a.nk_rows = nk_rows; a.sync = sync;
+  a.ssq_a = ssq_a; a.ssq_b = ssq_b; a.ws = ws; a.stats0 = stats0; a.cos_sin = cos_sin; a.nk_rows = nk_rows; a.sync = sync;
   a.n_layers = n_layers; a.M = M; a.H = hidden; a.F = ffn; a.nh = heads; a.tmax = tmax; a.eps = eps; a.scale = scale;
-  a.nb[0] = 3 * hidden / 16; a.nb[1] = M * heads; a.nb[2] = hidden / 16; a.nb[3] = 2 * ffn / 32; a.nb[4] = hidden / 16;
+  a.nb[0] = 3 * hidden / 16; a.nb[1] = M * heads; a.nb[2] = 2 * (hidden / 16); a.nb[3] = 2 * ffn / 32; a.nb[4] = 2 * (hidden / 16);
   a.per_layer = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4];
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // arrival counters, then (behind the sticky error line, which stays) the tickets of the K-split tiles
   if (hipMemsetAsync(sync, 0, sizeof(unsigned) * n_layers * CH_STAGES * CH_STAGE_WORDS, s) != hipSuccess) return HAFF_ERR_LAUNCH;
+  if (hipMemsetAsync(sync + (long)n_layers * CH_STAGES * CH_STAGE_WORDS + CH_LINE, 0, sizeof(unsigned) * n_layers * 2 * (hidden / 16), s) != hipSuccess)
+    return HAFF_ERR_LAUNCH;
   a.block0 = 0;
   if (!per_stage_launches) {
     hipLaunchKernelGGL(decode_chain_kernel, dim3((unsigned)(n_layers * a.per_layer)), dim3(64 * CH_KW), 0, s, a);
@@ -576,15 +677,15 @@ extern "C" int haff_decode_chain_status(const unsigned* sync, int n_layers, void
   return v ? 1 : 0;
 }
 
-// uint32 words of the sync buffer: 16 counter lines per (layer, stage) + the sticky error word (a line of its own)
-extern "C" int haff_decode_chain_sync_words(int n_layers) {
-  if (n_layers <= 0 || n_layers > CH_MAXL) return 0;
-  return n_layers * CH_STAGES * CH_STAGE_WORDS + CH_LINE;
+// uint32 words of the sync buffer: 16 counter lines per (layer, stage), the sticky error word (a line of its own), one ticket per K-split tile
+extern "C" int haff_decode_chain_sync_words(int n_layers, int hidden) {
+  if (n_layers <= 0 || n_layers > CH_MAXL || hidden <= 0) return 0;
+  return n_layers * CH_STAGES * CH_STAGE_WORDS + CH_LINE + n_layers * 2 * (hidden / 16);
 }
 
 // Workgroups per layer the chained launch uses (for sizing / reporting): 0 when the geometry is unsupported.
 extern "C" int haff_decode_chain_supported(int M, int hidden, int ffn, int heads, int n_layers) {
   if (n_layers <= 0 || n_layers > CH_MAXL || M <= 0 || M > 8) return 0;
-  if (hidden <= 0 || ffn <= 0 || (hidden % 128) || (ffn % 128) || hidden != heads * CH_D || hidden / 16 > 512) return 0;
-  return 3 * hidden / 16 + M * heads + hidden / 16 + 2 * ffn / 32 + hidden / 16;
+  if (hidden <= 0 || ffn <= 0 || (hidden % 256) || (ffn % 256) || hidden != heads * CH_D || hidden / 16 > 512) return 0;
+  return 3 * hidden / 16 + M * heads + 2 * (hidden / 16) + 2 * ffn / 32 + 2 * (hidden / 16);
 }

@@ -31,10 +31,10 @@ _PROTOS = {
                              c_int, c_int, c_long, c_long, c_void_p],
     "haff_gemm_stream_cap": [c_void_p, c_int],
     "haff_decode_chain_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p],
+                               c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p],
     "haff_decode_chain_supported": [c_int, c_int, c_int, c_int, c_int],
     "haff_decode_chain_status": [c_void_p, c_int, c_void_p],
-    "haff_decode_chain_sync_words": [c_int],
+    "haff_decode_chain_sync_words": [c_int, c_int],
     "haff_row_stats": [c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p],
     "haff_row_stats_finalize": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     "haff_gemm_bf16_qkv_rope": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,

@@ -47,6 +47,7 @@ class LisaMI355:
         self.expected_new_tokens = 8          # what the plan assumes a reply takes ("Sure, ... [SEG] ." templates) when max_new_tokens is larger
         self._plan = (None, False, None)      # (caps, wait, chunk) of the evaluate() call in flight (no caps outside one)
         self.last_plan = (None, False, None)  # ... of the last evaluate() call (what bench.py reports)
+        self.last_decode_chain = False
         # The SAM encoder runs on its own HIP stream beside the language model and joins before the mask decoders
         # (+4-5 % frames/s); False serialises everything on the caller's stream (per-kernel measurements). Results are
         # bit-identical either way (tests/test_fullsize_gpu.py; the history of that check: DESIGN.md section 10a).
@@ -56,6 +57,13 @@ class LisaMI355:
         # captured once per (batch, position) into a hipGraph and replayed. The KV cache is persistent per
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
         self.decode_graphs = True
+        # Decode steps of <= 8 rows as ONE chained launch per step (LlamaHip.decode_chain, csrc/decode_chain.hip). "auto": whenever no
+        # CAPPED encoder pass runs beside the decode steps (round 6, same-box A/B: one frame 41.3 -> 37.0 ms, 2 / 3 frames -7.6 / -4.4 %
+        # with the encoder enqueued first; beside an encoder capped to 128..192 CUs the chained launch's 64 000 workgroups keep
+        # refilling every slot of every CU and the two streams starve each other: 4 / 8 frames +21 / +15 % — there the five short
+        # launches per layer and the plan's caps stay). True / False force it for evaluate(); generate() called directly follows
+        # LlamaHip.decode_chain.
+        self.decode_chain = "auto"
         # evaluate(): the last Llama layer of the prefill runs o_proj / MLP / final norm on the rows that are read only (LlamaHip.forward,
         # keep_rows; round 6). False: every row (A/B; generate() called directly always returns every row)
         self.prune_last_layer = True
@@ -208,7 +216,7 @@ class LisaMI355:
         lazily built state inside the ops) and is followed by the capture, which executes nothing."""
         if not self.decode_graphs:
             return self._decode_book_eager(cache)
-        key = ("book", cache["book"]["tok"].shape[0], cache["tmax"])
+        key = ("book", self.llm.decode_chain, cache["book"]["tok"].shape[0], cache["tmax"])   # (the last two: what _persistent_cache evicts by)
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 16:
@@ -239,7 +247,7 @@ class LisaMI355:
             out = self._decode_step_eager(nxt, cache)
         else:
             B = nxt.shape[0]
-            key = (B, cache["tmax"])
+            key = (self.llm.decode_chain, B, cache["tmax"])
             ent = self._graphs.get(key)
             if ent is None:
                 if len(self._graphs) >= 16:
@@ -395,6 +403,9 @@ class LisaMI355:
         # too; at 64 frames the encoder is 60 % of the step and has to start first)
         late = self.overlap_streams and self.sam_beside_decode is not False and \
             (self.sam_beside_decode is True or input_ids.shape[0] <= 16)
+        chain_rows = self.llm.decode_chain and self.decode_chain is not False and input_ids.shape[0] <= self.llm.carry_rms_max_rows
+        if chain_rows and self.decode_chain == "auto" and self.sam_beside_decode is None and input_ids.shape[0] < overlap.MIN_FRAMES:
+            late = False    # 1..3 frames with chained decode steps: the encoder first (2 / 3 frames: 46.4 -> 45.3, 56.9 -> 55.4 ms; one frame: equal)
         # ... and which CUs its GEMM launches leave to the decode steps (overlap.py)
         n_frames = input_ids.shape[0]
         chunk = overlap.auto_chunk(n_frames, late) if self.sam_chunk == "auto" else self.sam_chunk
@@ -411,10 +422,20 @@ class LisaMI355:
             if self.sam_waits_for_prefill != "auto":
                 wait = bool(self.sam_waits_for_prefill) and late
         self._plan = self.last_plan = (caps, wait, chunk)
+        capped = bool(caps) and any(c < 256 for c in caps)
+        chain_prev = self.llm.decode_chain
+        if self.decode_chain == "auto":
+            self.llm.decode_chain = chain_prev and not capped
+        elif self.decode_chain is False:
+            self.llm.decode_chain = False
+        self.last_decode_chain = bool(chain_rows and self.llm.decode_chain)
         if not late:
             launch_sam()
-        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask,
-                                           after_prefill=launch_sam if late else None, needed_hidden_only=True)
+        try:
+            output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, forced_answer, attention_mask,
+                                               after_prefill=launch_sam if late else None, needed_hidden_only=True)
+        finally:
+            self.llm.decode_chain = chain_prev
         emb = sam_out[0]
         self._plan = (None, False, chunk)     # the encoder is enqueued: direct get_visual_embs* calls take no caps
         pred, frame_idx, counts = self.seg_embeddings(output_ids, hidden)

@@ -339,8 +339,8 @@ def decode_chain_supported(M, hidden, ffn, heads, n_layers):
     return int(load_library().haff_decode_chain_supported(int(M), int(hidden), int(ffn), int(heads), int(n_layers))) > 0
 
 
-def decode_chain_sync_words(n_layers):
-    return int(load_library().haff_decode_chain_sync_words(int(n_layers)))
+def decode_chain_sync_words(n_layers, hidden):
+    return int(load_library().haff_decode_chain_sync_words(int(n_layers), int(hidden)))
 
 
 def decode_chain_table(layers):
@@ -352,11 +352,11 @@ def decode_chain_table(layers):
     return (ChainLayer * len(layers))(*[ChainLayer(*[t.data_ptr() for t in row]) for row in layers])
 
 
-def decode_chain(table, n_layers, x, qkv, att, g, ssq_a, ssq_b, stats0, eps, cos_sin, nk_rows, heads, tmax, scale, sync,
+def decode_chain(table, n_layers, x, qkv, att, g, ssq_a, ssq_b, ws, stats0, eps, cos_sin, nk_rows, heads, tmax, scale, sync,
                  per_stage_launches=False):
     """One KV-cached decode step of the whole Llama stack at <= 8 rows as ONE launch (haff_decode_chain_bf16): x [M,H] bf16 is
     the residual stream (in place); qkv [M,3H], att [M,H], g [M,F], ssq_a / ssq_b f32 [H/16,16]: scratch; stats0 f32 [M,2];
-    sync uint32 (int32 tensor) [decode_chain_sync_words(n_layers)], zeroed once at allocation. per_stage_launches: the same kernel, one launch per
+    ws f32 [H/16, 2, 16, 16]: scratch; sync uint32 (int32 tensor) [decode_chain_sync_words(n_layers, H)], zeroed once at allocation. per_stage_launches: the same kernel, one launch per
     (layer, stage) — identical arithmetic without the chaining (tests, A/B)."""
     lib = load_library()
     _req(x, "x")
@@ -367,9 +367,10 @@ def decode_chain(table, n_layers, x, qkv, att, g, ssq_a, ssq_b, stats0, eps, cos
     assert ssq_a.dtype == torch.float32 and ssq_a.shape == (H // 16, 16) and ssq_b.shape == (H // 16, 16)
     assert stats0.dtype == torch.float32 and stats0.shape == (M, 2) and stats0.is_contiguous()
     assert nk_rows.dtype == torch.int32 and nk_rows.numel() == M and cos_sin.dtype == torch.float32 and cos_sin.shape[1] == 128
-    assert sync.dtype == torch.int32 and sync.numel() >= decode_chain_sync_words(n_layers)
+    assert sync.dtype == torch.int32 and sync.numel() >= decode_chain_sync_words(n_layers, H)
+    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() >= (H // 16) * 2 * 256
     rc = lib.haff_decode_chain_bf16(table, int(n_layers), M, H, F, int(heads), x.data_ptr(), qkv.data_ptr(), att.data_ptr(),
-                                    g.data_ptr(), ssq_a.data_ptr(), ssq_b.data_ptr(), stats0.data_ptr(), float(eps),
+                                    g.data_ptr(), ssq_a.data_ptr(), ssq_b.data_ptr(), ws.data_ptr(), stats0.data_ptr(), float(eps),
                                     cos_sin.data_ptr(), nk_rows.data_ptr(), int(tmax), float(scale), sync.data_ptr(),
                                     1 if per_stage_launches else 0, _stream())
     check(rc, "haff_decode_chain_bf16")

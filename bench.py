@@ -1069,6 +1069,9 @@ def main(argv=None):
                          "off = first (beside CLIP + prefill), auto = by batch size (lisa.py)")
     ap.add_argument("--no-prune-last-layer", action="store_true",
                     help="Llama prefill: the last layer's o_proj / MLP / norm on every row instead of the rows evaluate() reads (A/B)")
+    ap.add_argument("--decode-chain", default="auto", choices=["auto", "on"], help="on: the chained decode launch even beside a capped encoder (A/B)")
+    ap.add_argument("--no-decode-chain", action="store_true",
+                    help="decode steps of <= 8 rows: five launches per Llama layer instead of the one chained launch per step (csrc/decode_chain.hip; A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-full-frame", action="store_true", help="cpu_baseline: skip the one real end-to-end CPU frame (~31 GB host RAM, ~1 min)")
     ap.add_argument("--no-parity", action="store_true", help="skip the tiny-config HIP-vs-oracle parity object")
@@ -1142,6 +1145,10 @@ def main(argv=None):
         [int(c) for c in args.sam_caps.split(",")]
     if args.no_prune_last_layer:
         model.prune_last_layer = False
+    if args.no_decode_chain:
+        model.decode_chain = False
+    elif args.decode_chain == "on":
+        model.decode_chain = True
     if args.tables_global:
         model.sam_encoder.fused_global = False
     if args.no_fold_norms:
@@ -1269,7 +1276,9 @@ def main(argv=None):
                              # how the two streams shared the CUs in the timed steps (overlap.py): frames per encoder pass, workgroups per
                              # persistent GEMM launch of each pass (null = one per CU everywhere)
                              "sam_chunk": plan_timed[2], "sam_chunk_workgroup_caps": plan_timed[0],
-                             "sam_waits_for_prefill": plan_timed[1]})
+                             "sam_waits_for_prefill": plan_timed[1],
+                             # decode steps of <= 8 rows as ONE chained launch per step (csrc/decode_chain.hip) in the timed steps
+                             "decode_chain": bool(getattr(model, "last_decode_chain", False))})
         line["roofline"] = roofline
         line["rccl_ranks"] = n_ranks
         if f32_mode:

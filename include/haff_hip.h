@@ -68,22 +68,23 @@ int haff_gemm_bf16_rms(const void* A, long lda, const void* W, long ldw, void* C
  *           wgu [2F][H] (16-row [gate | up] groups, post_attention_layernorm gamma folded in), wd [H][F], kcache, vcache
  *           [M][tmax][H]} of DEVICE pointers, copied into the kernel arguments;
  *   x [M][H] bf16 residual stream, in place; stats0 f32 [M][2] {mean, rstd} of its rows on entry (haff_row_stats, rms);
- *   qkv [M][3H], att [M][H], g [M][F] bf16 and ssq_a / ssq_b f32 [H/16][16]: scratch; cos_sin f32 [tmax][128];
+ *   qkv [M][3H], att [M][H], g [M][F] bf16, ssq_a / ssq_b f32 [H/16][16] and ws f32 [H/16][2][16][16] (the partial tiles of
+ *   o_proj / down_proj, whose K extent is split over two workgroups and added in a fixed order): scratch; cos_sin f32 [tmax][128];
  *   nk_rows device int32 [M] = position of the new token + 1;
- *   sync: DEVICE uint32 [haff_decode_chain_sync_words(n_layers)], zeroed ONCE by the caller — the launch re-zeroes its arrival
+ *   sync: DEVICE uint32 [haff_decode_chain_sync_words(n_layers, hidden)], zeroed ONCE by the caller — the launch re-zeroes its arrival
  *   counters (8 shards + 8 replicas per (layer, stage), a 128-byte line each), the last line holds a sticky flag set when a
  *   bounded wait ran out (the grid then drains with a garbage result): haff_decode_chain_status.
- * hidden % 128 == 0, ffn % 128 == 0, hidden == heads * 128, hidden <= 8192, M <= 8, n_layers <= 48, pointers 16-B aligned;
+ * hidden % 256 == 0, ffn % 256 == 0, hidden == heads * 128, hidden <= 8192, M <= 8, n_layers <= 48, pointers 16-B aligned;
  * otherwise -2 / -1. per_stage_launches != 0: the same kernel as one launch per (layer, stage) — identical arithmetic without the
  * chaining (tests, A/B). Handed-off bytes travel as agent-scope (sc1) stores and loads, no fences. haff_decode_chain_supported: workgroups per layer of the launch, 0 = unsupported geometry.
  * haff_decode_chain_status (synchronises the stream): 0 = every wait so far was satisfied, 1 = one ran out. */
 typedef struct haff_chain_layer { const void *wqkv, *wo, *wgu, *wd; void *kcache, *vcache; } haff_chain_layer;
 int haff_decode_chain_bf16(const haff_chain_layer* layers, int n_layers, int M, int hidden, int ffn, int heads, void* x,
-                           void* qkv, void* att, void* g, float* ssq_a, float* ssq_b, const float* stats0, float eps,
+                           void* qkv, void* att, void* g, float* ssq_a, float* ssq_b, float* ws, const float* stats0, float eps,
                            const float* cos_sin, const int* nk_rows, int tmax, float scale, unsigned* sync,
                            int per_stage_launches, void* stream);
 int haff_decode_chain_supported(int M, int hidden, int ffn, int heads, int n_layers);
-int haff_decode_chain_sync_words(int n_layers);
+int haff_decode_chain_sync_words(int n_layers, int hidden);
 int haff_decode_chain_status(const unsigned* sync, int n_layers, void* stream);
 /* haff_gemm_bf16 with a gather on the A side: logical row m reads A row a_map[m] (0 <= a_map[m] < a_rows). Runs the
  * window-unpartition projection over real tokens only (image_encoder.py:186-188,291-318 drop the padded rows right

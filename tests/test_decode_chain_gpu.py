@@ -128,5 +128,5 @@ def test_chain_rejects_what_it_cannot_run(dev):
     assert ops.decode_chain_supported(8, 4096, 11008, 32, 32) and ops.decode_chain_supported(1, 5120, 13824, 40, 40)
     assert not ops.decode_chain_supported(9, 4096, 11008, 32, 32)       # more rows than the norm-carrying products gather
     assert not ops.decode_chain_supported(8, 4096, 11008, 64, 32)       # head dim != 128
-    assert not ops.decode_chain_supported(8, 4096, 11000, 32, 32)       # ffn % 128
+    assert not ops.decode_chain_supported(8, 4096, 11136, 32, 32)       # ffn % 256
     assert not ops.decode_chain_supported(8, 4096, 11008, 32, 49)       # more layers than the kernel arguments hold
