@@ -116,13 +116,16 @@ extern "C" int haff_decode_chain_trace_read(unsigned long long* host, int reset)
 #define CH_TRACE_MAX(slot, k) do {} while (0)
 #endif
 
-__device__ __forceinline__ void chain_wait(unsigned* sync, int idx, int replica, unsigned* err) {
+// nb_dep: workgroups of the stage waited for (its non-empty shards: min(nb_dep, 8) — the q|k|v / attention stages of a narrow model
+// have fewer workgroups than shards)
+__device__ __forceinline__ void chain_wait(unsigned* sync, int idx, int replica, unsigned* err, int nb_dep) {
   CH_TRACE_MIN(idx + 1, 0);
   if (idx < 0) return;
+  const unsigned full = (unsigned)min(nb_dep, CH_SHARDS);
   if (threadIdx.x == 0) {
     const unsigned* w = sync + (long)idx * CH_STAGE_WORDS + (CH_SHARDS + replica) * CH_LINE;
     int spins = 0;
-    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)CH_SHARDS) {
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < full) {
       __builtin_amdgcn_s_sleep(CH_SLEEP);
       ++spins;
       if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -181,8 +184,8 @@ __device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byt
 template <int NT, bool SWIGLU, int KS = 1>
 __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int N, int K, const bf16_t* X, long ldx, int M, bf16_t* C,
                                               long ldc, const bf16_t* resid, long ldr, const float* ssq_in, int ssq_n, float eps,
-                                              const float* ln_stats, float* ssq_out, int bx_in, int nb_stage, unsigned* sync, int wait_idx,
-                                              int signal_idx, unsigned* err, float* ws = nullptr, unsigned* tickets = nullptr) {
+                                              const float* ln_stats, float* ssq_out, int bx_in, int nb_stage, int nb_dep, unsigned* sync,
+                                              int wait_idx, int signal_idx, unsigned* err, float* ws = nullptr, unsigned* tickets = nullptr) {
   static_assert(KS == 1 || (NT == 1 && !SWIGLU), "the K split serves the one-tile residual products");
   const int bx = bx_in / KS, half = bx_in - bx * KS;
   constexpr int U = NT == 2 ? CH_U_GU : CH_U, KW = CH_KW;
@@ -253,7 +256,7 @@ __device__ __forceinline__ void chain_product(const bf16_t* __restrict__ W, int 
   // the weights depend on nobody: both register sets are on their way before this workgroup asks whether its inputs exist
   load_w(0, 0);
   if (KB < kq) load_w(1, KB);
-  chain_wait(sync, wait_idx, bx_in & (CH_SHARDS - 1), err);
+  chain_wait(sync, wait_idx, bx_in & (CH_SHARDS - 1), err, nb_dep);
 
   constexpr int SSQ_M = 8;
   float ssq_a[SSQ_M], ssq_b[SSQ_M];
@@ -446,7 +449,7 @@ __device__ __forceinline__ void chain_attention(const ChainArgs& a, const ChainL
       vr[n][u] = *reinterpret_cast<const uint4*>(vb + (long)kc * H);
     }
   }
-  chain_wait(sync, wait_idx, bh & (CH_SHARDS - 1), err);
+  chain_wait(sync, wait_idx, bh & (CH_SHARDS - 1), err, a.nb[0]);
 
   float qv[8];
   const __amdgpu_buffer_rsrc_t qr = ch_rsrc(a.qkv, (unsigned)(a.M * ld * 2));
@@ -562,6 +565,17 @@ __device__ __forceinline__ void chain_attention(const ChainArgs& a, const ChainL
   chain_signal(sync, signal_idx, bh, a.nb[1]);
 }
 
+// Zeroes the arrival counters and the tickets WRITE-THROUGH (agent-scope stores): the chained launch reads and updates these words
+// with agent-scope atomics, i.e. at the memory side. (Round 6: with hipMemsetAsync in front of the launch the chained step was
+// bit-repeatable eagerly and NOT inside a hipGraph replay — every replay gave another result while the same kernel launched stage by
+// stage stayed exact: the memset node's zeros were not where the atomics looked yet, waits saw the previous replay's counts and
+// let stages start early. tools/chain_stress.py)
+__global__ __launch_bounds__(256) void chain_zero_kernel(unsigned* a, long na, unsigned* b, long nb) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < na) __hip_atomic_store(a + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (i - na < nb) __hip_atomic_store(b + (i - na), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(64 * CH_KW) void decode_chain_kernel(ChainArgs a) {
   const int bid = (int)blockIdx.x + a.block0;
   const int layer = bid / a.per_layer;
@@ -582,22 +596,22 @@ __global__ __launch_bounds__(64 * CH_KW) void decode_chain_kernel(ChainArgs a) {
   switch (stage) {
     case 0:
       chain_product<1, false>(L.wqkv, 3 * H, H, a.x, H, M, a.qkv, 3L * H, nullptr, 0, layer > 0 ? a.ssq_b : nullptr, parts, a.eps,
-                              layer == 0 ? a.stats0 : nullptr, nullptr, r, a.nb[0], a.sync, dep, me, err);
+                              layer == 0 ? a.stats0 : nullptr, nullptr, r, a.nb[0], a.nb[4] / 2, a.sync, dep, me, err);
       break;
     case 1:
       chain_attention(a, L, r, a.sync, dep, me, err);
       break;
     case 2:
-      chain_product<1, false, 2>(L.wo, H, H, a.att, H, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_a, r, a.nb[2], a.sync, dep, me, err,
-                                 a.ws, err + CH_LINE + (long)(layer * 2) * parts);
+      chain_product<1, false, 2>(L.wo, H, H, a.att, H, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_a, r, a.nb[2], a.nb[1], a.sync, dep, me,
+                                 err, a.ws, err + CH_LINE + (long)(layer * 2) * parts);
       break;
     case 3:
-      chain_product<2, true>(L.wgu, 2 * F, H, a.x, H, M, a.g, F, nullptr, 0, a.ssq_a, parts, a.eps, nullptr, nullptr, r, a.nb[3], a.sync, dep,
-                             me, err);
+      chain_product<2, true>(L.wgu, 2 * F, H, a.x, H, M, a.g, F, nullptr, 0, a.ssq_a, parts, a.eps, nullptr, nullptr, r, a.nb[3], a.nb[2] / 2, a.sync,
+                             dep, me, err);
       break;
     default:
-      chain_product<1, false, 2>(L.wd, H, F, a.g, F, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_b, r, a.nb[4], a.sync, dep, me, err,
-                                 a.ws, err + CH_LINE + (long)(layer * 2 + 1) * parts);
+      chain_product<1, false, 2>(L.wd, H, F, a.g, F, M, a.x, H, a.x, H, nullptr, 0, a.eps, nullptr, a.ssq_b, r, a.nb[4], a.nb[3], a.sync, dep, me,
+                                 err, a.ws, err + CH_LINE + (long)(layer * 2 + 1) * parts);
       break;
   }
 }
@@ -648,9 +662,10 @@ extern "C" int haff_decode_chain_bf16(const haff_chain_layer* layers, int n_laye
   a.per_layer = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4];
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // arrival counters, then (behind the sticky error line, which stays) the tickets of the K-split tiles
-  if (hipMemsetAsync(sync, 0, sizeof(unsigned) * n_layers * CH_STAGES * CH_STAGE_WORDS, s) != hipSuccess) return HAFF_ERR_LAUNCH;
-  if (hipMemsetAsync(sync + (long)n_layers * CH_STAGES * CH_STAGE_WORDS + CH_LINE, 0, sizeof(unsigned) * n_layers * 2 * (hidden / 16), s) != hipSuccess)
-    return HAFF_ERR_LAUNCH;
+  {
+    const long na = (long)n_layers * CH_STAGES * CH_STAGE_WORDS, nt = (long)n_layers * 2 * (hidden / 16);
+    hipLaunchKernelGGL(chain_zero_kernel, dim3((unsigned)((na + nt + 255) / 256)), dim3(256), 0, s, sync, na, sync + na + CH_LINE, nt);
+  }
   a.block0 = 0;
   if (!per_stage_launches) {
     hipLaunchKernelGGL(decode_chain_kernel, dim3((unsigned)(n_layers * a.per_layer)), dim3(64 * CH_KW), 0, s, a);

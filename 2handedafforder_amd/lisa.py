@@ -179,6 +179,12 @@ class LisaMI355:
         while n_done < max_new_tokens and not bool(st["finished"].all()):
             self._decode_book_step(cache)
             n_done += 1
+        ch = cache.get("chain")
+        if ch is not None and n_done > 1 and not ops.decode_chain_status(ch["sync"], len(self.llm.layers)):
+            # a bounded wait of the chained decode launch ran out (csrc/decode_chain.hip): the tokens above are garbage — fail loudly
+            ch["sync"].zero_()
+            raise RuntimeError("chained decode launch: a stage's arrival counter never filled (sticky error word set); "
+                               "set LlamaHip.decode_chain = False to take the five-launch layer")
         return out_ids[:, :L + n_done].clone(), hidden[:, :T + n_done - 1].clone()
 
     def _persistent_cache(self, B, tmax):
