@@ -58,11 +58,11 @@ class LisaMI355:
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
         self.decode_graphs = True
         # Decode steps of <= 8 rows as ONE chained launch per step (LlamaHip.decode_chain, csrc/decode_chain.hip). "auto": whenever no
-        # CAPPED encoder pass runs beside the decode steps (round 6, same-box A/B: one frame 41.3 -> 37.0 ms, 2 / 3 frames -7.6 / -4.4 %
-        # with the encoder enqueued first; beside an encoder capped to 128..192 CUs the chained launch's 64 000 workgroups keep
-        # refilling every slot of every CU and the two streams starve each other: 4 / 8 frames +21 / +15 % — there the five short
-        # launches per layer and the plan's caps stay). True / False force it for evaluate(); generate() called directly follows
-        # LlamaHip.decode_chain.
+        # CAPPED encoder pass runs beside the decode steps (round 6, same-box A/B with the final synchronisation: decode step 3.24 ->
+        # 3.10 ms at one row, one frame 41.3 -> 40.5 ms, three frames 57.3 -> 56.3; beside an encoder capped to 128..192 CUs the
+        # chained launch's 64 000 workgroups keep refilling every slot of every CU and the two streams starve each other — 4 / 8
+        # frames lose 15..20 % — so there the five short launches per layer and the plan's caps stay). True / False force it for
+        # evaluate(); generate() called directly follows LlamaHip.decode_chain.
         self.decode_chain = "auto"
         # evaluate(): the last Llama layer of the prefill runs o_proj / MLP / final norm on the rows that are read only (LlamaHip.forward,
         # keep_rows; round 6). False: every row (A/B; generate() called directly always returns every row)
@@ -410,8 +410,6 @@ class LisaMI355:
         late = self.overlap_streams and self.sam_beside_decode is not False and \
             (self.sam_beside_decode is True or input_ids.shape[0] <= 16)
         chain_rows = self.llm.decode_chain and self.decode_chain is not False and input_ids.shape[0] <= self.llm.carry_rms_max_rows
-        if chain_rows and self.decode_chain == "auto" and self.sam_beside_decode is None and input_ids.shape[0] < overlap.MIN_FRAMES:
-            late = False    # 1..3 frames with chained decode steps: the encoder first (2 / 3 frames: 46.4 -> 45.3, 56.9 -> 55.4 ms; one frame: equal)
         # ... and which CUs its GEMM launches leave to the decode steps (overlap.py)
         n_frames = input_ids.shape[0]
         chunk = overlap.auto_chunk(n_frames, late) if self.sam_chunk == "auto" else self.sam_chunk
