@@ -6,32 +6,48 @@
 //
 // Why: at <= 8 rows a decode step is a stream over 13.2 GB (7B) of weights that the five-launches-per-layer form reads at 4.1 TB/s
 // (98 us per layer against 65 us of pure stream; rocprofv3: q|k|v / o / down 18 us average, gate|up 35 us, attention 8.7 us):
-// every launch boundary drains the memory pipe — the last workgroups of a product finish, the next product's first loads then
-// take a cold round trip. Here a workgroup of stage s+1 is dispatched as soon as a slot frees up, requests the first two register
-// sets of ITS weight slab (half of it at K = 4096) — weights depend on nothing — and only then waits for stage s's counter; the
-// attention stage's latency (a few KB of q / k / v per head) is covered by the o_proj and gate|up workgroups that already hold
-// their weights. The stream never stops at a boundary.
+// every launch boundary drains the memory pipe. Here a workgroup of stage s+1 is dispatched as soon as a slot frees up, requests the
+// first two register sets of ITS weight slab — weights depend on nothing — and only then waits for stage s's counter.
+// What it buys (MI355X, same box, hipGraph replay): 3.24 -> 3.10 ms per step at one row, 3.29 -> 3.15 at two, 3.37 -> 3.25 at four
+// (-4 %); the rest of the distance to the stream bound is the hand-off itself: ~4.4 us per stage from the last producer's store to
+// the first consumer's MFMA (store drain, shard add, replica adds, poll, sc1 loads of the activations) where a kernel boundary
+// costs 1.2-1.9 us but lets nothing run ahead. (With the waits switched off — a bug of the first version, below — the same grid runs
+// a step in 2.4 ms: that, not 3.1, is what the weight stream alone costs.)
+//
+// Three things the measurements forced:
+//  * hand-offs are `sc1` (agent-scope, write-through) stores and `sc1` loads, drained before ONE lane signals — no release / acquire
+//    fence per workgroup: the first version fenced (buffer_wbl2 sc1 / buffer_inv sc1) in each of the 64 000 workgroups of a step and
+//    ran at 9.1 ms per step;
+//  * arrival counters are SHARDED (8 shards + 8 replicas of the "shards complete" count per stage, a 128-byte line each): ~12 ns per
+//    agent-scope add on one word made 768 arrivals 9 us, a tenth of a layer;
+//  * o_proj / down_proj split K over TWO workgroups per 16-row tile: the dispatcher does not deal a stage's workgroups one per CU
+//    (down_proj's 256 landed on 210 CUs, 46 of them carrying two) and a CU takes in ~22 GB/s whatever runs on it, so the stage ran
+//    32 us for 90 MB; 512 half-K workgroups land two per CU on every CU (tools/chain_trace.py, -DCH_PLACE): 21 us;
+//  * the counters are zeroed WRITE-THROUGH by a kernel in front of the launch: behind a hipMemsetAsync node the chained step was
+//    bit-repeatable eagerly and a different result on every hipGraph replay (tools/chain_stress.py) — and 25 % faster, because the
+//    waits saw the previous replay's counts and let stages start early.
 //
 // Deadlock freedom: a workgroup waits only for workgroups with a LOWER blockIdx.x (earlier stage of the same layer, or the last
 // stage of the previous layer); the dispatcher hands out workgroups of a 1-D grid in index order per XCD, so everything a resident
-// workgroup waits for is resident or finished, and stage 0 of layer 0 waits for nothing. Every spin is bounded anyway: a wait
-// that runs out sets the sticky error word behind the counters, every later wait returns at once, the grid drains (the result is
-// then garbage and haff_decode_chain_status reports it).
+// workgroup waits for is resident or finished, and stage 0 of layer 0 waits for nothing — on any number of free CUs (beside
+// another stream's kernels too). Every spin is bounded anyway: a wait that runs out sets the sticky error word behind the counters,
+// every later wait returns at once, the grid drains (the result is then garbage; haff_decode_chain_status reports it and
+// LisaMI355.generate raises).
 //
 // Visibility between workgroups (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by another CU's stores):
 // every byte one stage hands to the next — the residual stream, q|k|v, the attention output, the SwiGLU output, the partial sums of
-// squares — is STORED write-through at agent scope (`sc1`: 8-byte / 4-byte relaxed agent atomics) and LOADED with `sc1` loads
-// (buffer_load_dwordx4 / global_load_dwordx2 ... sc1 to registers), the storing wave drains its stores (s_waitcnt vmcnt(0)) before ONE
-// lane adds to the stage's arrival counter, one lane of a consumer polls that counter with relaxed agent loads and the workgroup
-// barrier stands between the poll and every load of the handed-off bytes. No release / acquire fence per workgroup: the first version
-// of this file fenced (buffer_wbl2 sc1 / buffer_inv sc1) in each of the 64 000 workgroups of a step and ran at 9.1 ms per step
-// against 3.2 ms for the five-launch layer. Bytes no workgroup of the launch writes (weights, old cache rows, RoPE table, positions)
-// are plain loads; the cache rows appended here are read by later launches only.
+// squares, the K halves' partial tiles — is STORED write-through at agent scope (`sc1`: 8-byte / 4-byte relaxed agent atomics) and
+// LOADED with `sc1` loads (buffer_load_dwordx4 / global_load_dwordx2 ... sc1 to registers), the storing wave drains its stores
+// (s_waitcnt vmcnt(0)) before ONE lane adds to the stage's arrival counter, one lane of a consumer polls with relaxed agent loads and
+// the workgroup barrier stands between the poll and every load of the handed-off bytes. Bytes no workgroup of the launch writes
+// (weights, old cache rows, RoPE table, positions) are plain loads; the cache rows appended here are read by later launches only.
 //
-// Arithmetic: the product stage is gemm_skinny_kernel<1, NT, SWIGLU, 4> of gemm_bf16.hip statement for statement (same K split over
-// the four waves, same k-step order per accumulator, same LDS reduction order, same epilogue), the attention stage is
-// attn_decode_kernel<SPLIT, ROPE, NW = 4> of attention.hip: the chained step is BIT-IDENTICAL to the five-launch layer wherever
-// that one takes the 4-wave attention (5..8 rows; at <= 4 rows the library splits a head over 16 waves: same sums, another order).
+// Arithmetic: the product stage follows gemm_skinny_kernel<1, NT, SWIGLU, 4> of gemm_bf16.hip (same k-step order per accumulator,
+// same LDS reduction over the four waves, same epilogue; o_proj / down_proj add their two K halves in the fixed order half 0 +
+// half 1), the attention stage attn_decode_kernel<SPLIT, ROPE, NW = 4> of attention.hip. Against the five-launch layer the step
+// agrees to a few bf16 ulps of the output scale (hipcc contracts the FMAs of the two translation units differently; at <= 4 rows
+// the library splits a head over 16 waves); against ITSELF launched stage by stage (per_stage_launches: every wait satisfied by
+// stream order) it is BIT-IDENTICAL — what tests/test_decode_chain_gpu.py and tests/test_fullsize_gpu.py hold it to.
 #include "haff_common.h"
 
 namespace {

@@ -131,9 +131,6 @@ class LlamaHip:
         # layer are workgroup ranges chained by arrival counters, weights are requested before a workgroup waits for its inputs.
         # Same arithmetic as the five-launch layer below (bit-identical at 5..8 rows). False: the five launches per layer.
         self.decode_chain = True      # "stages": the same kernel as one launch per (layer, stage) (tests, A/B)
-        self.chain_scratch_stride = None
-        self.chain_own_x = False
-        self.chain_x_offset = 0
         self._cs = None
         # Prefill-sized batches (>= 1024 rows: where the 8-wave tile runs anyway): RoPE and the KV-cache append ride in the q|k|v projection's epilogue
         # (ops.qkv_rope): the weights get a second, row-permuted copy on first use (+3.2 GB at 7B, +6.3 GB at 13B of 288)
@@ -265,40 +262,26 @@ class LlamaHip:
         B, H = x.shape
         nh, hd = l.heads, self.hd
         self.fold_norm_weights()
-        if "ssq" not in cache:
-            cache["ssq"] = [torch.zeros((H // 16, 16), dtype=torch.float32, device=self.device) for _ in range(2)]
-        pa, pb = cache["ssq"]
         stats = ops.row_stats(x, l.rms_eps, rms=True)
         if self.decode_chain and x.is_contiguous() and ops.decode_chain_supported(B, H, l.ffn, nh, len(self.layers)):
             ch = cache.get("chain")
             if ch is None:
                 dev, bf = self.device, torch.bfloat16
-                n_sync = ops.decode_chain_sync_words(len(self.layers), H)
-                sizes = {"qkv": B * 3 * H * 2, "att": B * H * 2, "g": B * l.ffn * 2, "ws": (H // 16) * 2 * 256 * 4, "sync": n_sync * 4,
-                         "ssq_a": (H // 16) * 64, "ssq_b": (H // 16) * 64, "x": B * H * 2 + 65536}
-                stride = self.chain_scratch_stride
-                if stride:   # one arena, buffer i at i * stride (experiments: where the hot scratch sits relative to each other)
-                    assert stride >= max(sizes.values()) and stride % 512 == 0
-                    arena = torch.zeros((stride * len(sizes),), dtype=torch.uint8, device=dev)
-                    raw = {k: arena[i * stride:i * stride + n] for i, (k, n) in enumerate(sizes.items())}
-                else:
-                    arena = None
-                    raw = {k: torch.zeros((n,), dtype=torch.uint8, device=dev) for k, n in sizes.items()}
+                z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
                 ch = cache["chain"] = {
-                    "arena": arena,
                     "table": ops.decode_chain_table([(self._folded[i][0], L["wo"], self._folded[i][1], L["wd"], cache["k"][i], cache["v"][i])
                                                      for i, L in enumerate(self.layers)]),
-                    "qkv": raw["qkv"].view(bf).view(B, 3 * H), "att": raw["att"].view(bf).view(B, H), "g": raw["g"].view(bf).view(B, l.ffn),
-                    "ws": raw["ws"].view(torch.float32).view(H // 16, 2, 16, 16), "sync": raw["sync"].view(torch.int32),
-                    "ssq_a": raw["ssq_a"].view(torch.float32).view(H // 16, 16), "ssq_b": raw["ssq_b"].view(torch.float32).view(H // 16, 16),
-                    "x": raw["x"][self.chain_x_offset:self.chain_x_offset + B * H * 2].view(bf).view(B, H)}
+                    "qkv": z((B, 3 * H), bf), "att": z((B, H), bf), "g": z((B, l.ffn), bf), "ws": z((H // 16, 2, 16, 16), torch.float32),
+                    "ssq_a": z((H // 16, 16), torch.float32), "ssq_b": z((H // 16, 16), torch.float32),
+                    # arrival counters + tickets + the sticky error word: zeroed here once, the launch re-zeroes what it counts with
+                    "sync": z((ops.decode_chain_sync_words(len(self.layers), H),), torch.int32)}
             pa, pb = ch["ssq_a"], ch["ssq_b"]
-            if self.chain_own_x:
-                x = ch["x"].copy_(x)
-            ch["x_ptr"] = x.data_ptr()
             ops.decode_chain(ch["table"], len(self.layers), x, ch["qkv"], ch["att"], ch["g"], pa, pb, ch["ws"], stats, l.rms_eps, cs, nk, nh,
                              cache["tmax"], hd ** -0.5, ch["sync"], per_stage_launches=self.decode_chain == "stages")
             return ops.rmsnorm(x, self.norm, l.rms_eps).view(B, 1, H)
+        if "ssq" not in cache:
+            cache["ssq"] = [torch.zeros((H // 16, 16), dtype=torch.float32, device=self.device) for _ in range(2)]
+        pa, pb = cache["ssq"]
         for li, L in enumerate(self.layers):
             wq, wgu = self._folded[li]
             if li == 0:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-stage timeline of the chained decode step (a -DCH_TRACE build of csrc/decode_chain.hip, tools/build_chain_variant.sh trace -DCH_TRACE;
+"""Per-stage timeline of the chained decode step (a -DCH_TRACE build of csrc/decode_chain.hip, tools/build_chain_variant.sh trace -DCH_TRACE -DCH_PLACE;
 run with HAFF_LIB_PATH=.../libhaff_chain_trace.so): for every (layer, stage) the first workgroup's start, the first and the last
 satisfied wait and the last workgroup's end, in us from the launch's first stamp.   usage: chain_trace.py [B] [layers]"""
 import ctypes
@@ -50,9 +50,9 @@ for i, r in enumerate(t):
     prev_end = en
 
 pr = ctypes.CDLL(hlib.LIB_PATH).haff_decode_chain_place_read
-pr.argtypes = [ctypes.c_void_p]
+pr.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 pb = (ctypes.c_uint * (5 * 1024))()
-pr(pb)
+pr(pb, None)
 nbs = [3 * cfg.llm.hidden // 16, B * cfg.llm.heads, cfg.llm.hidden // 8, 2 * cfg.llm.ffn // 32, cfg.llm.hidden // 8]
 from collections import Counter
 print("placement of layer 2's workgroups (CU key = xcc, se, sh, cu of HW_ID):")

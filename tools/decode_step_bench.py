@@ -12,9 +12,6 @@ def main():
     ap.add_argument("--config", default="7b")
     ap.add_argument("--batches", default="1,8,16,32,64")
     ap.add_argument("--eager", action="store_true")
-    ap.add_argument("--scratch-stride", type=int, default=0, help="chained step: scratch buffers carved from one arena at this byte stride")
-    ap.add_argument("--own-x", action="store_true", help="chained step: the residual stream lives in the chain's own scratch (copied in)")
-    ap.add_argument("--x-offset", type=int, default=0)
     ap.add_argument("--prefold", action="store_true", help="build the norm-folded weight copies before the first cache is allocated")
     ap.add_argument("--dummy-cache", type=int, default=0)
     ap.add_argument("--dummy-step", action="store_true")
@@ -109,7 +106,6 @@ def main():
             ent = model._graphs.get((B, cache["tmax"]))
             ptrs = {k: ch[k].data_ptr() for k in ("qkv", "att", "g", "ws", "sync")}
             ptrs["ssq_a"], ptrs["ssq_b"] = ch["ssq_a"].data_ptr(), ch["ssq_b"].data_ptr()
-            ptrs["x"] = ch.get("x_ptr", 0)
             ptrs["k0"], ptrs["nk"] = cache["k"][0].data_ptr(), cache["nk"].data_ptr()
             if ent is not None:
                 ptrs["graph_in"], ptrs["graph_h1"] = ent[1].data_ptr(), ent[2].data_ptr()
