@@ -410,6 +410,11 @@ class LisaMI355:
         late = self.overlap_streams and self.sam_beside_decode is not False and \
             (self.sam_beside_decode is True or input_ids.shape[0] <= 16)
         chain_rows = self.llm.decode_chain and self.decode_chain is not False and input_ids.shape[0] <= self.llm.carry_rms_max_rows
+        if chain_rows and self.decode_chain == "auto" and self.sam_beside_decode is None and input_ids.shape[0] < overlap.MIN_FRAMES:
+            # 1..3 frames, chained decode steps: the encoder FIRST (beside CLIP + prefill), the steps alone behind it — a chained step is
+            # one 3 ms launch whose workgroups hold every CU, the encoder's launches cannot slip in between (same box, one frame:
+            # encoder first + chain 40.5 ms, behind the prefill + five launches 41.3, behind the prefill + chain 41.8)
+            late = False
         # ... and which CUs its GEMM launches leave to the decode steps (overlap.py)
         n_frames = input_ids.shape[0]
         chunk = overlap.auto_chunk(n_frames, late) if self.sam_chunk == "auto" else self.sam_chunk

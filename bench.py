@@ -1178,6 +1178,7 @@ def main(argv=None):
     outs = []
     elapsed = hdist.timed_steps(lambda: outs.append(step()), args.steps, device)  # fence | K steps | fence | max over ranks
     out = outs[-1]
+    chain_timed = bool(getattr(model, "last_decode_chain", False))
     plan_timed = model.last_plan     # (workgroup caps per encoder chunk, encoder waits for the prefill, frames per chunk) of the timed steps
     ms_per_step = 1e3 * elapsed / args.steps
     fps = world * B * args.steps / elapsed
@@ -1278,7 +1279,7 @@ def main(argv=None):
                              "sam_chunk": plan_timed[2], "sam_chunk_workgroup_caps": plan_timed[0],
                              "sam_waits_for_prefill": plan_timed[1],
                              # decode steps of <= 8 rows as ONE chained launch per step (csrc/decode_chain.hip) in the timed steps
-                             "decode_chain": bool(getattr(model, "last_decode_chain", False))})
+                             "decode_chain": chain_timed})
         line["roofline"] = roofline
         line["rccl_ranks"] = n_ranks
         if f32_mode:

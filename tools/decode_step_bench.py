@@ -28,12 +28,9 @@ def main():
     model = LisaMI355(cfg, checkpoint.synthetic_state_dict(cfg, 1234, dev), dtype=torch.bfloat16, device=dev)
     model.decode_graphs = not args.eager
     model.llm.decode_chain = not args.no_chain
-    model.llm.chain_scratch_stride = args.scratch_stride or None
-    model.llm.chain_own_x = args.own_x
     if args.prefold:
         model.llm.fold_norm_weights()
         torch.cuda.synchronize()
-    model.llm.chain_x_offset = args.x_offset
     l = cfg.llm
     w_bytes = 2.0 * (l.layers * (4 * l.hidden * l.hidden + 3 * l.hidden * l.ffn) + l.vocab * l.hidden)
     T0 = 36 + 255

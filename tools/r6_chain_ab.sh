@@ -28,6 +28,8 @@ for rep in 1 2; do
     set -- $c; n=$1; shift
     run ${n}_chain_$rep "$*"
     run ${n}_five_$rep "$* --no-decode-chain"
+    run ${n}_five_encfirst_$rep "$* --no-decode-chain --sam-beside-decode off --sam-caps off"
+    run ${n}_chain_late_$rep "$* --sam-beside-decode on"
   done
 done
 for c in "b4 --batch 4 --steps 20 --warmup 4" "b8 --batch 8 --steps 16 --warmup 4" "13b_b8 --config 13b --batch 8 --sam-chunk 8 --steps 10 --warmup 3"; do
