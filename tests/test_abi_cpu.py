@@ -70,6 +70,23 @@ def test_stream_caps_are_per_stream_and_thread_safe():
     assert not bad
 
 
+def test_decode_chain_geometry_checks_run_on_the_host():
+    """haff_decode_chain_supported / _sync_words are host arithmetic (no launch): the chained decode step takes <= 8 rows, head dim 128,
+    hidden and ffn multiples of 256 (its K halves are whole 32-deep k-steps per wave), <= 48 layers; the counter buffer holds 16 lines
+    per (layer, stage), one error line, one ticket per K-split tile. haff_decode_chain_bf16 refuses bad arguments before touching the GPU."""
+    lib = haff.load_library()
+    sup = lambda *a: int(lib.haff_decode_chain_supported(*a))   # noqa: E731
+    assert sup(1, 4096, 11008, 32, 32) == 3 * 256 + 32 + 512 + 688 + 512        # 7B, one row: workgroups per layer
+    assert sup(8, 5120, 13824, 40, 40) == 3 * 320 + 8 * 40 + 640 + 864 + 640    # 13B, 8 rows
+    assert sup(9, 4096, 11008, 32, 32) == 0 and sup(0, 4096, 11008, 32, 32) == 0
+    assert sup(8, 4096, 11008, 64, 32) == 0 and sup(8, 4096, 11136, 32, 32) == 0 and sup(8, 4224, 11008, 33, 32) == 0
+    assert sup(8, 4096, 11008, 32, 49) == 0 and sup(8, 16384, 11008, 128, 4) == 0
+    words = int(lib.haff_decode_chain_sync_words(32, 4096))
+    assert words == 32 * 5 * 16 * 32 + 32 + 32 * 2 * 256 and int(lib.haff_decode_chain_sync_words(0, 4096)) == 0
+    assert int(lib.haff_decode_chain_bf16(None, 32, 1, 4096, 11008, 32, *([None] * 8), 1e-5, None, None, 299, 0.088, None, 0, None)) == -1
+    assert int(lib.haff_decode_chain_status(None, 32, None)) == -1
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
