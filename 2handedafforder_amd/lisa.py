@@ -57,12 +57,13 @@ class LisaMI355:
         # captured once per (batch, position) into a hipGraph and replayed. The KV cache is persistent per
         # (batch, capacity) so the captured pointers stay valid across evaluate() calls.
         self.decode_graphs = True
-        # Decode steps of <= 8 rows as ONE chained launch per step (LlamaHip.decode_chain, csrc/decode_chain.hip). "auto": whenever no
-        # CAPPED encoder pass runs beside the decode steps (round 6, same-box A/B with the final synchronisation: decode step 3.24 ->
-        # 3.10 ms at one row, one frame 41.3 -> 40.5 ms, three frames 57.3 -> 56.3; beside an encoder capped to 128..192 CUs the
-        # chained launch's 64 000 workgroups keep refilling every slot of every CU and the two streams starve each other — 4 / 8
-        # frames lose 15..20 % — so there the five short launches per layer and the plan's caps stay). True / False force it for
-        # evaluate(); generate() called directly follows LlamaHip.decode_chain.
+        # Decode steps of <= 8 rows as ONE chained launch per step (LlamaHip.decode_chain, csrc/decode_chain.hip). "auto": below
+        # overlap.MIN_FRAMES (4) frames per call (round 6, same box: decode step 3.25 -> 3.11 ms at one row, one frame 41.3 -> 40.6 ms,
+        # three frames 57.8 -> 56.7). From 4 frames on the plan caps the encoder to 128..192 CUs beside the decode steps, and there a
+        # chained step's 80 000 workgroups keep refilling every slot of every CU while the encoder's one-per-CU launches wait — 4 / 8
+        # frames lose 20..25 % — so the five short launches per layer stay. The choice depends on the batch alone, not on the schedule
+        # (streams, caps): every schedule of a batch gives the same bits. True: chained at any batch <= 8 (A/B); False: never.
+        # generate() called directly follows LlamaHip.decode_chain.
         self.decode_chain = "auto"
         # evaluate(): the last Llama layer of the prefill runs o_proj / MLP / final norm on the rows that are read only (LlamaHip.forward,
         # keep_rows; round 6). False: every row (A/B; generate() called directly always returns every row)
@@ -409,11 +410,17 @@ class LisaMI355:
         # too; at 64 frames the encoder is 60 % of the step and has to start first)
         late = self.overlap_streams and self.sam_beside_decode is not False and \
             (self.sam_beside_decode is True or input_ids.shape[0] <= 16)
-        chain_rows = self.llm.decode_chain and self.decode_chain is not False and input_ids.shape[0] <= self.llm.carry_rms_max_rows
-        if chain_rows and self.decode_chain == "auto" and self.sam_beside_decode is None and input_ids.shape[0] < overlap.MIN_FRAMES:
-            # 1..3 frames, chained decode steps: the encoder FIRST (beside CLIP + prefill), the steps alone behind it — a chained step is
-            # one 3 ms launch whose workgroups hold every CU, the encoder's launches cannot slip in between (same box, one frame:
-            # encoder first + chain 40.5 ms, behind the prefill + five launches 41.3, behind the prefill + chain 41.8)
+        # Which kernels decode: a function of the BATCH alone, never of the schedule (every schedule of one batch must give the same
+        # bits: tests/test_lisa_gpu.py::test_stream_schedules_do_not_change_results, tools/two_stream_soak.py). "auto": the chained
+        # launch below overlap.MIN_FRAMES frames — where no encoder pass is ever capped beside the decode steps — five launches per
+        # layer from there on (the plan caps the encoder beside them; a chained step would starve it: the comment at decode_chain).
+        n_rows = input_ids.shape[0]
+        chain_now = bool(self.llm.decode_chain) and n_rows <= self.llm.carry_rms_max_rows and \
+            (self.decode_chain is True or (self.decode_chain == "auto" and n_rows < overlap.MIN_FRAMES))
+        if chain_now and self.decode_chain == "auto" and self.sam_beside_decode is None:
+            # chained decode steps: the encoder FIRST (beside CLIP + prefill), the steps alone behind it — a chained step is one 3 ms
+            # launch whose workgroups hold every CU, the encoder's launches cannot slip in between (same box, one frame: encoder
+            # first + chain 40.6 ms, behind the prefill + five launches 41.3, behind the prefill + chain 41.8-42.1)
             late = False
         # ... and which CUs its GEMM launches leave to the decode steps (overlap.py)
         n_frames = input_ids.shape[0]
@@ -431,13 +438,9 @@ class LisaMI355:
             if self.sam_waits_for_prefill != "auto":
                 wait = bool(self.sam_waits_for_prefill) and late
         self._plan = self.last_plan = (caps, wait, chunk)
-        capped = bool(caps) and any(c < 256 for c in caps)
         chain_prev = self.llm.decode_chain
-        if self.decode_chain == "auto":
-            self.llm.decode_chain = chain_prev and not capped
-        elif self.decode_chain is False:
-            self.llm.decode_chain = False
-        self.last_decode_chain = bool(chain_rows and self.llm.decode_chain)
+        self.llm.decode_chain = chain_prev if chain_now else False
+        self.last_decode_chain = chain_now
         if not late:
             launch_sam()
         try:

@@ -152,19 +152,19 @@ def test_full_size_13b_batch8_config(dev):
     # the encoder behind the prefill, on about half the CUs beside the decode steps (the cap follows this device's rates)
     from haff import overlap
     assert model.last_plan[1:] == (True, 8) and len(model.last_plan[0]) == 1 and model.last_plan[0][0] in overlap.CAPS[:2], model.last_plan
-    assert not model.last_decode_chain     # beside a capped encoder pass the decode steps stay five launches per layer (lisa.py, decode_chain "auto")
+    assert not model.last_decode_chain     # from 4 frames on the decode steps stay five launches per layer (lisa.py, decode_chain "auto")
     b = run()
     assert all(torch.equal(x, y) for x, y in zip(a, b)), "13B step is not deterministic"
     model.sam_chunk_caps = None
-    model.decode_chain = False             # (the same decode kernels as above: the cap is scheduling only)
     b = run()
     assert model.last_plan[0] is None and not model.last_decode_chain
     assert all(torch.equal(x, y) for x, y in zip(a, b)), "the workgroup cap changed the result (13B)"
-    model.decode_chain = "auto"            # no capped pass beside them: the decode steps are ONE chained launch each (csrc/decode_chain.hip)
+    model.decode_chain = True              # forced: ONE chained launch per decode step (csrc/decode_chain.hip), 40 layers, 8 rows
     c = run()
     assert model.last_decode_chain
     assert torch.equal(c[0], a[0]) and all(torch.equal(x, y) for x, y in zip(c, run())), "chained decode steps are not deterministic (13B)"
     assert (c[1] - a[1]).abs().max().item() <= 5e-2 * a[1].abs().max().item() and (c[2] - a[2]).abs().max().item() <= 2e-2
+    model.decode_chain = "auto"
     model.sam_chunk_caps = "auto"
     model.decode_graphs = False
     c = run()
